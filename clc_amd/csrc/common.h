@@ -1,0 +1,52 @@
+// Internal helpers shared by the HIP translation units of libclc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/clc_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void clc_set_error(const char* fmt, ...);
+
+#define CLC_CHECK(cond, ...)            \
+  do {                                  \
+    if (!(cond)) {                      \
+      clc_set_error(__VA_ARGS__);       \
+      return -1;                        \
+    }                                   \
+  } while (0)
+
+#define CLC_LAUNCH_CHECK()                                              \
+  do {                                                                  \
+    hipError_t e_ = hipGetLastError();                                  \
+    if (e_ != hipSuccess) {                                             \
+      clc_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return -2;                                                        \
+    }                                                                   \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case CLC_ACT_LRELU: return v > 0.f ? v : 0.01f * v;
+    case CLC_ACT_RELU: return v > 0.f ? v : 0.f;
+    case CLC_ACT_GELU: return gelu_f(v);
+    default: return v;
+  }
+}
+
+// wave64 sum
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

@@ -1,0 +1,366 @@
+// conv_igemm.hip — NHWC fp32 convolution as implicit GEMM on v_mfma_f32_32x32x2_f32 (gfx950).
+//
+// Replaces the cuDNN forward / backward-data kernels behind every nn.Conv2d / nn.Linear of the
+// CLC hot path (/root/reference/models/CLC_run.py:120,123,185-187,207-208,273-277,335-354,
+// 412-481; CompressAI layers).
+//
+// GEMM view:  M = output pixels, N = output channels, K = (tap, input channel).
+//   A[m][k] is gathered from the NHWC input (zero outside the image), B[n][k] is the filter
+//   row [Cout][tap][Cin] — both K-contiguous, so one LDS image serves both: [rows][32+4] floats,
+//   16-B global loads -> ds_write_b128, fragments by ds_read_b128.
+// The f32 MFMA takes ONE float per lane per operand (lane l: A[i=l&31][k=l>>5]); a lane reads 4
+// consecutive k with one ds_read_b128 and feeds 4 MFMAs from it, i.e. MFMA step (t,s) contracts
+// the physical k pair {8t+s, 8t+4+s}.  A and B use the same pairing, so the sum is exact; only
+// the (fixed, shape-independent) accumulation order differs from a k-ascending loop.
+// The accumulation order per output element depends only on (ks, Cin) — never on the tile
+// shape, the batch size or the launch grid — so results are identical across tile configs.
+//
+// f32 MFMA runs at the f32 vector rate (64 cyc per 32x32x2): the kernel is MFMA-bound, LDS and
+// HBM traffic are far from their limits (arithmetic intensity >> the 25 FLOP/B ridge), so the
+// structure is a plain double-buffered LDS pipeline with register prefetch, 2 workgroups/CU.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;   // K-tile (floats)
+constexpr int LD = 36;   // LDS row stride (floats): 9 16-B slots -> conflict-free b128 reads
+
+struct ConvParams {
+  const float* x; const float* w; const float* bias; float* y;
+  const float* mul; const float* res; float* y_pre;
+  int N, H, W, Cin, ldx;       // source tensor geometry
+  int OH, OW, Cout, ldy;       // destination geometry (pre-shuffle)
+  int ks, stride, pad, transposed, in_op, act, norm, shuffle;
+  int ldm, ldr, ldp, ldw;
+  float res_scale;
+  int M;                       // rows per class (transposed&stride2: per parity class)
+  int kc_tiles;                // ceil(Cin/32)
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (64 * WM * WN) >= 256 ? 2 : 4)
+void conv_igemm_kernel(const ConvParams p) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_P = (BM * 8 + NT - 1) / NT, B_P = (BN * 8 + NT - 1) / NT;
+  static_assert(TM >= 1 && TN >= 1, "tile");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                    // [2][BM][LD]
+  float* Bs = smem + 2 * BM * LD;      // [2][BN][LD]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // parity class for the transposed stride-2 case (dgrad of a strided conv)
+  const int cls = blockIdx.z, ph = cls >> 1, pw = cls & 1;
+  const int s = p.stride;
+  const int DH = (p.transposed && s == 2) ? p.OH / 2 : p.OH;   // decode dims of m
+  const int DW = (p.transposed && s == 2) ? p.OW / 2 : p.OW;
+
+  // ---- per-thread gather rows (fixed over the K loop) ----
+  int a_base[A_P], a_y0[A_P], a_x0[A_P];
+  bool a_ok[A_P];
+#pragma unroll
+  for (int i = 0; i < A_P; ++i) {
+    const int piece = tid + i * NT, row = piece >> 3;
+    const int m = m0 + row;
+    a_ok[i] = (row < BM) && (m < p.M);
+    const int mm = a_ok[i] ? m : 0;
+    const int n = mm / (DH * DW), r = mm - n * (DH * DW);
+    int oy = r / DW, ox = r - oy * DW;
+    if (p.transposed) {
+      if (s == 2) { oy = 2 * oy + ph; ox = 2 * ox + pw; }
+      a_y0[i] = oy + p.pad; a_x0[i] = ox + p.pad;
+    } else {
+      a_y0[i] = oy * s - p.pad; a_x0[i] = ox * s - p.pad;
+    }
+    a_base[i] = n * p.H * p.W;
+  }
+  const int c4 = (tid & 7) * 4;
+
+  f32x4 a_reg[A_P], b_reg[B_P];
+
+  auto load_tile = [&](int kh, int kw, int kc) {
+    const int c = kc * BK + c4;
+    const bool c_ok = c < p.Cin;
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) {
+      int iy, ix; bool ok = a_ok[i] && c_ok;
+      if (p.transposed) {
+        const int ty = a_y0[i] - kh, tx = a_x0[i] - kw;
+        ok = ok && ty >= 0 && tx >= 0 && ((ty | tx) & (s - 1)) == 0;
+        iy = ty >> (s - 1); ix = tx >> (s - 1);
+        ok = ok && iy < p.H && ix < p.W;
+      } else {
+        iy = a_y0[i] + kh; ix = a_x0[i] + kw;
+        ok = ok && iy >= 0 && ix >= 0 && iy < p.H && ix < p.W;
+      }
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(a_base[i] + iy * p.W + ix) * p.ldx + c);
+      if (p.in_op == CLC_IN_SQUARE) v = v * v;
+      a_reg[i] = v;
+    }
+    const int tap = kh * p.ks + kw;
+#pragma unroll
+    for (int i = 0; i < B_P; ++i) {
+      const int piece = tid + i * NT, row = piece >> 3, co = n0 + row;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < BN && co < p.Cout && c_ok) v = *reinterpret_cast<const f32x4*>(p.w + (size_t)co * p.ldw + tap * p.Cin + c);
+      b_reg[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) {
+      const int piece = tid + i * NT, row = piece >> 3;
+      if (row < BM) *reinterpret_cast<f32x4*>(As + (buf * BM + row) * LD + c4) = a_reg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_P; ++i) {
+      const int piece = tid + i * NT, row = piece >> 3;
+      if (row < BN) *reinterpret_cast<f32x4*>(Bs + (buf * BN + row) * LD + c4) = b_reg[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- K loop over (tap, channel tile); taps of the wrong parity are skipped block-uniformly ----
+  const int ntaps = p.ks * p.ks;
+  auto tap_live = [&](int t) -> bool {
+    if (!(p.transposed && s == 2)) return true;
+    const int kh = t / p.ks, kw = t - kh * p.ks;
+    return (((ph + p.pad - kh) & 1) == 0) && (((pw + p.pad - kw) & 1) == 0);
+  };
+  int total = 0;
+  for (int t = 0; t < ntaps; ++t) total += tap_live(t) ? p.kc_tiles : 0;
+
+  int t_cur = 0, kc_cur = 0;
+  auto advance = [&]() {  // move (t_cur, kc_cur) to the next live tile
+    if (++kc_cur == p.kc_tiles) { kc_cur = 0; ++t_cur; while (t_cur < ntaps && !tap_live(t_cur)) ++t_cur; }
+  };
+  while (t_cur < ntaps && !tap_live(t_cur)) ++t_cur;
+
+  if (total > 0) {
+    load_tile(t_cur / p.ks, t_cur % p.ks, kc_cur);
+    store_tile(0);
+    __syncthreads();
+  }
+  const int frag_col = 4 * (lane >> 5);
+  for (int it = 0; it < total; ++it) {
+    const int buf = it & 1;
+    const bool more = it + 1 < total;
+    if (more) { advance(); load_tile(t_cur / p.ks, t_cur % p.ks, kc_cur); }
+    const float* Ab = As + (buf * BM + wm * (BM / WM) + (lane & 31)) * LD + frag_col;
+    const float* Bb = Bs + (buf * BN + wn * (BN / WN) + (lane & 31)) * LD + frag_col;
+#pragma unroll
+    for (int t8 = 0; t8 < 4; ++t8) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LD + t8 * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LD + t8 * 8);
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][ss], bf[j][ss], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D map col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel) ----
+  const int col = lane & 31, rhalf = 4 * (lane >> 5);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + wn * (BN / WN) + j * 32 + col;
+    if (co >= p.Cout) continue;
+    const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + rhalf;
+        const int m = m0 + wm * (BM / WM) + i * 32 + row;
+        if (m >= p.M) continue;
+        size_t pix; int ch = co;
+        if (p.transposed && s == 2) {
+          const int n = m / (DH * DW), rr = m - n * (DH * DW);
+          const int oy = rr / DW, ox = rr - oy * DW;
+          pix = (size_t)(n * p.OH + 2 * oy + ph) * p.OW + 2 * ox + pw;
+        } else if (p.shuffle) {
+          const int n = m / (p.OH * p.OW), rr = m - n * (p.OH * p.OW);
+          const int oy = rr / p.OW, ox = rr - oy * p.OW;
+          ch = co >> 2;
+          pix = (size_t)(n * 2 * p.OH + 2 * oy + ((co >> 1) & 1)) * (2 * p.OW) + 2 * ox + (co & 1);
+        } else {
+          pix = (size_t)m;
+        }
+        float v = acc[i][j][r] + bv;
+        if (p.y_pre) p.y_pre[pix * p.ldp + ch] = v;
+        if (p.norm != CLC_NORM_NONE) {
+          const float mv = p.mul[pix * p.ldm + ch];
+          v = (p.norm == CLC_NORM_GDN) ? mv * rsqrtf(v) : mv * sqrtf(v);
+        }
+        v = apply_act(v, p.act);
+        if (p.res) v += p.res_scale * p.res[pix * p.ldr + ch];
+        p.y[pix * p.ldy + ch] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch(const ConvParams& p, int classes, hipStream_t st) {
+  dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, classes);
+  const size_t lds = (size_t)2 * (BM + BN) * LD * sizeof(float);
+  static bool attr_set = false;  // >64 KiB of dynamic LDS needs an explicit opt-in (first call happens before any graph capture)
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(64 * WM * WN), lds, st, p);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+
+// small-Cin (image, Cin<=4, unaligned) direct convolution: one thread per (pixel, 4 output channels)
+__global__ void conv_direct_small_kernel(const ConvParams p) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cgroups = (p.Cout + 3) / 4;
+  const long total = (long)p.M * cgroups;
+  if (idx >= total) return;
+  const int cg = (int)(idx % cgroups);
+  const int m = (int)(idx / cgroups);
+  const int n = m / (p.OH * p.OW), rr = m - n * (p.OH * p.OW);
+  const int oy = rr / p.OW, ox = rr - oy * p.OW;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int kh = 0; kh < p.ks; ++kh) {
+    const int iy = oy * p.stride - p.pad + kh;
+    if (iy < 0 || iy >= p.H) continue;
+    for (int kw = 0; kw < p.ks; ++kw) {
+      const int ix = ox * p.stride - p.pad + kw;
+      if (ix < 0 || ix >= p.W) continue;
+      const float* xp = p.x + (size_t)((n * p.H + iy) * p.W + ix) * p.ldx;
+      for (int ci = 0; ci < p.Cin; ++ci) {
+        float xv = xp[ci];
+        if (p.in_op == CLC_IN_SQUARE) xv *= xv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = cg * 4 + q;
+          if (co < p.Cout) acc[q] = fmaf(xv, p.w[(size_t)co * p.ldw + (kh * p.ks + kw) * p.Cin + ci], acc[q]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int co = cg * 4 + q;
+    if (co >= p.Cout) continue;
+    float v = acc[q] + (p.bias ? p.bias[co] : 0.f);
+    size_t pix = (size_t)m; int ch = co;
+    if (p.shuffle) {
+      ch = co >> 2;
+      pix = (size_t)(n * 2 * p.OH + 2 * oy + ((co >> 1) & 1)) * (2 * p.OW) + 2 * ox + (co & 1);
+    }
+    if (p.y_pre) p.y_pre[pix * p.ldp + ch] = v;
+    if (p.norm != CLC_NORM_NONE) {
+      const float mv = p.mul[pix * p.ldm + ch];
+      v = (p.norm == CLC_NORM_GDN) ? mv * rsqrtf(v) : mv * sqrtf(v);
+    }
+    v = apply_act(v, p.act);
+    if (p.res) v += p.res_scale * p.res[pix * p.ldr + ch];
+    p.y[pix * p.ldy + ch] = v;
+  }
+}
+
+__global__ void filter_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int T, int Cin) {
+  // w [Cout][T][Cin] -> wt [Cin][T][Cout]; 32x32 LDS tile per (t, co-tile, ci-tile)
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z;
+  const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * T + t) * Cin + ci] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < Cin && co < Cout) wt[((size_t)ci * T + t) * Cout + co] = tile[tx][r];
+  }
+}
+
+}  // namespace
+
+extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  CLC_CHECK(d && d->x && d->w && d->y, "clc_conv2d: null pointer");
+  CLC_CHECK(d->ks == 1 || d->ks == 3, "clc_conv2d: ks must be 1 or 3 (got %d)", d->ks);
+  CLC_CHECK(d->stride == 1 || d->stride == 2, "clc_conv2d: stride must be 1 or 2 (got %d)", d->stride);
+  CLC_CHECK(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->OH > 0 && d->OW > 0, "clc_conv2d: bad dims");
+  CLC_CHECK(d->ldx >= d->Cin, "clc_conv2d: ldx < Cin");
+  if (!d->transposed) {
+    CLC_CHECK(d->OH == (d->H + 2 * d->pad - d->ks) / d->stride + 1 && d->OW == (d->W + 2 * d->pad - d->ks) / d->stride + 1,
+              "clc_conv2d: output dims %dx%d inconsistent with input %dx%d ks=%d s=%d pad=%d", d->OH, d->OW, d->H, d->W, d->ks, d->stride, d->pad);
+  } else {
+    CLC_CHECK(d->H == (d->OH + 2 * d->pad - d->ks) / d->stride + 1 && d->W == (d->OW + 2 * d->pad - d->ks) / d->stride + 1,
+              "clc_conv2d(transposed): dY dims %dx%d inconsistent with dX %dx%d", d->H, d->W, d->OH, d->OW);
+    CLC_CHECK(d->stride == 1 || (d->OH % 2 == 0 && d->OW % 2 == 0), "clc_conv2d(transposed,s2): odd dX dims");
+    CLC_CHECK(!d->shuffle, "clc_conv2d: shuffle with transposed");
+  }
+  CLC_CHECK(!d->shuffle || d->Cout % 4 == 0, "clc_conv2d: shuffle needs Cout %% 4 == 0");
+  CLC_CHECK(d->norm == CLC_NORM_NONE || d->mul, "clc_conv2d: norm without mul");
+  const int och = d->shuffle ? d->Cout / 4 : d->Cout;
+  CLC_CHECK(d->ldy >= och, "clc_conv2d: ldy < channels");
+  CLC_CHECK((long)d->N * d->H * d->W < (1l << 31) / 1 && (long)d->N * d->OH * d->OW * (d->shuffle ? 4 : 1) < (1l << 31), "clc_conv2d: too many pixels");
+
+  ConvParams p;
+  p.x = d->x; p.w = d->w; p.bias = d->bias; p.y = d->y; p.mul = d->mul; p.res = d->res; p.y_pre = d->y_pre;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.ldx = d->ldx;
+  p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout; p.ldy = d->ldy;
+  p.ks = d->ks; p.stride = d->stride; p.pad = d->pad; p.transposed = d->transposed; p.in_op = d->in_op;
+  p.act = d->act; p.norm = d->norm; p.shuffle = d->shuffle;
+  p.ldm = d->ldm; p.ldr = d->ldr; p.ldp = d->ldp; p.ldw = d->ks * d->ks * d->Cin; p.res_scale = d->res_scale;
+  p.kc_tiles = (d->Cin + BK - 1) / BK;
+  int classes = 1;
+  p.M = d->N * d->OH * d->OW;
+  if (d->transposed && d->stride == 2) { classes = 4; p.M = d->N * (d->OH / 2) * (d->OW / 2); }
+
+  const bool vec_ok = (d->Cin % 4 == 0) && (d->ldx % 4 == 0) && aligned16(d->x) && aligned16(d->w);
+  if (!vec_ok) {
+    CLC_CHECK(!d->transposed, "clc_conv2d: unaligned/small-Cin path has no transposed mode (Cin=%d ldx=%d)", d->Cin, d->ldx);
+    const int cgroups = (d->Cout + 3) / 4;
+    const long total = (long)p.M * cgroups;
+    hipLaunchKernelGGL(conv_direct_small_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    CLC_LAUNCH_CHECK();
+    return 0;
+  }
+  // tile selection: depends on (M, Cout) only for speed; numerics are tile-independent (see header)
+  const long M = p.M;
+  const int C = d->Cout;
+  auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((C + bn - 1) / bn) * classes; };
+  const bool n128 = (C % 128 == 0) || C >= 384;
+  const bool n64 = (C % 64 == 0) || C > 64;
+  if (n128 && blocks(128, 128) >= 384) return launch<128, 128, 2, 2>(p, classes, st);
+  if (n64 && blocks(128, 64) >= 384) return launch<128, 64, 2, 2>(p, classes, st);
+  if (n64 && blocks(64, 64) >= 256) return launch<64, 64, 2, 2>(p, classes, st);
+  if (blocks(64, 32) >= 256 || M >= 4096) return launch<64, 32, 2, 1>(p, classes, st);
+  return launch<32, 32, 1, 1>(p, classes, st);
+}
+
+extern "C" int clc_filter_transpose(const float* w, float* wt, int Cout, int T, int Cin, clc_stream_t stream) {
+  CLC_CHECK(w && wt && Cout > 0 && T > 0 && Cin > 0, "clc_filter_transpose: bad args");
+  dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, T);
+  hipLaunchKernelGGL(filter_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wt, Cout, T, Cin);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,286 @@
+// conv_wgrad.hip — filter gradient of the NHWC fp32 convolutions on v_mfma_f32_32x32x2_f32 (gfx950).
+//
+// Replaces cuDNN backward-weight behind loss.backward() (/root/reference/train_CLC.py:159) for
+// every conv / linear of the path.
+//
+// GEMM view:  dW[co][tap][ci] = sum_pix dY[pix][co] * in_op(X[pix@tap][ci])
+//   M = co, N = ci (one filter tap per workgroup column), K = output pixels.
+// Both operands are K-major in memory (pixel rows, channel-contiguous), so the LDS images are
+// [k][M] and [k][N]: 16-B coalesced loads -> ds_write_b128, fragments by conflict-free
+// ds_read_b32 (lane i reads column i of row k).  K is split over blockIdx.z; every split writes
+// its own partial slab and a second kernel sums the slabs in a fixed order -> bitwise
+// reproducible (no float atomics; train_CLC.py:28-29 asks for deterministic kernels).
+// The bias gradient (column sums of dY) rides along in the workgroups of the first column.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+
+struct WgradParams {
+  const float* x; const float* dy; float* partial; float* bias_partial;
+  int N, H, W, Cin, ldx;
+  int OH, OW, Cout, lddy;
+  int ks, stride, pad, in_op;
+  int K;            // total pixels N*OH*OW
+  int k_per_split;  // multiple of BK
+  int nci;          // ci tiles
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2)
+void conv_wgrad_kernel(const WgradParams p) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_P = (BK * BM / 4 + NT - 1) / NT, B_P = (BK * BN / 4 + NT - 1) / NT;
+  constexpr int AQ = BM / 4, BQ = BN / 4;  // float4 pieces per row
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                 // [2][BK][BM]
+  float* Bs = smem + 2 * BK * BM;   // [2][BK][BN]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tap = blockIdx.x / p.nci, ci0 = (blockIdx.x % p.nci) * BN;
+  const int kh = tap / p.ks, kw = tap - kh * p.ks;
+  const int co0 = blockIdx.y * BM;
+  const int split = blockIdx.z;
+  const int k_begin = split * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int ntiles = (k_end - k_begin + BK - 1) / BK;
+  const bool do_bias = (p.bias_partial != nullptr) && (blockIdx.x == 0);
+
+  f32x4 a_reg[A_P], b_reg[B_P], bias_acc[A_P];
+#pragma unroll
+  for (int i = 0; i < A_P; ++i) bias_acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto load_tile = [&](int kt) {
+    const int kbase = k_begin + kt * BK;
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) {
+      const int piece = tid + i * NT, row = piece / AQ, q = piece - row * AQ;
+      const int pix = kbase + row, co = co0 + q * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < BK && pix < k_end && co < p.Cout) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)pix * p.lddy + co);
+      a_reg[i] = v;
+      if (do_bias) bias_acc[i] += v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_P; ++i) {
+      const int piece = tid + i * NT, row = piece / BQ, q = piece - row * BQ;
+      const int pix = kbase + row, ci = ci0 + q * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < BK && pix < k_end && ci < p.Cin) {
+        const int n = pix / (p.OH * p.OW), r = pix - n * (p.OH * p.OW);
+        const int oy = r / p.OW, ox = r - oy * p.OW;
+        const int iy = oy * p.stride - p.pad + kh, ix = ox * p.stride - p.pad + kw;
+        if (iy >= 0 && ix >= 0 && iy < p.H && ix < p.W) {
+          v = *reinterpret_cast<const f32x4*>(p.x + (size_t)((n * p.H + iy) * p.W + ix) * p.ldx + ci);
+          if (p.in_op == CLC_IN_SQUARE) v = v * v;
+        }
+      }
+      b_reg[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) {
+      const int piece = tid + i * NT, row = piece / AQ, q = piece - row * AQ;
+      if (row < BK) *reinterpret_cast<f32x4*>(As + (buf * BK + row) * BM + q * 4) = a_reg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_P; ++i) {
+      const int piece = tid + i * NT, row = piece / BQ, q = piece - row * BQ;
+      if (row < BK) *reinterpret_cast<f32x4*>(Bs + (buf * BK + row) * BN + q * 4) = b_reg[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (ntiles > 0) {
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+  }
+  const int khalf = lane >> 5, li = lane & 31;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < ntiles;
+    if (more) load_tile(kt + 1);
+    const float* Ab = As + (buf * BK + khalf) * BM + wm * (BM / WM) + li;
+    const float* Bb = Bs + (buf * BK + khalf) * BN + wn * (BN / WN) + li;
+#pragma unroll
+    for (int ss = 0; ss < BK / 2; ++ss) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = Ab[(2 * ss) * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Bb[(2 * ss) * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // partial slab [split][Cout][T][Cin]
+  const int T = p.ks * p.ks;
+  float* slab = p.partial + (size_t)split * p.Cout * T * p.Cin;
+  const int rhalf = 4 * (lane >> 5);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int ci = ci0 + wn * (BN / WN) + j * 32 + li;
+    if (ci >= p.Cin) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+        if (co < p.Cout) slab[((size_t)co * T + tap) * p.Cin + ci] = acc[i][j][r];
+      }
+  }
+
+  if (do_bias) {  // reduce the per-thread column sums over the BK rows through LDS (fixed order)
+    __syncthreads();
+    float* red = smem;  // [BK][BM]
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) {
+      const int piece = tid + i * NT, row = piece / AQ, q = piece - row * AQ;
+      if (row < BK) *reinterpret_cast<f32x4*>(red + row * BM + q * 4) = bias_acc[i];
+    }
+    __syncthreads();
+    for (int c = tid; c < BM; c += NT) {
+      float s = 0.f;
+      for (int r = 0; r < BK; ++r) s += red[r * BM + c];
+      if (co0 + c < p.Cout) p.bias_partial[(size_t)split * p.Cout + co0 + c] = s;
+    }
+  }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, long n, int splits, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = accumulate ? out[i] : 0.f;
+  for (int k = 0; k < splits; ++k) s += partial[(size_t)k * n + i];
+  out[i] = s;
+}
+
+// small / unaligned Cin (the RGB input conv): plain VALU, one workgroup per (co, split)
+__global__ void wgrad_small_kernel(const WgradParams p, int splits) {
+  // thread t handles column j = t (tap, ci) if j < T*Cin ; loops over the split's pixels
+  const int co = blockIdx.x, split = blockIdx.y;
+  const int T = p.ks * p.ks, ncol = T * p.Cin;
+  const int j = threadIdx.x;
+  const int k_begin = split * p.k_per_split, k_end = min(p.K, k_begin + p.k_per_split);
+  float acc = 0.f, bsum = 0.f;
+  if (j < ncol) {
+    const int tap = j / p.Cin, ci = j - tap * p.Cin, kh = tap / p.ks, kw = tap - kh * p.ks;
+    for (int pix = k_begin; pix < k_end; ++pix) {
+      const float g = p.dy[(size_t)pix * p.lddy + co];
+      const int n = pix / (p.OH * p.OW), r = pix - n * (p.OH * p.OW);
+      const int oy = r / p.OW, ox = r - oy * p.OW;
+      const int iy = oy * p.stride - p.pad + kh, ix = ox * p.stride - p.pad + kw;
+      if (iy >= 0 && ix >= 0 && iy < p.H && ix < p.W) {
+        float xv = p.x[(size_t)((n * p.H + iy) * p.W + ix) * p.ldx + ci];
+        if (p.in_op == CLC_IN_SQUARE) xv *= xv;
+        acc = fmaf(g, xv, acc);
+      }
+      bsum += g;
+    }
+    p.partial[((size_t)split * p.Cout + co) * ncol + j] = acc;
+    if (j == 0 && p.bias_partial) p.bias_partial[(size_t)split * p.Cout + co] = bsum;
+  }
+}
+
+struct Plan { int bm, bn, splits, k_per_split, nci; bool small; };
+
+Plan make_plan(const clc_wgrad_desc* d) {
+  Plan pl;
+  const long K = (long)d->N * d->OH * d->OW;
+  const int T = d->ks * d->ks;
+  pl.small = !((d->Cin % 4 == 0) && (d->ldx % 4 == 0) && (d->Cout % 4 == 0) && (d->lddy % 4 == 0));
+  if (pl.small) {
+    pl.bm = pl.bn = 0; pl.nci = 1;
+    int splits = (int)((K + 2047) / 2048);
+    if (splits < 1) splits = 1;
+    if (splits > 256) splits = 256;
+    long kps = (K + splits - 1) / splits;
+    pl.k_per_split = (int)kps; pl.splits = (int)((K + kps - 1) / kps);
+    return pl;
+  }
+  pl.bm = (d->Cout >= 128) ? 128 : 64;
+  pl.bn = (d->Cin >= 128 && d->Cin % 128 == 0) ? 128 : 64;
+  if (pl.bm == 128 && pl.bn == 128 && (long)((d->Cout + 127) / 128) * ((d->Cin + 127) / 128) * T < 8 && K < 16384) pl.bn = 64;
+  pl.nci = (d->Cin + pl.bn - 1) / pl.bn;
+  const long tiles = (long)((d->Cout + pl.bm - 1) / pl.bm) * pl.nci * T;
+  long splits = (768 + tiles - 1) / tiles;          // aim for >= ~3 workgroups per CU
+  const long max_splits = (K + 511) / 512;           // >= 16 K-tiles per split
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  long kps = (K + splits - 1) / splits;
+  kps = (kps + BK - 1) / BK * BK;
+  pl.k_per_split = (int)kps;
+  pl.splits = (int)((K + kps - 1) / kps);
+  return pl;
+}
+
+}  // namespace
+
+extern "C" size_t clc_conv2d_wgrad_workspace_bytes(const clc_wgrad_desc* d) {
+  if (!d) return 0;
+  Plan pl = make_plan(d);
+  const size_t wsz = (size_t)d->Cout * d->ks * d->ks * d->Cin;
+  return ((size_t)pl.splits * (wsz + d->Cout) + 64) * sizeof(float);
+}
+
+extern "C" int clc_conv2d_wgrad(const clc_wgrad_desc* d, clc_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  CLC_CHECK(d && d->x && d->dy && d->dw, "clc_conv2d_wgrad: null pointer");
+  CLC_CHECK(d->ks == 1 || d->ks == 3, "clc_conv2d_wgrad: ks must be 1 or 3");
+  CLC_CHECK(d->stride == 1 || d->stride == 2, "clc_conv2d_wgrad: stride must be 1 or 2");
+  CLC_CHECK(d->OH == (d->H + 2 * d->pad - d->ks) / d->stride + 1 && d->OW == (d->W + 2 * d->pad - d->ks) / d->stride + 1,
+            "clc_conv2d_wgrad: output dims inconsistent");
+  CLC_CHECK(d->ldx >= d->Cin && d->lddy >= d->Cout, "clc_conv2d_wgrad: ld too small");
+  CLC_CHECK((long)d->N * d->H * d->W < (1l << 31) && (long)d->N * d->OH * d->OW < (1l << 31), "clc_conv2d_wgrad: too many pixels");
+  CLC_CHECK(d->workspace && d->workspace_bytes >= clc_conv2d_wgrad_workspace_bytes(d), "clc_conv2d_wgrad: workspace too small");
+  Plan pl = make_plan(d);
+  const int T = d->ks * d->ks;
+  const size_t wsz = (size_t)d->Cout * T * d->Cin;
+  WgradParams p;
+  p.x = d->x; p.dy = d->dy;
+  p.partial = (float*)d->workspace;
+  p.bias_partial = d->dbias ? p.partial + (size_t)pl.splits * wsz : nullptr;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.ldx = d->ldx;
+  p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout; p.lddy = d->lddy;
+  p.ks = d->ks; p.stride = d->stride; p.pad = d->pad; p.in_op = d->in_op;
+  p.K = d->N * d->OH * d->OW; p.k_per_split = pl.k_per_split; p.nci = pl.nci;
+  if (pl.small) {
+    CLC_CHECK(T * d->Cin <= 256, "clc_conv2d_wgrad: small path needs ks*ks*Cin <= 256");
+    hipLaunchKernelGGL(wgrad_small_kernel, dim3(d->Cout, pl.splits), dim3(((T * d->Cin + 63) / 64) * 64), 0, st, p, pl.splits);
+    CLC_LAUNCH_CHECK();
+  } else {
+    CLC_CHECK(aligned16(d->x) && aligned16(d->dy), "clc_conv2d_wgrad: unaligned pointers");
+    dim3 grid(pl.nci * T, (d->Cout + pl.bm - 1) / pl.bm, pl.splits);
+    const size_t lds = (size_t)2 * BK * (pl.bm + pl.bn) * sizeof(float);
+    if (pl.bm == 128 && pl.bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), lds, st, p);
+    else if (pl.bm == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 2>), grid, dim3(256), lds, st, p);
+    else if (pl.bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2>), grid, dim3(256), lds, st, p);
+    CLC_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((wsz + 255) / 256)), dim3(256), 0, st, p.partial, d->dw, (long)wsz, pl.splits, d->accumulate);
+  CLC_LAUNCH_CHECK();
+  if (d->dbias) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((d->Cout + 255) / 256), dim3(256), 0, st, p.bias_partial, d->dbias, (long)d->Cout, pl.splits, d->accumulate);
+    CLC_LAUNCH_CHECK();
+  }
+  return 0;
+}

@@ -1,0 +1,340 @@
+// elementwise.hip — HBM-bound fused elementwise / normalisation / reduction kernels (gfx950).
+//
+// Everything here is a streaming pass: 16-B loads where the layout allows, grid-stride loops
+// capped at 2048 workgroups, wave64 shuffles for row reductions, and two-stage (partials ->
+// fixed-order sum) reductions instead of float atomics so results are bitwise reproducible.
+//   * LayerNorm fwd/bwd            nn.LayerNorm in Block, /root/reference/models/CLC_run.py:180,183,191-192
+//   * activation backward          LeakyReLU / ReLU / GELU of the CompressAI blocks and MLPs
+//   * GDN backward pieces          CompressAI GDN
+//   * SWAtten gate fwd/bwd         /root/reference/models/CLC_run.py:241-242
+//   * column sums, axpby, strided slice copy, fixed-order partial sums, squared-difference
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxBlocks = 2048;
+inline int grid_for(long n, int per_block) {
+  long b = (n + per_block - 1) / per_block;
+  return (int)(b < 1 ? 1 : (b > kMaxBlocks ? kMaxBlocks : b));
+}
+
+// ---------------------------------------------------------------- LayerNorm
+// one wave per row; C <= 64*LN_MAX_PER_LANE
+constexpr int LN_MAX_PER_LANE = 8;
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y, int ldy,
+                                                          float* __restrict__ mean, float* __restrict__ rstd, long rows, int C) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per = (C + 63) / 64;
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+    float v[LN_MAX_PER_LANE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+      const int c = lane + i * 64;
+      v[i] = (i < per && c < C) ? x[r * ldx + c] : 0.f;
+      s += v[i];
+    }
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+      const int c = lane + i * 64;
+      const float d = (i < per && c < C) ? v[i] - mu : 0.f;
+      q += d * d;
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)C + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+      const int c = lane + i * 64;
+      if (i < per && c < C) y[r * ldy + c] = (v[i] - mu) * rs * gamma[c] + beta[c];
+    }
+    if (lane == 0 && mean) { mean[r] = mu; rstd[r] = rs; }
+  }
+}
+
+// dx per row; per-block partial dgamma/dbeta -> ws[block][2][C]
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, float* __restrict__ dx, int lddx,
+                                                          float* __restrict__ ws, long rows, int C) {
+  extern __shared__ float sm[];  // [4 waves][2][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per = (C + 63) / 64;
+  float dg[LN_MAX_PER_LANE], db[LN_MAX_PER_LANE];
+#pragma unroll
+  for (int i = 0; i < LN_MAX_PER_LANE; ++i) dg[i] = db[i] = 0.f;
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+    const float mu = mean[r], rs = rstd[r];
+    float g[LN_MAX_PER_LANE], xh[LN_MAX_PER_LANE];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+      const int c = lane + i * 64;
+      const bool ok = (i < per && c < C);
+      const float d = ok ? dy[r * lddy + c] : 0.f;
+      xh[i] = ok ? (x[r * ldx + c] - mu) * rs : 0.f;
+      g[i] = ok ? d * gamma[c] : 0.f;
+      dg[i] += d * xh[i];
+      db[i] += d;
+      s1 += g[i];
+      s2 += g[i] * xh[i];
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+      const int c = lane + i * 64;
+      if (i < per && c < C) dx[r * lddx + c] = rs * (g[i] - s1 - xh[i] * s2);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+    const int c = lane + i * 64;
+    if (i < per && c < C) { sm[(wave * 2 + 0) * C + c] = dg[i]; sm[(wave * 2 + 1) * C + c] = db[i]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * C; c += 256) {
+    const int which = c / C, cc = c - which * C;
+    float s = 0.f;
+    for (int w = 0; w < 4; ++w) s += sm[(w * 2 + which) * C + cc];
+    ws[((size_t)blockIdx.x * 2 + which) * C + cc] = s;
+  }
+}
+
+// out[c] (+)= sum_b ws[b][which][c]
+__global__ void ln_param_reduce_kernel(const float* __restrict__ ws, int nblocks, int C, float* dgamma, float* dbeta, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * C) return;
+  const int which = c / C, cc = c - which * C;
+  float* out = which == 0 ? dgamma : dbeta;
+  float s = accumulate ? out[cc] : 0.f;
+  for (int b = 0; b < nblocks; ++b) s += ws[((size_t)b * 2 + which) * C + cc];
+  out[cc] = s;
+}
+
+// ---------------------------------------------------------------- activation backward
+__global__ void act_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ saved, int lds, int use_pre, int act,
+                               float* __restrict__ dz, int lddz, long rows, int C) {
+  const long total = rows * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    const float g = dy[r * lddy + c], s = saved[r * lds + c];
+    float d;
+    switch (act) {
+      case CLC_ACT_LRELU: d = s > 0.f ? 1.f : 0.01f; break;
+      case CLC_ACT_RELU: d = s > 0.f ? 1.f : 0.f; break;
+      case CLC_ACT_GELU: {
+        const float cdf = 0.5f * (1.0f + erff(s * 0.70710678118654752440f));
+        d = cdf + s * 0.39894228040143267794f * expf(-0.5f * s * s);
+        break;
+      }
+      default: d = 1.f;
+    }
+    dz[r * lddz + c] = g * d;
+  }
+}
+
+// ---------------------------------------------------------------- column sums (two stage)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int ld, long rows, int C, float* __restrict__ ws, long rows_per_block) {
+  // block handles rows [b*rpb, (b+1)*rpb); thread t handles columns t, t+256, ...
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += x[r * ld + c];
+    ws[(size_t)blockIdx.x * C + c] = s;
+  }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ ws, int nblocks, int C, float* out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = accumulate ? out[c] : 0.f;
+  for (int b = 0; b < nblocks; ++b) s += ws[(size_t)b * C + c];
+  out[c] = s;
+}
+
+// ---------------------------------------------------------------- GDN backward pieces
+__global__ void gdn_bwd_elem_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ v,
+                                    float* __restrict__ dxd, float* __restrict__ dv, long n, int inverse) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float g = dy[i], xv = x[i], vv = v[i];
+    if (!inverse) {
+      const float rs = rsqrtf(vv);            // y = x * v^-1/2
+      dxd[i] = g * rs;
+      dv[i] = g * xv * (-0.5f) * rs / vv;     // d/dv v^-1/2 = -1/2 v^-3/2
+    } else {
+      const float sq = sqrtf(vv);             // y = x * v^1/2
+      dxd[i] = g * sq;
+      dv[i] = g * xv * 0.5f / sq;
+    }
+  }
+}
+__global__ void gdn_bwd_combine_kernel(const float* __restrict__ dxd, const float* __restrict__ x, const float* __restrict__ t,
+                                       float* __restrict__ dx, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dx[i] = dxd[i] + 2.f * x[i] * t[i];
+}
+
+// ---------------------------------------------------------------- gate
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__global__ void gate_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ idn, float* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = a[i] * sigmoidf_(b[i]) + idn[i];
+}
+__global__ void gate_bwd_kernel(const float* __restrict__ g, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ da,
+                                float* __restrict__ db, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float s = sigmoidf_(b[i]);
+    da[i] = g[i] * s;
+    db[i] = g[i] * a[i] * s * (1.f - s);
+  }
+}
+
+__global__ void axpby_kernel(const float* __restrict__ a, float alpha, const float* __restrict__ b, float beta, float* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+__global__ void copy2d_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, long rows, int C) {
+  const long total = rows * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    dst[r * ldd + c] = src[r * lds + c];
+  }
+}
+
+// ---------------------------------------------------------------- fixed-order sums
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ p, int n, float scale, float* out, int accumulate) {
+  __shared__ float sm[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += p[i];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + scale * sm[0];
+}
+__global__ __launch_bounds__(256) void sqdiff_partials_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, float* __restrict__ partials) {
+  __shared__ float sm[256];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float d = a[i] - b[i];
+    s += d * d;
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = sm[0];
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int clc_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, float* mean,
+                                 float* rstd, long rows, int C, clc_stream_t stream) {
+  CLC_CHECK(x && gamma && beta && y && rows > 0 && C > 0, "clc_layernorm_fwd: bad args");
+  CLC_CHECK(C <= 64 * LN_MAX_PER_LANE, "clc_layernorm_fwd: C=%d too large", C);
+  CLC_CHECK((mean == nullptr) == (rstd == nullptr), "clc_layernorm_fwd: mean/rstd must both be given or both NULL");
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, ST, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, C);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+
+static int ln_bwd_blocks(long rows) { long b = (rows + 63) / 64; return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }
+
+extern "C" size_t clc_layernorm_bwd_workspace_bytes(long rows, int C) { return (size_t)ln_bwd_blocks(rows) * 2 * C * sizeof(float); }
+
+extern "C" int clc_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* mean,
+                                 const float* rstd, float* dx, int lddx, float* dgamma, float* dbeta, int accumulate, long rows,
+                                 int C, void* ws, size_t ws_bytes, clc_stream_t stream) {
+  CLC_CHECK(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0, "clc_layernorm_bwd: bad args");
+  CLC_CHECK(C <= 64 * LN_MAX_PER_LANE, "clc_layernorm_bwd: C=%d too large", C);
+  CLC_CHECK(ws && ws_bytes >= clc_layernorm_bwd_workspace_bytes(rows, C), "clc_layernorm_bwd: workspace too small");
+  const int nb = ln_bwd_blocks(rows);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), (size_t)8 * C * sizeof(float), ST, dy, lddy, x, ldx, gamma, mean, rstd, dx,
+                     lddx, (float*)ws, rows, C);
+  CLC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ST, (const float*)ws, nb, C, dgamma, dbeta, accumulate);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int clc_act_bwd(const float* dy, int lddy, const float* saved, int lds, int use_pre, int act, float* dz, int lddz, long rows,
+                           int C, clc_stream_t stream) {
+  CLC_CHECK(dy && saved && dz && rows > 0 && C > 0, "clc_act_bwd: bad args");
+  CLC_CHECK(!(act == CLC_ACT_GELU && !use_pre), "clc_act_bwd: GELU needs the pre-activation");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(rows * C, 1024)), dim3(256), 0, ST, dy, lddy, saved, lds, use_pre, act, dz, lddz, rows, C);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+
+static int colsum_blocks(long rows) { long b = (rows + 255) / 256; return (int)(b < 1 ? 1 : (b > 512 ? 512 : b)); }
+extern "C" size_t clc_colsum_workspace_bytes(long rows, int C) { return (size_t)colsum_blocks(rows) * C * sizeof(float); }
+extern "C" int clc_colsum(const float* x, int ld, long rows, int C, float* out, int accumulate, void* ws, size_t ws_bytes, clc_stream_t stream) {
+  CLC_CHECK(x && out && rows > 0 && C > 0, "clc_colsum: bad args");
+  CLC_CHECK(ws && ws_bytes >= clc_colsum_workspace_bytes(rows, C), "clc_colsum: workspace too small");
+  const int nb = colsum_blocks(rows);
+  const long rpb = (rows + nb - 1) / nb;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, ST, x, ld, rows, C, (float*)ws, rpb);
+  CLC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, (const float*)ws, nb, C, out, accumulate);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int clc_gdn_bwd_elem(const float* dy, const float* x, const float* v, float* dx_direct, float* dv, long n, int inverse, clc_stream_t stream) {
+  CLC_CHECK(dy && x && v && dx_direct && dv && n > 0, "clc_gdn_bwd_elem: bad args");
+  hipLaunchKernelGGL(gdn_bwd_elem_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, ST, dy, x, v, dx_direct, dv, n, inverse);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int clc_gdn_bwd_combine(const float* dx_direct, const float* x, const float* t, float* dx, long n, clc_stream_t stream) {
+  CLC_CHECK(dx_direct && x && t && dx && n > 0, "clc_gdn_bwd_combine: bad args");
+  hipLaunchKernelGGL(gdn_bwd_combine_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, ST, dx_direct, x, t, dx, n);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int clc_gate_fwd(const float* a, const float* b, const float* idn, float* out, long n, clc_stream_t stream) {
+  CLC_CHECK(a && b && idn && out && n > 0, "clc_gate_fwd: bad args");
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, ST, a, b, idn, out, n);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int clc_gate_bwd(const float* dout, const float* a, const float* b, float* da, float* db, long n, clc_stream_t stream) {
+  CLC_CHECK(dout && a && b && da && db && n > 0, "clc_gate_bwd: bad args");
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, ST, dout, a, b, da, db, n);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int clc_axpby(const float* a, float alpha, const float* b, float beta, float* out, long n, clc_stream_t stream) {
+  CLC_CHECK(a && out && n > 0, "clc_axpby: bad args");
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, ST, a, alpha, b, beta, out, n);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int clc_copy2d(const float* src, int lds, float* dst, int ldd, long rows, int C, clc_stream_t stream) {
+  CLC_CHECK(src && dst && rows > 0 && C > 0, "clc_copy2d: bad args");
+  hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(rows * C, 1024)), dim3(256), 0, ST, src, lds, dst, ldd, rows, C);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int clc_sum_partials(const float* partials, int n, float scale, float* out, int accumulate, clc_stream_t stream) {
+  CLC_CHECK(partials && out && n > 0, "clc_sum_partials: bad args");
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ST, partials, n, scale, out, accumulate);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int clc_sqdiff_partials(const float* a, const float* b, long n, float* partials, int n_partials, clc_stream_t stream) {
+  CLC_CHECK(a && b && partials && n > 0 && n_partials > 0 && n_partials <= kMaxBlocks, "clc_sqdiff_partials: bad args");
+  hipLaunchKernelGGL(sqdiff_partials_kernel, dim3(n_partials), dim3(256), 0, ST, a, b, n, partials);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,197 @@
+// rans_host.cpp — host-side range-ANS entropy coder and CDF quantiser of libclc_hip.so (bit-exact).
+//
+// Replaces the CompressAI C++ extension the reference calls through pybind11:
+//   compressai.ans.BufferedRansEncoder.encode_with_indexes/flush   /root/reference/models/CLC_run.py:658,712-713
+//   compressai.ans.RansDecoder.set_stream/decode_stream            /root/reference/models/CLC_run.py:762-763,793
+//   RansEncoder/RansDecoder.{encode,decode}_with_indexes (EntropyBottleneck)      CLC_run.py:643-644,749
+//   compressai._CXX.pmf_to_quantized_cdf (via update())                           CLC_run.py:486-491
+// Stream format: rANS with a 64-bit state, L = 2^31, 32-bit little-endian renorm
+// words, 16-bit probability precision, 4-bit bypass escape for symbols outside the CDF support.
+//
+// Unlike the reference's pipeline (Python lists -> std::vector<RansSymbol> -> reverse pop), this
+// coder works straight on int32 arrays (the device-side quantize/build_indexes kernel fills
+// them, one D2H copy per image) and encodes in ONE backward sweep over the symbols, writing
+// words from the end of the caller's buffer — no intermediate symbol buffer, no Python marshalling.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <stdarg.h>
+#include <vector>
+
+#include "../../include/clc_hip.h"
+
+static thread_local char g_err[512] = "";
+void clc_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* clc_last_error(void) { return g_err; }
+extern "C" int clc_version(void) { return 100; }
+
+namespace {
+constexpr int kPrec = 16, kBypassBits = 4;
+constexpr uint32_t kBypassMax = (1u << kBypassBits) - 1;
+constexpr uint64_t kL = 1ull << 31;
+
+struct BackWriter {
+  uint32_t* begin;
+  uint32_t* ptr;  // next free slot is ptr-1
+  bool overflow = false;
+  inline void put(uint32_t w) {
+    if (ptr == begin) { overflow = true; return; }
+    *--ptr = w;
+  }
+};
+
+inline void enc_put(uint64_t& x, BackWriter& o, uint32_t start, uint32_t freq) {
+  const uint64_t x_max = ((kL >> kPrec) << 32) * freq;
+  if (x >= x_max) { o.put((uint32_t)x); x >>= 32; }
+  x = ((x / freq) << kPrec) + (x % freq) + start;
+}
+inline void enc_put_bits(uint64_t& x, BackWriter& o, uint32_t val) {
+  const uint64_t x_max = ((kL >> 16) << 32) * (uint64_t)(1u << (16 - kBypassBits));
+  if (x >= x_max) { o.put((uint32_t)x); x >>= 32; }
+  x = (x << kBypassBits) | val;
+}
+}  // namespace
+
+extern "C" long clc_rans_encode_bound(long n) { return 4 * (n * 12 + 18); }
+
+extern "C" long clc_rans_encode(const int32_t* symbols, const int32_t* indexes, long n, const int32_t* cdfs, int cdf_stride,
+                                const int32_t* cdf_sizes, const int32_t* offsets, uint8_t* out, long out_cap) {
+  if (n < 0 || (n > 0 && (!symbols || !indexes)) || !cdfs || !cdf_sizes || !offsets || !out) { clc_set_error("clc_rans_encode: bad args"); return -1; }
+  if (out_cap < 8 || (reinterpret_cast<uintptr_t>(out) & 3)) { clc_set_error("clc_rans_encode: output buffer too small or unaligned"); return -1; }
+  BackWriter o;
+  o.begin = reinterpret_cast<uint32_t*>(out);
+  o.ptr = o.begin + out_cap / 4;
+  uint32_t* const end = o.ptr;
+  uint64_t x = kL;
+  for (long i = n - 1; i >= 0; --i) {
+    const int32_t ci = indexes[i];
+    const int32_t* cdf = cdfs + (long)ci * cdf_stride;
+    const int32_t max_value = cdf_sizes[ci] - 2;
+    if (max_value < 0 || cdf_sizes[ci] > cdf_stride) { clc_set_error("clc_rans_encode: bad cdf size at index %d", ci); return -1; }
+    int32_t value = symbols[i] - offsets[ci];
+    uint32_t raw = 0;
+    bool escape = false;
+    if (value < 0) { raw = (uint32_t)(-2 * (int64_t)value - 1); value = max_value; escape = true; }
+    else if (value >= max_value) { raw = (uint32_t)(2 * ((int64_t)value - max_value)); value = max_value; escape = true; }
+    if (escape) {
+      // forward order is: symbol, count (unary in 15s), nibbles LSB first -> emit in reverse
+      int nb = 0;
+      while (nb < 8 && (raw >> (nb * kBypassBits)) != 0) ++nb;
+      for (int j = nb - 1; j >= 0; --j) enc_put_bits(x, o, (raw >> (j * kBypassBits)) & kBypassMax);
+      const int full = nb / (int)kBypassMax, rem = nb % (int)kBypassMax;
+      enc_put_bits(x, o, (uint32_t)rem);
+      for (int j = 0; j < full; ++j) enc_put_bits(x, o, kBypassMax);
+    }
+    const uint32_t start = (uint32_t)cdf[value] & 0xFFFFu;
+    const uint32_t freq = (uint32_t)(cdf[value + 1] - cdf[value]) & 0xFFFFu;
+    if (freq == 0) { clc_set_error("clc_rans_encode: zero-frequency symbol (index %d value %d)", ci, value); return -1; }
+    enc_put(x, o, start, freq);
+  }
+  o.put((uint32_t)(x >> 32));
+  o.put((uint32_t)x);
+  if (o.overflow) { clc_set_error("clc_rans_encode: output buffer too small"); return -2; }
+  const long nbytes = (long)(end - o.ptr) * 4;
+  memmove(out, o.ptr, (size_t)nbytes);
+  return nbytes;
+}
+
+struct clc_rans_decoder {
+  std::vector<uint32_t> words;
+  size_t pos;
+  uint64_t x;
+};
+
+extern "C" clc_rans_decoder* clc_rans_decoder_create(const uint8_t* stream, long nbytes) {
+  if (!stream || nbytes < 8 || (nbytes & 3)) { clc_set_error("clc_rans_decoder_create: stream must be >= 8 bytes, multiple of 4"); return nullptr; }
+  clc_rans_decoder* d = new (std::nothrow) clc_rans_decoder();
+  if (!d) { clc_set_error("clc_rans_decoder_create: out of memory"); return nullptr; }
+  d->words.resize((size_t)nbytes / 4);
+  memcpy(d->words.data(), stream, (size_t)nbytes);
+  d->x = (uint64_t)d->words[0] | ((uint64_t)d->words[1] << 32);
+  d->pos = 2;
+  return d;
+}
+
+extern "C" void clc_rans_decoder_destroy(clc_rans_decoder* d) { delete d; }
+
+namespace {
+inline void renorm(clc_rans_decoder* d) {
+  if (d->x < kL) {
+    const uint32_t w = d->pos < d->words.size() ? d->words[d->pos] : 0u;  // truncated stream: feed zeros, never read OOB
+    d->pos++;
+    d->x = (d->x << 32) | w;
+  }
+}
+inline uint32_t get_bits(clc_rans_decoder* d) {
+  const uint32_t v = (uint32_t)(d->x & kBypassMax);
+  d->x >>= kBypassBits;
+  renorm(d);
+  return v;
+}
+}  // namespace
+
+extern "C" long clc_rans_decoder_decode(clc_rans_decoder* d, const int32_t* indexes, long n, const int32_t* cdfs, int cdf_stride,
+                                        const int32_t* cdf_sizes, const int32_t* offsets, int32_t* out) {
+  if (!d || n < 0 || (n > 0 && (!indexes || !out)) || !cdfs || !cdf_sizes || !offsets) { clc_set_error("clc_rans_decoder_decode: bad args"); return -1; }
+  for (long i = 0; i < n; ++i) {
+    const int32_t ci = indexes[i];
+    const int32_t* cdf = cdfs + (long)ci * cdf_stride;
+    const int32_t size = cdf_sizes[ci], max_value = size - 2;
+    const uint32_t cf = (uint32_t)(d->x & 0xFFFFu);
+    // largest s with cdf[s] <= cf  (cdf is strictly increasing over [0,size))
+    int32_t lo = 0, hi = size - 1;
+    while (lo < hi) {
+      const int32_t mid = (lo + hi + 1) >> 1;
+      if ((uint32_t)cdf[mid] <= cf) lo = mid; else hi = mid - 1;
+    }
+    const int32_t s = lo;
+    const uint32_t start = (uint32_t)cdf[s], freq = (uint32_t)(cdf[s + 1] - cdf[s]);
+    d->x = (uint64_t)freq * (d->x >> kPrec) + cf - start;
+    renorm(d);
+    int32_t value = s;
+    if (s == max_value) {
+      uint32_t v = get_bits(d);
+      int32_t nb = (int32_t)v;
+      while (v == kBypassMax) { v = get_bits(d); nb += (int32_t)v; }
+      uint32_t raw = 0;
+      for (int32_t j = 0; j < nb; ++j) { const uint32_t b = get_bits(d); if (j < 8) raw |= b << (j * kBypassBits); }
+      value = (int32_t)(raw >> 1);
+      value = (raw & 1u) ? -value - 1 : value + max_value;
+    }
+    out[i] = value + offsets[ci];
+  }
+  return (long)d->pos;  // 32-bit words consumed so far
+}
+
+extern "C" int clc_pmf_to_quantized_cdf(const float* pmf, int n, int precision, int32_t* cdf_out) {
+  if (!pmf || !cdf_out || n <= 0 || precision < 1 || precision > 16) { clc_set_error("clc_pmf_to_quantized_cdf: bad args"); return -1; }
+  std::vector<uint32_t> c((size_t)n + 1);
+  c[0] = 0;
+  uint32_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!(pmf[i] >= 0.f) || !std::isfinite(pmf[i])) { clc_set_error("clc_pmf_to_quantized_cdf: invalid pmf[%d]", i); return -1; }
+    c[i + 1] = (uint32_t)std::round(pmf[i] * (float)(1 << precision));  // float32 product, half away from zero
+    total += c[i + 1];
+  }
+  if (total == 0) { clc_set_error("clc_pmf_to_quantized_cdf: pmf sums to zero"); return -1; }
+  uint32_t run = 0;
+  for (int i = 0; i <= n; ++i) { run += (uint32_t)((((uint64_t)1 << precision) * c[i]) / total); c[i] = run; }
+  c[n] = 1u << precision;
+  for (int i = 0; i < n; ++i) {
+    if (c[i] != c[i + 1]) continue;
+    uint32_t best_freq = ~0u; int best = -1;
+    for (int j = 0; j < n; ++j) { const uint32_t f = c[j + 1] - c[j]; if (f > 1 && f < best_freq) { best_freq = f; best = j; } }
+    if (best < 0) { clc_set_error("clc_pmf_to_quantized_cdf: cannot steal frequency"); return -1; }
+    if (best < i) for (int j = best + 1; j <= i; ++j) c[j]--; else for (int j = i + 1; j <= best; ++j) c[j]++;
+  }
+  for (int i = 0; i <= n; ++i) cdf_out[i] = (int32_t)c[i];
+  return 0;
+}

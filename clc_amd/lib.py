@@ -1,0 +1,129 @@
+"""ctypes binding of libclc_hip.so (the C ABI declared in include/clc_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a kernel call
+fails, this module raises — loudly — instead of routing anywhere else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libclc_hip.so")
+
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU = 0, 1, 2, 3
+IN_NONE, IN_SQUARE = 0, 1
+NORM_NONE, NORM_GDN, NORM_IGDN = 0, 1, 2
+
+fp = C.c_void_p  # device / host pointers are passed as integers (tensor.data_ptr())
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("x", fp), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("ldx", C.c_int),
+                ("w", fp), ("bias", fp),
+                ("y", fp), ("OH", C.c_int), ("OW", C.c_int), ("Cout", C.c_int), ("ldy", C.c_int),
+                ("ks", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
+                ("transposed", C.c_int), ("in_op", C.c_int), ("act", C.c_int),
+                ("norm", C.c_int), ("mul", fp), ("ldm", C.c_int),
+                ("res", fp), ("ldr", C.c_int), ("res_scale", C.c_float),
+                ("y_pre", fp), ("ldp", C.c_int),
+                ("shuffle", C.c_int)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("x", fp), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("ldx", C.c_int),
+                ("dy", fp), ("OH", C.c_int), ("OW", C.c_int), ("Cout", C.c_int), ("lddy", C.c_int),
+                ("dw", fp), ("dbias", fp),
+                ("ks", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
+                ("in_op", C.c_int), ("accumulate", C.c_int),
+                ("workspace", fp), ("workspace_bytes", C.c_size_t)]
+
+
+class ParamEntry(C.Structure):
+    _fields_ = [("p", fp), ("g", fp), ("m", fp), ("v", fp), ("n", C.c_long)]
+
+
+_i, _l, _f, _sz = C.c_int, C.c_long, C.c_float, C.c_size_t
+_pp = C.POINTER(fp)
+
+# name -> (restype, argtypes); every symbol include/clc_hip.h declares must appear here
+SIGNATURES = {
+    "clc_last_error": (C.c_char_p, []),
+    "clc_version": (_i, []),
+    "clc_conv2d": (_i, [C.POINTER(ConvDesc), fp]),
+    "clc_conv2d_wgrad_workspace_bytes": (_sz, [C.POINTER(WgradDesc)]),
+    "clc_conv2d_wgrad": (_i, [C.POINTER(WgradDesc), fp]),
+    "clc_filter_transpose": (_i, [fp, fp, _i, _i, _i, fp]),
+    "clc_act_bwd": (_i, [fp, _i, fp, _i, _i, _i, fp, _i, _l, _i, fp]),
+    "clc_colsum_workspace_bytes": (_sz, [_l, _i]),
+    "clc_colsum": (_i, [fp, _i, _l, _i, fp, _i, fp, _sz, fp]),
+    "clc_layernorm_fwd": (_i, [fp, _i, fp, fp, fp, _i, fp, fp, _l, _i, fp]),
+    "clc_layernorm_bwd_workspace_bytes": (_sz, [_l, _i]),
+    "clc_layernorm_bwd": (_i, [fp, _i, fp, _i, fp, fp, fp, fp, _i, fp, fp, _i, _l, _i, fp, _sz, fp]),
+    "clc_gdn_bwd_elem": (_i, [fp, fp, fp, fp, fp, _l, _i, fp]),
+    "clc_gdn_bwd_combine": (_i, [fp, fp, fp, fp, _l, fp]),
+    "clc_gate_fwd": (_i, [fp, fp, fp, fp, _l, fp]),
+    "clc_gate_bwd": (_i, [fp, fp, fp, fp, fp, _l, fp]),
+    "clc_axpby": (_i, [fp, _f, fp, _f, fp, _l, fp]),
+    "clc_copy2d": (_i, [fp, _i, fp, _i, _l, _i, fp]),
+    "clc_winattn_fwd": (_i, [fp, _i, fp, fp, _i, fp, _i, _i, _i, _i, _i, _i, _i, fp]),
+    "clc_winattn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "clc_winattn_bwd": (_i, [fp, _i, fp, _i, fp, fp, _i, fp, fp, _i, fp, _i, _i, _i, _i, _i, _i, _i, _i, fp, _sz, fp]),
+    "clc_gauss_lik_partials": (_i, [_l, _i]),
+    "clc_gauss_lik_fwd": (_i, [fp, _i, fp, _i, fp, _i, fp, _i, fp, _i, fp, _i, _l, _i, _i, fp, _i, fp]),
+    "clc_gauss_lik_bwd": (_i, [fp, _i, fp, _i, fp, _i, fp, _i, fp, _i, fp, _i, fp, _i, fp, _i, _l, _i, _i, fp]),
+    "clc_eb_lik_fwd": (_i, [fp, _i, fp, _i, fp, _pp, _pp, _pp, fp, _i, fp, _i, _l, _i, _i, fp]),
+    "clc_eb_lik_bwd": (_i, [fp, _i, fp, _i, fp, _i, fp, _pp, _pp, _pp, _pp, _pp, _pp, fp, _i, _l, _i, _i, fp]),
+    "clc_eb_aux": (_i, [fp, _pp, _pp, _pp, fp, fp, fp, _i, fp]),
+    "clc_quantize_build_indexes": (_i, [fp, _i, fp, _i, fp, _i, fp, _i, fp, fp, fp, _i, _l, _i, fp]),
+    "clc_sum_partials": (_i, [fp, _i, _f, fp, _i, fp]),
+    "clc_sqdiff_partials": (_i, [fp, fp, _l, fp, _i, fp]),
+    "clc_optim_chunk_elems": (_i, []),
+    "clc_grad_sqnorm_partials": (_i, [fp, fp, _i, fp, fp]),
+    "clc_adamw_step": (_i, [fp, fp, _i, fp, _f, _f, _f, _f, _f, _f, fp, fp]),
+    "clc_scalar_add": (_i, [fp, _f, fp]),
+    "clc_rans_encode_bound": (_l, [_l]),
+    "clc_rans_encode": (_l, [fp, fp, _l, fp, _i, fp, fp, fp, _l]),
+    "clc_rans_decoder_create": (fp, [fp, _l]),
+    "clc_rans_decoder_decode": (_l, [fp, fp, _l, fp, _i, fp, fp, fp]),
+    "clc_rans_decoder_destroy": (None, [fp]),
+    "clc_pmf_to_quantized_cdf": (_i, [fp, _i, _i, fp]),
+}
+
+
+class ClcError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libclc_hip.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ClcError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(make -C clc_amd/csrc). There is no CPU fallback for the clc_amd product path.")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc is None:
+        return
+    if rc < 0:
+        msg = load().clc_last_error()
+        raise ClcError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+    return rc
+
+
+def ptr_array(ptrs):
+    arr = (fp * len(ptrs))(*ptrs)
+    return arr

@@ -1,0 +1,495 @@
+"""Autograd-aware operator layer over the C ABI (libclc_hip.so).
+
+Tensors keep the reference's logical NCHW shapes but live in channels_last memory
+(= the NHWC layout the kernels use), so every ``permute``/``Rearrange`` of the reference
+(/root/reference/models/CLC_run.py:215,217,260,263) is a no-op here and ``split``/``chunk``
+are strided views the kernels read directly through their leading-dimension argument.
+
+Every op runs on the current HIP stream, allocates only through the PyTorch caching
+allocator, never synchronises -> the whole training step is hipGraph-capturable.
+There is no CPU path: a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import lib as _lib
+from .lib import ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, IN_NONE, IN_SQUARE, NORM_GDN, NORM_IGDN, NORM_NONE
+
+CL = torch.channels_last
+
+
+def _L():
+    return _lib.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise _lib.ClcError(f"{what}: tensor is on {t.device}; the clc_amd product path runs on the GPU only "
+                            "(no CPU fallback by design)")
+    if t.dtype != torch.float32:
+        raise _lib.ClcError(f"{what}: dtype {t.dtype} (fp32 only)")
+
+
+def nhwc(t: torch.Tensor):
+    """(tensor, ptr, N, H, W, C, ld) of a logical-NCHW tensor stored pixel-major; copies only if it must."""
+    assert t.dim() == 4, t.shape
+    N, Cc, H, W = t.shape
+    ok = t.stride(1) == 1 or Cc == 1
+    ld = t.stride(3) if W > 1 else (t.stride(2) if H > 1 else (t.stride(0) if N > 1 else Cc))
+    if W > 1 and H > 1:
+        ok = ok and t.stride(2) == W * ld
+    if N > 1:
+        ok = ok and t.stride(0) == H * W * ld
+    ok = ok and ld >= Cc
+    if not ok:
+        t = t.contiguous(memory_format=CL)
+        if t.stride(1) != 1 and Cc > 1:  # ambiguous-stride corner cases
+            t = torch.empty((N, Cc, H, W), device=t.device, dtype=t.dtype, memory_format=CL).copy_(t)
+        ld = Cc
+    return t, t.data_ptr(), N, H, W, Cc, ld
+
+
+def dense(t: torch.Tensor) -> torch.Tensor:
+    """pixel-major AND channel-dense (ld == C); copies a channel-slice view."""
+    t, _p, N, H, W, Cc, ld = nhwc(t)
+    if ld != Cc:
+        t = torch.empty((N, Cc, H, W), device=t.device, dtype=t.dtype, memory_format=CL).copy_(t)
+    return t
+
+
+def new_act(N, Cc, H, W, like: torch.Tensor):
+    return torch.empty((N, Cc, H, W), device=like.device, dtype=torch.float32, memory_format=CL)
+
+
+def to_kernel_weight(w: torch.Tensor) -> torch.Tensor:
+    """[Co,Ci,kh,kw] -> physically [Co][kh][kw][Ci] (no copy when already channels_last)."""
+    if w.dim() == 2:
+        return w if w.is_contiguous() else w.contiguous()
+    if w.is_contiguous(memory_format=CL) or (w.shape[2] == 1 and w.shape[3] == 1 and w.is_contiguous()):
+        return w
+    return w.contiguous(memory_format=CL)
+
+
+# ------------------------------------------------------------------------------------------ conv
+
+
+def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_NONE, norm=NORM_NONE, mul=None,
+             res=None, res_scale=1.0, y_pre=None, shuffle=False, transposed=False, out=None, out_hw=None):
+    """One clc_conv2d launch. ``w`` must already be in kernel layout [Cout][ks][ks][Cin]."""
+    _require_gpu(x, "conv2d")
+    x, xp, N, H, W, Cin, ldx = nhwc(x)
+    Cout = w.shape[0]
+    pad = ks // 2 if pad is None else pad
+    if transposed:
+        OH, OW = out_hw
+    else:
+        OH, OW = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    if out is None:
+        out = new_act(N, Cout // 4, 2 * OH, 2 * OW, x) if shuffle else new_act(N, Cout, OH, OW, x)
+    o, op, _, _, _, _, ldy = nhwc(out)
+    assert o is out, "conv2d: output buffer must be pixel-major"
+    d = _lib.ConvDesc()
+    d.x, d.N, d.H, d.W, d.Cin, d.ldx = xp, N, H, W, Cin, ldx
+    d.w = w.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.y, d.OH, d.OW, d.Cout, d.ldy = op, OH, OW, Cout, ldy
+    d.ks, d.stride, d.pad = ks, stride, pad
+    d.transposed, d.in_op, d.act, d.norm, d.shuffle = int(transposed), in_op, act, norm, int(shuffle)
+    keep = [x, w, bias, out]
+    if mul is not None:
+        m, mp, *_r, ldm = nhwc(mul)
+        d.mul, d.ldm = mp, ldm
+        keep.append(m)
+    if res is not None:
+        r, rp, *_r, ldr = nhwc(res)
+        d.res, d.ldr, d.res_scale = rp, ldr, float(res_scale)
+        keep.append(r)
+    if y_pre is not None:
+        q, qp, *_r, ldp = nhwc(y_pre)
+        assert q is y_pre
+        d.y_pre, d.ldp = qp, ldp
+    _lib.check(_L().clc_conv2d(C.byref(d), _stream()), "clc_conv2d")
+    return out
+
+
+def filter_transpose(w, Cout, T, Cin):
+    wt = torch.empty(Cin * T * Cout, device=w.device, dtype=torch.float32)
+    _lib.check(_L().clc_filter_transpose(w.data_ptr(), wt.data_ptr(), Cout, T, Cin, _stream()), "clc_filter_transpose")
+    return wt.view(Cin, T * Cout)
+
+
+def wgrad_raw(x, dy, *, ks, stride, pad, Cout, Cin, want_bias, in_op=IN_NONE):
+    """Returns (dw [Cout, ks*ks*Cin] flat kernel layout, dbias or None)."""
+    x, xp, N, H, W, _, ldx = nhwc(x)
+    dy, dp, _, OH, OW, _, lddy = nhwc(dy)
+    dw = torch.empty(Cout * ks * ks * Cin, device=x.device, dtype=torch.float32)
+    db = torch.empty(Cout, device=x.device, dtype=torch.float32) if want_bias else None
+    d = _lib.WgradDesc()
+    d.x, d.N, d.H, d.W, d.Cin, d.ldx = xp, N, H, W, Cin, ldx
+    d.dy, d.OH, d.OW, d.Cout, d.lddy = dp, OH, OW, Cout, lddy
+    d.dw, d.dbias = dw.data_ptr(), (db.data_ptr() if want_bias else None)
+    d.ks, d.stride, d.pad, d.in_op, d.accumulate = ks, stride, pad, in_op, 0
+    nbytes = _L().clc_conv2d_wgrad_workspace_bytes(C.byref(d))
+    ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+    _lib.check(_L().clc_conv2d_wgrad(C.byref(d), _stream()), "clc_conv2d_wgrad")
+    return dw, db
+
+
+def _dw_to_param_layout(dw_flat, w_param):
+    """kernel layout [Co][kh][kw][Ci] -> a tensor shaped like the parameter (logical OIHW / [out,in])."""
+    if w_param.dim() == 2:
+        return dw_flat.view(w_param.shape)
+    Co, Ci, kh, kw = w_param.shape
+    return dw_flat.view(Co, kh, kw, Ci).permute(0, 3, 1, 2)  # logical OIHW, channels_last strides
+
+
+def act_bwd(dy, saved, use_pre, act):
+    dy, dyp, N, H, W, Cc, lddy = nhwc(dy)
+    saved, sp, *_r, lds = nhwc(saved)
+    dz = new_act(N, Cc, H, W, dy)
+    _lib.check(_L().clc_act_bwd(dyp, lddy, sp, lds, int(use_pre), act, dz.data_ptr(), Cc, N * H * W, Cc, _stream()), "clc_act_bwd")
+    return dz
+
+
+class _ConvFn(Function):
+    """y = act(conv(x, w) + b) + res_scale * res, optionally PixelShuffle(2)-stored."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, res, ks, stride, act, res_scale, shuffle):
+        wk = to_kernel_weight(w)
+        need_grad = any(ctx.needs_input_grad)
+        # the activation derivative needs the pre-activation whenever the output does not determine it
+        save_pre = need_grad and (act == ACT_GELU or (act in (ACT_LRELU, ACT_RELU) and res is not None))
+        N, _, H, W = x.shape
+        Cout = w.shape[0]
+        pad = ks // 2
+        OH, OW = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+        y_pre = None
+        if save_pre:
+            y_pre = new_act(N, Cout // 4, 2 * OH, 2 * OW, x) if shuffle else new_act(N, Cout, OH, OW, x)
+        y = conv_raw(x, wk, b, ks=ks, stride=stride, act=act, res=res, res_scale=res_scale, y_pre=y_pre, shuffle=shuffle)
+        ctx.cfg = (ks, stride, act, res_scale, shuffle, b is not None, res is not None)
+        saved_act = y_pre if save_pre else (y if act in (ACT_LRELU, ACT_RELU) else None)
+        ctx.use_pre = save_pre
+        ctx.save_for_backward(x, w, saved_act)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ks, stride, act, res_scale, shuffle, has_b, has_res = ctx.cfg
+        x, w, saved_act = ctx.saved_tensors
+        Cout, Cin = w.shape[0], w.shape[1]
+        need_x, need_w, need_b, need_res = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_b and ctx.needs_input_grad[2], has_res and ctx.needs_input_grad[3]
+        dres = None
+        if need_res:
+            dres = dy if res_scale == 1.0 else dy * res_scale
+        dz = act_bwd(dy, saved_act, ctx.use_pre, act) if act != ACT_NONE else dy
+        if shuffle:  # undo PixelShuffle(2): [N, C/4, 2H, 2W] -> [N, C, H, W] (strided copy; TODO fuse into the gathers)
+            dz = torch.nn.functional.pixel_unshuffle(dz, 2).contiguous(memory_format=CL)
+        dx = dw = db = None
+        pad = ks // 2
+        if need_w or need_b:
+            dwf, db = wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=need_b)
+            dw = _dw_to_param_layout(dwf, w) if need_w else None
+        if need_x:
+            wt = filter_transpose(to_kernel_weight(w), Cout, ks * ks, Cin)
+            dx = conv_raw(dz, wt.view(Cin, -1), None, ks=ks, stride=stride, pad=pad, transposed=True, out_hw=(x.shape[2], x.shape[3]))
+        return dx, dw, db, dres, None, None, None, None, None
+
+
+def conv2d(x, w, b=None, *, stride=1, act=ACT_NONE, res=None, res_scale=1.0, shuffle=False):
+    ks = w.shape[2] if w.dim() == 4 else 1
+    return _ConvFn.apply(x, w, b, res, ks, stride, act, float(res_scale), bool(shuffle))
+
+
+def linear(x, w, b=None, *, act=ACT_NONE, res=None):
+    """nn.Linear on channels (tokens are pixels): x [N,Cin,H,W] pixel-major, w [Cout,Cin]."""
+    return _ConvFn.apply(x, w, b, res, 1, 1, act, 1.0, False)
+
+
+# ------------------------------------------------------------------------------------------- GDN
+
+
+class _GDNFn(Function):
+    """y = x * rsqrt(beta + gamma . x^2)  (inverse: * sqrt), fused: 1x1 conv with square-on-load + norm epilogue.
+    Optional residual ``res`` is added in the same epilogue (ResidualBlockWithStride / Upsample tail)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, inverse):
+        N, Cc, H, W = x.shape
+        need_grad = any(ctx.needs_input_grad)
+        v = new_act(N, Cc, H, W, x) if need_grad else None
+        g = gamma if gamma.is_contiguous() else gamma.contiguous()
+        y = conv_raw(x, g, beta, ks=1, in_op=IN_SQUARE, norm=NORM_IGDN if inverse else NORM_GDN, mul=x, y_pre=v, res=res)
+        ctx.inverse = inverse
+        ctx.has_res = res is not None
+        ctx.save_for_backward(x, g, v)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, v = ctx.saved_tensors
+        N, Cc, H, W = x.shape
+        dy, xx = dense(dy), dense(x)
+        n = N * Cc * H * W
+        dxd, dv = new_act(N, Cc, H, W, x), new_act(N, Cc, H, W, x)
+        _lib.check(_L().clc_gdn_bwd_elem(dy.data_ptr(), xx.data_ptr(), v.data_ptr(), dxd.data_ptr(), dv.data_ptr(), n, int(ctx.inverse), _stream()), "clc_gdn_bwd_elem")
+        dgamma = dbeta = dx = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dgf, dbeta = wgrad_raw(xx, dv, ks=1, stride=1, pad=0, Cout=Cc, Cin=Cc, want_bias=True, in_op=IN_SQUARE)
+            dgamma = dgf.view(Cc, Cc)
+        if ctx.needs_input_grad[0]:
+            gt = filter_transpose(g, Cc, 1, Cc)
+            t = conv_raw(dv, gt, None, ks=1, transposed=True, out_hw=(H, W))
+            dx = new_act(N, Cc, H, W, x)
+            _lib.check(_L().clc_gdn_bwd_combine(dxd.data_ptr(), xx.data_ptr(), t.data_ptr(), dx.data_ptr(), n, _stream()), "clc_gdn_bwd_combine")
+        return dx, dgamma, dbeta, (dy if ctx.has_res and ctx.needs_input_grad[3] else None), None
+
+
+def gdn(x, gamma_eff, beta_eff, inverse=False, res=None):
+    return _GDNFn.apply(x, gamma_eff, beta_eff, res, bool(inverse))
+
+
+# ------------------------------------------------------------------------------------- LayerNorm
+
+
+class _LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        x, xp, N, H, W, Cc, ldx = nhwc(x)
+        rows = N * H * W
+        y = new_act(N, Cc, H, W, x)
+        need = any(ctx.needs_input_grad)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32) if need else None
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if need else None
+        _lib.check(_L().clc_layernorm_fwd(xp, ldx, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), Cc,
+                                          mean.data_ptr() if need else None, rstd.data_ptr() if need else None, rows, Cc, _stream()), "clc_layernorm_fwd")
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        x, xp, N, H, W, Cc, ldx = nhwc(x)
+        dy, dyp, *_r, lddy = nhwc(dy)
+        rows = N * H * W
+        dx = new_act(N, Cc, H, W, x)
+        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+        nbytes = _L().clc_layernorm_bwd_workspace_bytes(rows, Cc)
+        ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
+        _lib.check(_L().clc_layernorm_bwd(dyp, lddy, xp, ldx, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), Cc,
+                                          dg.data_ptr(), db.data_ptr(), 0, rows, Cc, ws.data_ptr(), nbytes, _stream()), "clc_layernorm_bwd")
+        return dx, dg, db
+
+
+def layernorm(x, gamma, beta):
+    return _LayerNormFn.apply(x, gamma, beta)
+
+
+# ------------------------------------------------------------------------------ window attention
+
+
+class _WinAttnFn(Function):
+    """qkv [N,3C,H,W] pixel-major -> attention output [N,C,H,W]; relbias [heads,2ws-1,2ws-1]."""
+
+    @staticmethod
+    def forward(ctx, qkv, relbias, heads, ws, shift):
+        qkv, qp, N, H, W, C3, ldq = nhwc(qkv)
+        Cc = C3 // 3
+        out = new_act(N, Cc, H, W, qkv)
+        need = any(ctx.needs_input_grad)
+        lse = torch.empty(N * H * W * heads, device=qkv.device, dtype=torch.float32) if need else None
+        rb = relbias if relbias.is_contiguous() else relbias.contiguous()
+        _lib.check(_L().clc_winattn_fwd(qp, ldq, rb.data_ptr(), out.data_ptr(), Cc, lse.data_ptr() if need else None,
+                                        N, H, W, Cc, heads, ws, int(shift), _stream()), "clc_winattn_fwd")
+        ctx.cfg = (heads, ws, shift)
+        ctx.save_for_backward(qkv, rb, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        heads, ws, shift = ctx.cfg
+        qkv, rb, out, lse = ctx.saved_tensors
+        qkv, qp, N, H, W, C3, ldq = nhwc(qkv)
+        Cc = C3 // 3
+        dout, dop, *_r, lddo = nhwc(dout)
+        dqkv = new_act(N, C3, H, W, qkv)
+        drb = torch.empty_like(rb)
+        nbytes = _L().clc_winattn_bwd_workspace_bytes(N, H, W, heads, ws)
+        wsb = torch.empty((nbytes + 3) // 4, device=qkv.device, dtype=torch.float32)
+        _lib.check(_L().clc_winattn_bwd(dop, lddo, qp, ldq, rb.data_ptr(), out.data_ptr(), Cc, lse.data_ptr(), dqkv.data_ptr(), C3,
+                                        drb.data_ptr(), 0, N, H, W, Cc, heads, ws, int(shift), wsb.data_ptr(), nbytes, _stream()), "clc_winattn_bwd")
+        return dqkv, drb, None, None, None
+
+
+def window_attention(qkv, relbias, heads, ws, shift):
+    return _WinAttnFn.apply(qkv, relbias, int(heads), int(ws), bool(shift))
+
+
+# ------------------------------------------------------------------------------------------ gate
+
+
+class _GateFn(Function):
+    """a * sigmoid(b) + idn."""
+
+    @staticmethod
+    def forward(ctx, a, b, idn):
+        a, b, idn = dense(a), dense(b), dense(idn)
+        out = new_act(*a.shape, a)
+        _lib.check(_L().clc_gate_fwd(a.data_ptr(), b.data_ptr(), idn.data_ptr(), out.data_ptr(), a.numel(), _stream()), "clc_gate_fwd")
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = dense(g)
+        da, db = new_act(*a.shape, a), new_act(*a.shape, a)
+        _lib.check(_L().clc_gate_bwd(g.data_ptr(), a.data_ptr(), b.data_ptr(), da.data_ptr(), db.data_ptr(), a.numel(), _stream()), "clc_gate_bwd")
+        return da, db, g
+
+
+def gate(a, b, idn):
+    return _GateFn.apply(a, b, idn)
+
+
+# --------------------------------------------------------------------------------------- entropy
+
+
+class _GaussLikFn(Function):
+    """GaussianConditional.forward likelihood (training: additive noise; eval: dequantised)."""
+
+    @staticmethod
+    def forward(ctx, y, scale, mu, noise, training):
+        y, yp, N, H, W, Cc, ldy = nhwc(y)
+        scale, sp, *_a, ldsc = nhwc(scale)
+        mu, mp, *_b, ldmu = nhwc(mu)
+        rows = N * H * W
+        lik = new_act(N, Cc, H, W, y)
+        npn, ldn = (None, 0)
+        if training:
+            noise, npn, *_c, ldn = nhwc(noise)
+        _lib.check(_L().clc_gauss_lik_fwd(yp, ldy, mp, ldmu, sp, ldsc, npn, ldn, lik.data_ptr(), Cc, None, 0, rows, Cc,
+                                          0 if training else 1, None, 0, _stream()), "clc_gauss_lik_fwd")
+        ctx.training = training
+        ctx.save_for_backward(y, scale, mu, noise if training else None)
+        return lik
+
+    @staticmethod
+    def backward(ctx, dlik):
+        y, scale, mu, noise = ctx.saved_tensors
+        y, yp, N, H, W, Cc, ldy = nhwc(y)
+        scale, sp, *_a, ldsc = nhwc(scale)
+        mu, mp, *_b, ldmu = nhwc(mu)
+        dlik, dlp, *_c, lddl = nhwc(dlik)
+        rows = N * H * W
+        npn, ldn = (None, 0)
+        if ctx.training:
+            noise, npn, *_d, ldn = nhwc(noise)
+        dy = new_act(N, Cc, H, W, y) if ctx.training else None
+        dmu = new_act(N, Cc, H, W, y) if ctx.training else None
+        dsc = new_act(N, Cc, H, W, y)
+        _lib.check(_L().clc_gauss_lik_bwd(dlp, lddl, yp, ldy, mp, ldmu, sp, ldsc, npn, ldn,
+                                          dy.data_ptr() if dy is not None else None, Cc, dmu.data_ptr() if dmu is not None else None, Cc,
+                                          dsc.data_ptr(), Cc, rows, Cc, 0 if ctx.training else 1, _stream()), "clc_gauss_lik_bwd")
+        return dy, dsc, dmu, None, None
+
+
+def gaussian_likelihood(y, scale, mu, noise, training):
+    return _GaussLikFn.apply(y, scale, mu, noise, bool(training))
+
+
+def _eb_ptrs(mats, biases, factors):
+    return (_lib.ptr_array([t.data_ptr() for t in mats]), _lib.ptr_array([t.data_ptr() for t in biases]),
+            _lib.ptr_array([t.data_ptr() for t in factors]))
+
+
+class _EBLikFn(Function):
+    """EntropyBottleneck likelihood of z [N,C,H,W]; params = 5 matrices, 5 biases, 4 factors."""
+
+    @staticmethod
+    def forward(ctx, z, noise, quantiles, training, *params):
+        mats, biases, factors = params[0:5], params[5:10], params[10:14]
+        z, zp, N, H, W, Cc, ldz = nhwc(z)
+        rows = N * H * W
+        lik = new_act(N, Cc, H, W, z)
+        npn, ldn = (None, 0)
+        if training:
+            noise, npn, *_c, ldn = nhwc(noise)
+        pm, pb, pf = _eb_ptrs(mats, biases, factors)
+        _lib.check(_L().clc_eb_lik_fwd(zp, ldz, npn, ldn, quantiles.data_ptr(), pm, pb, pf, lik.data_ptr(), Cc, None, 0, rows, Cc,
+                                       0 if training else 1, _stream()), "clc_eb_lik_fwd")
+        ctx.training = training
+        ctx.save_for_backward(z, noise if training else None, quantiles, *params)
+        return lik
+
+    @staticmethod
+    def backward(ctx, dlik):
+        z, noise, quantiles, *params = ctx.saved_tensors
+        mats, biases, factors = params[0:5], params[5:10], params[10:14]
+        z, zp, N, H, W, Cc, ldz = nhwc(z)
+        dlik, dlp, *_c, lddl = nhwc(dlik)
+        rows = N * H * W
+        npn, ldn = (None, 0)
+        if ctx.training:
+            noise, npn, *_d, ldn = nhwc(noise)
+        grads = [torch.empty_like(p) for p in params]
+        pm, pb, pf = _eb_ptrs(mats, biases, factors)
+        gm, gb, gf = _eb_ptrs(grads[0:5], grads[5:10], grads[10:14])
+        dz = new_act(N, Cc, H, W, z) if ctx.training else None
+        _lib.check(_L().clc_eb_lik_bwd(dlp, lddl, zp, ldz, npn, ldn, quantiles.data_ptr(), pm, pb, pf, gm, gb, gf,
+                                       dz.data_ptr() if dz is not None else None, Cc, rows, Cc, 0 if ctx.training else 1, _stream()), "clc_eb_lik_bwd")
+        return (dz, None, None, None, *grads)
+
+
+def eb_likelihood(z, noise, quantiles, training, mats, biases, factors):
+    return _EBLikFn.apply(z, noise, quantiles, bool(training), *mats, *biases, *factors)
+
+
+class _EBAuxFn(Function):
+    @staticmethod
+    def forward(ctx, quantiles, target, *params):
+        mats, biases, factors = params[0:5], params[5:10], params[10:14]
+        Cc = quantiles.shape[0]
+        part = torch.empty(Cc, device=quantiles.device, dtype=torch.float32)
+        dq = torch.empty_like(quantiles)
+        pm, pb, pf = _eb_ptrs(mats, biases, factors)
+        _lib.check(_L().clc_eb_aux(quantiles.data_ptr(), pm, pb, pf, target.data_ptr(), part.data_ptr(), dq.data_ptr(), Cc, _stream()), "clc_eb_aux")
+        out = torch.zeros(1, device=quantiles.device, dtype=torch.float32)
+        _lib.check(_L().clc_sum_partials(part.data_ptr(), Cc, 1.0, out.data_ptr(), 0, _stream()), "clc_sum_partials")
+        ctx.save_for_backward(dq)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dq,) = ctx.saved_tensors
+        return (dq * g, None) + (None,) * 14
+
+
+def eb_aux_loss(quantiles, target, mats, biases, factors):
+    return _EBAuxFn.apply(quantiles, target, *[m.detach() for m in mats], *[b.detach() for b in biases], *[f.detach() for f in factors])
+
+
+def quantize_build_indexes(y, mu, scale, scale_table):
+    """-> (symbols int32 [N,C,H,W], indexes int32, y_hat) — INT path of compress()."""
+    y, yp, N, H, W, Cc, ldy = nhwc(y)
+    mu, mp, *_a, ldmu = nhwc(mu)
+    scale, sp, *_b, ldsc = nhwc(scale)
+    rows = N * H * W
+    sym = torch.empty((N, H, W, Cc), device=y.device, dtype=torch.int32)
+    idx = torch.empty((N, H, W, Cc), device=y.device, dtype=torch.int32)
+    y_hat = new_act(N, Cc, H, W, y)
+    _lib.check(_L().clc_quantize_build_indexes(yp, ldy, mp, ldmu, sp, ldsc, scale_table.data_ptr(), scale_table.numel(), sym.data_ptr(),
+                                               idx.data_ptr(), y_hat.data_ptr(), Cc, rows, Cc, _stream()), "clc_quantize_build_indexes")
+    # logical NCHW views over the NHWC int buffers
+    return sym.permute(0, 3, 1, 2), idx.permute(0, 3, 1, 2), y_hat

@@ -1,0 +1,223 @@
+/* clc_hip.h — C ABI of libclc_hip.so, the MI355X (gfx950) engine behind the CLC hot path.
+ *
+ * The reference (ydchen0806/CLC) has no FFI of its own: its callers import Python
+ * nn.Modules (`from models import TCM, CLC`, /root/reference/train_CLC.py:25,
+ * eval_CLC.py:4) whose arithmetic is executed by cuDNN / cuBLAS / ATen and by the
+ * CompressAI C++ extensions.  This header is therefore the boundary a maintainer would
+ * bind INSTEAD of those native back-ends (INTEGRATION.md shows the ctypes stub); each
+ * entry point cites the reference call site whose native work it replaces.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; no torch types.  Device pointers unless marked HOST.
+ *  - All activations are NHWC fp32 ("pixel-major"): element (n,h,w,c) of a tensor lives
+ *    at base[((n*H+h)*W+w)*ld + c]; `ld` (floats) lets a call read or write a channel
+ *    slice of a wider buffer, so torch.cat / split / chunk never materialise.
+ *  - Conv weights are [Cout][KH][KW][Cin] (PyTorch OIHW tensor in channels_last memory format).
+ *  - Every function enqueues work on `stream` and returns immediately: no allocation,
+ *    no synchronisation, no host read-back -> capturable in a hipGraph.  The caller owns
+ *    every buffer including workspaces (sizes from the *_workspace_bytes helpers).
+ *  - Return value: 0 = ok, negative = error; clc_last_error() gives the message
+ *    (thread-local).  No C++ exception crosses the ABI.
+ *  - Results are run-to-run deterministic (no floating-point atomics anywhere) and do not
+ *    depend on the batch size for a given image (per-output accumulation order is fixed),
+ *    which the encoder/decoder agreement of compress()/decompress() relies on.
+ */
+#ifndef CLC_HIP_H
+#define CLC_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* clc_stream_t; /* hipStream_t */
+
+const char* clc_last_error(void);
+int clc_version(void);
+
+/* ---- activation / epilogue codes ---------------------------------------------------- */
+enum { CLC_ACT_NONE = 0, CLC_ACT_LRELU = 1, CLC_ACT_RELU = 2, CLC_ACT_GELU = 3 };
+/* input prologue applied to the gathered activations */
+enum { CLC_IN_NONE = 0, CLC_IN_SQUARE = 1 };
+/* norm modes of the epilogue: out = mul * rsqrt(v) (GDN) or mul * sqrt(v) (inverse GDN) */
+enum { CLC_NORM_NONE = 0, CLC_NORM_GDN = 1, CLC_NORM_IGDN = 2 };
+
+/* ---- convolution as implicit GEMM on v_mfma_f32_32x32x2_f32 ------------------------- *
+ * Replaces cuDNN conv fwd / bwd-data / bwd-weight behind every nn.Conv2d and nn.Linear
+ * of the path: /root/reference/models/CLC_run.py:120,123,185-187,207-208,232-233,
+ * 273-277,335-354,371-396,412-481 and the CompressAI layers of SURVEY.md A.1.
+ *
+ * y[n,oh,ow,co] = epi( sum_{kh,kw,ci} in_op(x[n, oh*s-pad+kh, ow*s-pad+kw, ci]) * w[co,kh,kw,ci] )
+ * epi(v): v += bias[co]; (y_pre <- v); v = norm(v, mul); v = act(v); v += res_scale*res
+ * transposed = 1 computes the data gradient of that conv instead: "x" is dY
+ * [N,H,W,Cin=Cout_fwd], "y" is dX [N,OH,OW,Cout=Cin_fwd] and w must be the transposed
+ * filter [Cin_fwd][KH][KW][Cout_fwd] (clc_filter_transpose).
+ * shuffle = 1 fuses PixelShuffle(2) into the store: y has 2*OH x 2*OW pixels of Cout/4 ch.
+ */
+typedef struct {
+  const float* x; int N, H, W, Cin, ldx;
+  const float* w;            /* [Cout][ks][ks][Cin] */
+  const float* bias;         /* [Cout] or NULL */
+  float* y; int OH, OW, Cout, ldy;
+  int ks, stride, pad;
+  int transposed;
+  int in_op;
+  int act;
+  int norm; const float* mul; int ldm;
+  const float* res; int ldr; float res_scale;
+  float* y_pre; int ldp;     /* optional pre-activation copy (training) */
+  int shuffle;
+} clc_conv_desc;
+
+int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream);
+
+/* Weight gradient: dw[co,kh,kw,ci] = sum_{n,oh,ow} dy[n,oh,ow,co] * in_op(x[n,oh*s-pad+kh,ow*s-pad+kw,ci]).
+ * Deterministic split-K: partial slabs in `workspace`, summed in a fixed order.
+ * dbias (optional) = column sums of dy. accumulate=1 adds into dw/dbias. */
+typedef struct {
+  const float* x; int N, H, W, Cin, ldx;
+  const float* dy; int OH, OW, Cout, lddy;
+  float* dw; float* dbias;
+  int ks, stride, pad;
+  int in_op;
+  int accumulate;
+  void* workspace; size_t workspace_bytes;
+} clc_wgrad_desc;
+
+size_t clc_conv2d_wgrad_workspace_bytes(const clc_wgrad_desc* d);
+int clc_conv2d_wgrad(const clc_wgrad_desc* d, clc_stream_t stream);
+
+/* [Cout][T][Cin] -> [Cin][T][Cout]  (T = ks*ks) */
+int clc_filter_transpose(const float* w, float* wt, int Cout, int T, int Cin, clc_stream_t stream);
+
+/* ---- elementwise / normalisation ------------------------------------------------------ */
+/* dz = dy * act'(saved); saved = pre-activation (use_pre=1) or the activation output */
+int clc_act_bwd(const float* dy, int lddy, const float* saved, int lds, int use_pre, int act, float* dz, int lddz,
+                long rows, int C, clc_stream_t stream);
+/* column sums: out[c] (+)= sum_r x[r*ld + c]; workspace >= clc_colsum_workspace_bytes */
+size_t clc_colsum_workspace_bytes(long rows, int C);
+int clc_colsum(const float* x, int ld, long rows, int C, float* out, int accumulate, void* ws, size_t ws_bytes,
+               clc_stream_t stream);
+
+/* LayerNorm over the channel dim of [rows, C] tokens (nn.LayerNorm, CLC_run.py:180,183), eps = 1e-5.
+ * fwd saves mean/rstd per row when non-NULL. */
+int clc_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, float* mean,
+                      float* rstd, long rows, int C, clc_stream_t stream);
+/* dx; dgamma/dbeta partial sums go through ws (deterministic two-stage) */
+size_t clc_layernorm_bwd_workspace_bytes(long rows, int C);
+int clc_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* mean,
+                      const float* rstd, float* dx, int lddx, float* dgamma, float* dbeta, int accumulate, long rows,
+                      int C, void* ws, size_t ws_bytes, clc_stream_t stream);
+
+/* GDN backward pieces (CompressAI GDN inside ResidualBlockWithStride / ResidualBlockUpsample):
+ * given dy, x, norm v = beta + gamma.x^2 :  dx_direct = dy * f(v);  dv = dy * x * f'(v)
+ * with f = rsqrt (inverse=0) or sqrt (inverse=1).  */
+int clc_gdn_bwd_elem(const float* dy, const float* x, const float* v, float* dx_direct, float* dv, long n, int inverse,
+                     clc_stream_t stream);
+/* dx = dx_direct + 2*x*t  (t = gamma^T . dv from clc_conv2d) */
+int clc_gdn_bwd_combine(const float* dx_direct, const float* x, const float* t, float* dx, long n, clc_stream_t stream);
+
+/* out = a * sigmoid(b) + idn  (SWAtten gate, CLC_run.py:241-242) and its backward */
+int clc_gate_fwd(const float* a, const float* b, const float* idn, float* out, long n, clc_stream_t stream);
+int clc_gate_bwd(const float* dout, const float* a, const float* b, float* da, float* db, long n, clc_stream_t stream);
+
+/* generic fused adds: out = alpha*a + beta*b */
+int clc_axpby(const float* a, float alpha, const float* b, float beta, float* out, long n, clc_stream_t stream);
+/* strided copy of a channel slice: dst[r*ldd + c] = src[r*lds + c] (c < C) */
+int clc_copy2d(const float* src, int lds, float* dst, int ldd, long rows, int C, clc_stream_t stream);
+
+/* ---- window attention (WMSA core, CLC_run.py:142-164) --------------------------------- *
+ * qkv: [B,H,W,3C] tokens, channel = which*C + head*hd + c ; out: [B,H,W,C].
+ * One workgroup per (window, head): softmax(q k^T * hd^-1/2 + relbias[head] (+ shift mask)) v.
+ * shift=1 -> cyclic shift by ws/2 folded into the addressing (torch.roll never materialises).
+ * relbias: [heads][2ws-1][2ws-1] (the parameter itself; the index gather is done in-kernel). */
+/* lse (optional, training): [B*H*W][heads] log-sum-exp of every softmax row, consumed by the backward */
+int clc_winattn_fwd(const float* qkv, int ldq, const float* relbias, float* out, int ldo, float* lse, int B, int H, int W,
+                    int C, int heads, int ws, int shift, clc_stream_t stream);
+/* backward: rebuilds probabilities from qkv + lse, uses the forward output for D = dO.O;
+ * drelbias partials via ws (deterministic) */
+size_t clc_winattn_bwd_workspace_bytes(int B, int H, int W, int heads, int ws);
+int clc_winattn_bwd(const float* dout, int lddo, const float* qkv, int ldq, const float* relbias, const float* out,
+                    int ldo, const float* lse, float* dqkv, int lddq, float* drelbias, int accumulate, int B, int H, int W,
+                    int C, int heads, int ws, int shift, void* wsb, size_t ws_bytes, clc_stream_t stream);
+
+/* ---- entropy-model kernels ------------------------------------------------------------ *
+ * GaussianConditional likelihood + rate (CLC_run.py:569-571, train_CLC.py:48-51)
+ *   mode 0 (train): y_in = y + noise ; mode 1 (eval): y_in = round(y-mu)+mu
+ *   sigma = max(scale, 0.11); lik = max(Phi((.5-|y_in-mu|)/sigma) - Phi((-.5-|..|)/sigma), 1e-9)
+ * Writes lik, y_hat = round(y-mu)+mu (STE value) and adds sum(log2 lik) of this call into
+ * bits_partial[blockIdx] (two-stage deterministic reduction; finish with clc_sum_partials). */
+int clc_gauss_lik_fwd(const float* y, int ldy, const float* mu, int ldmu, const float* scale, int ldsc,
+                      const float* noise, int ldn, float* lik, int ldl, float* y_hat, int ldh, long rows, int C,
+                      int mode, float* bits_partial, int n_partials, clc_stream_t stream);
+/* grads wrt y, mu, scale given dlik (gradient wrt lik) — includes both LowerBound rules */
+int clc_gauss_lik_bwd(const float* dlik, int lddl, const float* y, int ldy, const float* mu, int ldmu,
+                      const float* scale, int ldsc, const float* noise, int ldn, float* dy, int lddy, float* dmu,
+                      int lddmu, float* dscale, int lddsc, long rows, int C, int mode, clc_stream_t stream);
+
+/* number of workgroup partials clc_gauss_lik_fwd writes for (rows, C) */
+int clc_gauss_lik_partials(long rows, int C);
+
+/* EntropyBottleneck factorised density (CLC_run.py:526-530). z/lik: [rows, C] NHWC slices;
+ * matrices/biases/factors: HOST arrays of 5/5/4 device pointers to _matrix{k} [C,f(k+1),f(k)],
+ * _bias{k} [C,f(k+1),1], _factor{k} [C,f(k+1),1]; quantiles [C,1,3].
+ * mode 0 (train): v = z + noise; mode 1 (eval): v = round(z - median) + median. z_hat = round(z-med)+med. */
+int clc_eb_lik_fwd(const float* z, int ldz, const float* noise, int ldn, const float* quantiles,
+                   const float* const* matrices, const float* const* biases, const float* const* factors, float* lik,
+                   int ldl, float* z_hat, int ldh, long rows, int C, int mode, clc_stream_t stream);
+/* parameter gradients are written (not accumulated); dz may be NULL */
+int clc_eb_lik_bwd(const float* dlik, int lddl, const float* z, int ldz, const float* noise, int ldn,
+                   const float* quantiles, const float* const* matrices, const float* const* biases,
+                   const float* const* factors, float* const* dmatrices, float* const* dbiases, float* const* dfactors,
+                   float* dz, int lddz, long rows, int C, int mode, clc_stream_t stream);
+/* aux loss (EntropyBottleneck.loss(), train_CLC.py:181): loss_partial[c] = sum_q |logits(quantiles[c,q]) - target[q]|,
+ * dquantiles[c,q] = d loss / d quantiles (parameters are detached, as in the reference) */
+int clc_eb_aux(const float* quantiles, const float* const* matrices, const float* const* biases,
+               const float* const* factors, const float* target, float* loss_partial, float* dquantiles, int C,
+               clc_stream_t stream);
+
+/* quantize("symbols") + build_indexes (CLC_run.py:689-690): INT path, bit-exact */
+int clc_quantize_build_indexes(const float* y, int ldy, const float* mu, int ldmu, const float* scale, int ldsc,
+                               const float* scale_table, int n_scales, int32_t* symbols, int32_t* indexes,
+                               float* y_hat, int ldh, long rows, int C, clc_stream_t stream);
+
+/* sum of n floats (fixed order) -> out[0] (+)= scale * sum */
+int clc_sum_partials(const float* partials, int n, float scale, float* out, int accumulate, clc_stream_t stream);
+/* sum((a-b)^2) partials */
+int clc_sqdiff_partials(const float* a, const float* b, long n, float* partials, int n_partials, clc_stream_t stream);
+
+/* ---- optimizer ------------------------------------------------------------------------ *
+ * Multi-tensor AdamW + grad-norm clip + nan_to_num (train_CLC.py:164-179) over a flat
+ * table of (param, grad, m, v, numel) entries resident on the device. */
+typedef struct { float* p; float* g; float* m; float* v; long n; } clc_param_entry;
+/* chunks_dev: n_chunks pairs (entry index, element offset); one workgroup per chunk of
+ * clc_optim_chunk_elems() elements.  partials: n_chunks floats (sum g^2 per chunk). */
+int clc_optim_chunk_elems(void);
+int clc_grad_sqnorm_partials(const clc_param_entry* table_dev, const int32_t* chunks_dev, int n_chunks, float* partials,
+                             clc_stream_t stream);
+/* g <- nan_to_num(g * min(1, max_norm/(sqrt(*total_sqnorm_dev)+1e-6))) ; AdamW update with the
+ * step count read from *step_dev (device float, >= 1) so the launch is graph-replayable. */
+int clc_adamw_step(const clc_param_entry* table_dev, const int32_t* chunks_dev, int n_chunks, const float* total_sqnorm_dev,
+                   float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, const float* step_dev,
+                   clc_stream_t stream);
+int clc_scalar_add(float* x_dev, float v, clc_stream_t stream);
+
+/* ---- entropy coder (HOST, bit-exact) --------------------------------------------------- *
+ * Replaces compressai.ans.BufferedRansEncoder/RansDecoder (CLC_run.py:658,712-713,762-763,793),
+ * RansEncoder/RansDecoder.{encode,decode}_with_indexes behind EntropyBottleneck.compress/decompress
+ * (CLC_run.py:643-644,749) and compressai._CXX.pmf_to_quantized_cdf (via update(), CLC_run.py:486-491). */
+long clc_rans_encode_bound(long n_symbols);
+long clc_rans_encode(const int32_t* symbols, const int32_t* indexes, long n, const int32_t* cdfs, int cdf_stride,
+                     const int32_t* cdf_sizes, const int32_t* offsets, uint8_t* out, long out_cap); /* HOST */
+typedef struct clc_rans_decoder clc_rans_decoder;
+clc_rans_decoder* clc_rans_decoder_create(const uint8_t* stream, long nbytes);                    /* HOST, copies */
+long clc_rans_decoder_decode(clc_rans_decoder* d, const int32_t* indexes, long n, const int32_t* cdfs, int cdf_stride,
+                             const int32_t* cdf_sizes, const int32_t* offsets, int32_t* out);      /* HOST */
+void clc_rans_decoder_destroy(clc_rans_decoder* d);
+int clc_pmf_to_quantized_cdf(const float* pmf, int n, int precision, int32_t* cdf_out /* n+1 */);  /* HOST */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLC_HIP_H */

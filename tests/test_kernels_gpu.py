@@ -1,0 +1,338 @@
+"""GPU parity of every HIP kernel (through the C ABI via clc_amd.ops) against plain-PyTorch CPU references.
+
+Tolerances (fp32 kernels on f32 MFMA == exact fmaf chains; the only difference to the CPU
+reference is summation order): rel 2e-5 of the output scale for forward, 1e-4 for gradients
+(long split-K reductions).  Integer outputs (symbols / indexes) must be bit-exact.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CL = torch.channels_last
+
+
+def _close(a, b, tol, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    scale = max(b.abs().max().item(), 1e-6)
+    err = (a - b).abs().max().item() / scale
+    assert err <= tol, f"{what}: rel err {err:.3e} > {tol:.1e} (scale {scale:.3e})"
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _dev(t, dev, cl=True, grad=False):
+    t = t.to(dev)
+    if cl and t.dim() == 4:
+        t = t.contiguous(memory_format=CL)
+    return t.requires_grad_(grad)
+
+
+CONV_CASES = [
+    # N, Cin, H, W, Cout, ks, stride
+    (2, 64, 32, 32, 64, 3, 1),
+    (1, 128, 16, 16, 128, 3, 1),
+    (2, 128, 32, 32, 128, 3, 2),
+    (2, 128, 32, 32, 128, 1, 2),
+    (1, 448, 16, 16, 224, 3, 1),
+    (1, 224, 16, 16, 128, 3, 1),
+    (2, 64, 16, 16, 192, 1, 1),
+    (1, 3, 64, 64, 128, 3, 2),
+    (8, 320, 16, 16, 128, 3, 2),
+    (1, 192, 4, 4, 512, 3, 1),
+    (3, 128, 24, 40, 96, 3, 1),  # ragged: non power-of-two map, Cout not a tile multiple
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("act", [0, 1, 3])
+def test_conv_fwd_bwd(dev, case, act):
+    from clc_amd import ops
+
+    N, Cin, H, W, Cout, ks, stride = case
+    x = _rand((N, Cin, H, W), 1)
+    w = _rand((Cout, Cin, ks, ks), 2, (1.0 / (Cin * ks * ks)) ** 0.5)
+    b = _rand((Cout,), 3, 0.1)
+    xr, wr, br = x.clone().requires_grad_(Cin != 3), w.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = F.conv2d(xr, wr, br, stride=stride, padding=ks // 2)
+    ref = {0: ref, 1: F.leaky_relu(ref, 0.01), 3: F.gelu(ref)}[act]
+    gy = _rand(ref.shape, 4)
+    ref.backward(gy)
+
+    xd, wd, bd = _dev(x, dev, grad=Cin != 3), _dev(w, dev, grad=True), _dev(b, dev, grad=True)
+    y = ops.conv2d(xd, wd, bd, stride=stride, act=act)
+    assert y.shape == ref.shape
+    _close(y, ref, 2e-5, "conv fwd")
+    y.backward(_dev(gy, dev))
+    _close(wd.grad, wr.grad, 1e-4, "conv wgrad")
+    _close(bd.grad, br.grad, 1e-4, "conv bgrad")
+    if Cin != 3:
+        _close(xd.grad, xr.grad, 1e-4, "conv dgrad")
+
+
+def test_conv_residual_slice_shuffle(dev):
+    from clc_amd import ops
+
+    # channel-slice input (split view), residual with scale, lrelu + residual (needs saved pre-activation)
+    N, C, H, W = 2, 128, 32, 32
+    u = _rand((N, C, H, W), 1)
+    w = _rand((64, 64, 3, 3), 2, 0.05)
+    b = _rand((64,), 3, 0.1)
+    ur, wr, br = u.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    cr = ur[:, :64]
+    ref = F.leaky_relu(F.conv2d(cr, wr, br, padding=1), 0.01) + 2.0 * cr
+    gy = _rand(ref.shape, 4)
+    ref.backward(gy)
+    ud, wd, bd = _dev(u, dev, grad=True), _dev(w, dev, grad=True), _dev(b, dev, grad=True)
+    cd = ud[:, :64]
+    y = ops.conv2d(cd, wd, bd, act=1, res=cd, res_scale=2.0)
+    _close(y, ref, 2e-5, "slice+res fwd")
+    y.backward(_dev(gy, dev))
+    _close(ud.grad, ur.grad, 1e-4, "slice+res dgrad")
+    _close(wd.grad, wr.grad, 1e-4, "slice+res wgrad")
+
+    # subpel conv: 3x3 conv + PixelShuffle(2) fused in the store
+    w2 = _rand((4 * 32, 128, 3, 3), 5, 0.03)
+    b2 = _rand((4 * 32,), 6, 0.1)
+    x2 = _rand((2, 128, 16, 16), 7)
+    xr2, wr2, br2 = x2.clone().requires_grad_(), w2.clone().requires_grad_(), b2.clone().requires_grad_()
+    ref2 = F.pixel_shuffle(F.conv2d(xr2, wr2, br2, padding=1), 2)
+    gy2 = _rand(ref2.shape, 8)
+    ref2.backward(gy2)
+    xd2, wd2, bd2 = _dev(x2, dev, grad=True), _dev(w2, dev, grad=True), _dev(b2, dev, grad=True)
+    y2 = ops.conv2d(xd2, wd2, bd2, shuffle=True)
+    _close(y2, ref2, 2e-5, "subpel fwd")
+    y2.backward(_dev(gy2, dev))
+    _close(xd2.grad, xr2.grad, 1e-4, "subpel dgrad")
+    _close(wd2.grad, wr2.grad, 1e-4, "subpel wgrad")
+    _close(bd2.grad, br2.grad, 1e-4, "subpel bgrad")
+
+
+def test_conv_batch_invariance_and_determinism(dev):
+    """Encoder/decoder agreement needs bitwise identical results for an image regardless of batch size / tile config."""
+    from clc_amd import ops
+
+    x = _rand((8, 448, 16, 16), 1)
+    w = _rand((224, 448, 3, 3), 2, 0.02)
+    xd, wd = _dev(x, dev), _dev(w, dev)
+    with torch.no_grad():
+        y8 = ops.conv2d(xd, wd, None)
+        y1 = ops.conv2d(xd[3:4].contiguous(memory_format=CL), wd, None)
+        y8b = ops.conv2d(xd, wd, None)
+    assert torch.equal(y8[3:4], y1), "result depends on the batch size"
+    assert torch.equal(y8, y8b), "not run-to-run deterministic"
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_gdn(dev, inverse):
+    from clc_amd import ops
+    from oracle.leaves import GDN
+
+    C = 128
+    m = GDN(C, inverse=inverse)
+    with torch.no_grad():
+        m.gamma.add_(0.02 * torch.rand(C, C, generator=torch.Generator().manual_seed(1)))
+    x = _rand((2, C, 16, 16), 2).requires_grad_()
+    res = _rand((2, C, 16, 16), 5)
+    ref = m(x) + res
+    gy = _rand(ref.shape, 3)
+    ref.backward(gy)
+    beta_eff = m.beta_reparam(m.beta).detach()
+    gamma_eff = m.gamma_reparam(m.gamma).detach()
+    # reference grads w.r.t. the effective (re-parametrised) tensors
+    be, ge = beta_eff.clone().requires_grad_(), gamma_eff.clone().requires_grad_()
+    x2 = x.detach().clone().requires_grad_()
+    norm = F.conv2d(x2 ** 2, ge.reshape(C, C, 1, 1), be)
+    r2 = x2 * (torch.sqrt(norm) if inverse else torch.rsqrt(norm)) + res
+    r2.backward(gy)
+    xd = _dev(x.detach(), dev, grad=True)
+    gd, bd = _dev(gamma_eff, dev, grad=True), _dev(beta_eff, dev, grad=True)
+    y = ops.gdn(xd, gd, bd, inverse=inverse, res=_dev(res, dev))
+    _close(y, ref, 2e-5, "gdn fwd")
+    y.backward(_dev(gy, dev))
+    _close(xd.grad, x2.grad, 1e-4, "gdn dx")
+    _close(gd.grad, ge.grad, 1e-4, "gdn dgamma")
+    _close(bd.grad, be.grad, 1e-4, "gdn dbeta")
+
+
+@pytest.mark.parametrize("C", [64, 128])
+def test_layernorm(dev, C):
+    from clc_amd import ops
+
+    x = _rand((2, C, 16, 24), 1, 2.0).requires_grad_()
+    g = (1 + 0.1 * _rand((C,), 2)).requires_grad_()
+    b = (0.1 * _rand((C,), 3)).requires_grad_()
+    ref = F.layer_norm(x.permute(0, 2, 3, 1), (C,), g, b).permute(0, 3, 1, 2)
+    gy = _rand(ref.shape, 4)
+    ref.backward(gy)
+    xd, gd, bd = _dev(x.detach(), dev, grad=True), _dev(g.detach(), dev, grad=True), _dev(b.detach(), dev, grad=True)
+    y = ops.layernorm(xd, gd, bd)
+    _close(y, ref, 2e-5, "ln fwd")
+    y.backward(_dev(gy, dev))
+    _close(xd.grad, x.grad, 1e-4, "ln dx")
+    _close(gd.grad, g.grad, 1e-4, "ln dgamma")
+    _close(bd.grad, b.grad, 1e-4, "ln dbeta")
+
+
+def _ref_wmsa_core(qkv_nchw, relbias, heads, ws, shift):
+    """attention core of the oracle WMSA (no projections) on [N,3C,H,W]."""
+    from oracle.graph import WMSA
+
+    N, C3, H, W = qkv_nchw.shape
+    C = C3 // 3
+    m = WMSA(C, C, C // heads, ws, "SW" if shift else "W")
+    m.relative_position_params = torch.nn.Parameter(relbias)
+    x = qkv_nchw.permute(0, 2, 3, 1)
+    sh = ws // 2
+    if shift:
+        x = torch.roll(x, shifts=(-sh, -sh), dims=(1, 2))
+    hw, ww = H // ws, W // ws
+    xw = x.reshape(N, hw, ws, ww, ws, C3).permute(0, 1, 3, 2, 4, 5).reshape(N, hw * ww, ws * ws, C3)
+    hd = C // heads
+    qkv = xw.reshape(N, hw * ww, ws * ws, 3 * heads, hd).permute(3, 0, 1, 2, 4)
+    q, k, v = qkv[:heads], qkv[heads:2 * heads], qkv[2 * heads:]
+    sim = torch.matmul(q, k.transpose(-1, -2)) * hd ** -0.5 + m.rel_bias()[:, None, None]
+    if shift:
+        sim = sim.masked_fill(m.shift_mask(hw, ww)[None, None], float("-inf"))
+    out = torch.matmul(torch.softmax(sim, -1), v).permute(1, 2, 3, 0, 4).reshape(N, hw * ww, ws * ws, C)
+    out = out.reshape(N, hw, ww, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(N, H, W, C)
+    if shift:
+        out = torch.roll(out, shifts=(sh, sh), dims=(1, 2))
+    return out.permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("cfg", [(64, 8, 8, 32, 32), (64, 4, 8, 16, 24), (64, 2, 8, 16, 16), (128, 8, 8, 16, 16), (64, 2, 4, 8, 8), (64, 2, 4, 8, 16)])
+@pytest.mark.parametrize("shift", [False, True])
+def test_window_attention(dev, cfg, shift):
+    from clc_amd import ops
+
+    C, heads, ws, H, W = cfg
+    N = 2
+    qkv = _rand((N, 3 * C, H, W), 1).requires_grad_()
+    rb = _rand((heads, 2 * ws - 1, 2 * ws - 1), 2, 0.5).requires_grad_()
+    ref = _ref_wmsa_core(qkv, rb, heads, ws, shift)
+    gy = _rand(ref.shape, 3)
+    ref.backward(gy)
+    qd, rd = _dev(qkv.detach(), dev, grad=True), _dev(rb.detach(), dev, grad=True)
+    y = ops.window_attention(qd, rd, heads, ws, shift)
+    _close(y, ref, 2e-5, "attn fwd")
+    y.backward(_dev(gy, dev))
+    _close(qd.grad, qkv.grad, 1e-4, "attn dqkv")
+    _close(rd.grad, rb.grad, 1e-4, "attn drelbias")
+
+
+def test_gate(dev):
+    from clc_amd import ops
+
+    a, b, i = (_rand((2, 128, 16, 16), s).requires_grad_() for s in (1, 2, 3))
+    ref = a * torch.sigmoid(b) + i
+    gy = _rand(ref.shape, 4)
+    ref.backward(gy)
+    ad, bd, idd = (_dev(t.detach(), dev, grad=True) for t in (a, b, i))
+    y = ops.gate(ad, bd, idd)
+    _close(y, ref, 1e-6, "gate fwd")
+    y.backward(_dev(gy, dev))
+    _close(ad.grad, a.grad, 1e-5, "gate da")
+    _close(bd.grad, b.grad, 1e-5, "gate db")
+    _close(idd.grad, i.grad, 1e-6, "gate didn")
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_gaussian_likelihood(dev, training):
+    from clc_amd import ops
+    from oracle.leaves import GaussianConditional
+
+    gc = GaussianConditional(None)
+    y = _rand((2, 64, 16, 16), 1, 3.0).requires_grad_()
+    mu = _rand((2, 64, 16, 16), 2, 1.0).requires_grad_()
+    sc = (_rand((2, 64, 16, 16), 3, 1.0) + 0.5).requires_grad_()  # some below the 0.11 bound, some negative
+    noise = torch.rand((2, 64, 16, 16), generator=torch.Generator().manual_seed(4)) - 0.5
+    if training:
+        lik = gc._likelihood(y + noise, sc, mu)
+    else:
+        lik = gc._likelihood(torch.round(y - mu) + mu, sc, mu)
+    lik = gc.likelihood_lower_bound(lik)
+    w = torch.rand(lik.shape, generator=torch.Generator().manual_seed(5)) - 0.7  # mixed-sign upstream grads (LowerBound rule)
+    (lik * w).sum().backward()
+    yd, md, sd = (_dev(t.detach(), dev, grad=True) for t in (y, mu, sc))
+    l2 = ops.gaussian_likelihood(yd, sd, md, _dev(noise, dev) if training else None, training)
+    _close(l2, lik, 1e-5, "gauss lik")
+    # relative check in log domain for the tails
+    assert (torch.log(l2.cpu()) - torch.log(lik.detach())).abs().max() < 2e-3
+    (l2 * _dev(w, dev)).sum().backward()
+    _close(sd.grad, sc.grad, 2e-4, "gauss dscale")
+    if training:
+        _close(yd.grad, y.grad, 2e-4, "gauss dy")
+        _close(md.grad, mu.grad, 2e-4, "gauss dmu")
+    else:
+        assert yd.grad is None or float(yd.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_entropy_bottleneck_likelihood(dev, training):
+    from clc_amd import ops
+    from oracle.leaves import EntropyBottleneck
+    from oracle.recipe import apply_weight_recipe
+
+    C = 192
+    eb = EntropyBottleneck(C)
+    apply_weight_recipe(eb, 3)
+    eb.train(training)
+    z = _rand((8, C, 4, 4), 1, 2.0).requires_grad_()
+    noise = torch.rand(z.shape, generator=torch.Generator().manual_seed(4)) - 0.5
+    med = eb._get_medians().reshape(1, C, 1, 1)
+    v = z + noise if training else torch.round(z - med) + med
+    vv = v.permute(1, 0, 2, 3).reshape(C, 1, -1)
+    lik = eb.likelihood_lower_bound(eb._likelihood(vv)).reshape(C, 8, 4, 4).permute(1, 0, 2, 3)
+    w = torch.rand(lik.shape, generator=torch.Generator().manual_seed(5)) - 0.3
+    (lik * w).sum().backward()
+    mats = [getattr(eb, f"_matrix{k}") for k in range(5)]
+    biases = [getattr(eb, f"_bias{k}") for k in range(5)]
+    factors = [getattr(eb, f"_factor{k}") for k in range(4)]
+    md, bd, fd = ([_dev(t.detach(), dev, cl=False, grad=True) for t in ts] for ts in (mats, biases, factors))
+    zd = _dev(z.detach(), dev, grad=True)
+    qd = _dev(eb.quantiles.detach(), dev, cl=False)
+    l2 = ops.eb_likelihood(zd, _dev(noise, dev) if training else None, qd, training, md, bd, fd)
+    _close(l2, lik, 1e-5, "eb lik")
+    (l2 * _dev(w, dev)).sum().backward()
+    for k in range(5):
+        _close(md[k].grad, mats[k].grad, 2e-4, f"eb dmatrix{k}")
+        _close(bd[k].grad, biases[k].grad, 2e-4, f"eb dbias{k}")
+    for k in range(4):
+        _close(fd[k].grad, factors[k].grad, 2e-4, f"eb dfactor{k}")
+    if training:
+        _close(zd.grad, z.grad, 2e-4, "eb dz")
+    # aux loss
+    eb.zero_grad()
+    aux = eb.loss()
+    aux.backward()
+    qg = _dev(eb.quantiles.detach(), dev, cl=False, grad=True)
+    a2 = ops.eb_aux_loss(qg, _dev(eb.target, dev, cl=False), md, bd, fd)
+    _close(a2, aux, 1e-5, "eb aux")
+    a2.backward()
+    _close(qg.grad, eb.quantiles.grad, 1e-4, "eb dquantiles")
+
+
+def test_quantize_build_indexes_bit_exact(dev):
+    from clc_amd import ops
+    from oracle.leaves import GaussianConditional, get_scale_table
+
+    gc = GaussianConditional(None)
+    gc.scale_table = get_scale_table()
+    y = _rand((1, 64, 16, 16), 1, 4.0)
+    mu = _rand((1, 64, 16, 16), 2, 1.0)
+    sc = torch.exp(_rand((1, 64, 16, 16), 3, 2.0))
+    sc.view(-1)[:64] = gc.scale_table  # exactly on the thresholds
+    sc.view(-1)[64:70] = torch.tensor([0.0, -1.0, 0.11, 0.10999, 256.0, 1e4])
+    sym_ref = gc.quantize(y, "symbols", mu)
+    idx_ref = gc.build_indexes(sc)
+    sym, idx, y_hat = ops.quantize_build_indexes(_dev(y, dev), _dev(mu, dev), _dev(sc, dev), gc.scale_table.to(dev))
+    assert torch.equal(sym.cpu(), sym_ref), "symbols differ"
+    assert torch.equal(idx.cpu(), idx_ref), "indexes differ"
+    assert torch.equal(y_hat.cpu(), sym_ref.float() + mu)
