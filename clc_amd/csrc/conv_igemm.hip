@@ -30,7 +30,7 @@ struct ConvParams {
   const float* mul; const float* res; float* y_pre;
   int N, H, W, Cin, ldx;       // source tensor geometry
   int OH, OW, Cout, ldy;       // destination geometry (pre-shuffle)
-  int ks, stride, pad, transposed, in_op, act, norm, shuffle;
+  int ks, stride, pad, transposed, in_op, act, norm, shuffle, res_first;
   int ldm, ldr, ldp, ldw;
   float res_scale;
   int M;                       // rows per class (transposed&stride2: per parity class)
@@ -205,13 +205,14 @@ void conv_igemm_kernel(const ConvParams p) {
           pix = (size_t)m;
         }
         float v = acc[i][j][r] + bv;
+        if (p.res && p.res_first) v += p.res_scale * p.res[pix * p.ldr + ch];
         if (p.y_pre) p.y_pre[pix * p.ldp + ch] = v;
         if (p.norm != CLC_NORM_NONE) {
           const float mv = p.mul[pix * p.ldm + ch];
           v = (p.norm == CLC_NORM_GDN) ? mv * rsqrtf(v) : mv * sqrtf(v);
         }
         v = apply_act(v, p.act);
-        if (p.res) v += p.res_scale * p.res[pix * p.ldr + ch];
+        if (p.res && !p.res_first) v += p.res_scale * p.res[pix * p.ldr + ch];
         p.y[pix * p.ldy + ch] = v;
       }
     }
@@ -271,13 +272,14 @@ __global__ void conv_direct_small_kernel(const ConvParams p) {
       ch = co >> 2;
       pix = (size_t)(n * 2 * p.OH + 2 * oy + ((co >> 1) & 1)) * (2 * p.OW) + 2 * ox + (co & 1);
     }
+    if (p.res && p.res_first) v += p.res_scale * p.res[pix * p.ldr + ch];
     if (p.y_pre) p.y_pre[pix * p.ldp + ch] = v;
     if (p.norm != CLC_NORM_NONE) {
       const float mv = p.mul[pix * p.ldm + ch];
       v = (p.norm == CLC_NORM_GDN) ? mv * rsqrtf(v) : mv * sqrtf(v);
     }
     v = apply_act(v, p.act);
-    if (p.res) v += p.res_scale * p.res[pix * p.ldr + ch];
+    if (p.res && !p.res_first) v += p.res_scale * p.res[pix * p.ldr + ch];
     p.y[pix * p.ldy + ch] = v;
   }
 }
@@ -328,7 +330,7 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.ldx = d->ldx;
   p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout; p.ldy = d->ldy;
   p.ks = d->ks; p.stride = d->stride; p.pad = d->pad; p.transposed = d->transposed; p.in_op = d->in_op;
-  p.act = d->act; p.norm = d->norm; p.shuffle = d->shuffle;
+  p.act = d->act; p.norm = d->norm; p.shuffle = d->shuffle; p.res_first = d->res_first;
   p.ldm = d->ldm; p.ldr = d->ldr; p.ldp = d->ldp; p.ldw = d->ks * d->ks * d->Cin; p.res_scale = d->res_scale;
   p.kc_tiles = (d->Cin + BK - 1) / BK;
   int classes = 1;

@@ -131,6 +131,11 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, int lddy, const flo
         d = cdf + s * 0.39894228040143267794f * expf(-0.5f * s * s);
         break;
       }
+      case CLC_ACT_HALFTANH: {
+        const float t = use_pre ? tanhf(s) : 2.f * s;  // output = 0.5*tanh(v)
+        d = 0.5f * (1.f - t * t);
+        break;
+      }
       default: d = 1.f;
     }
     dz[r * lddz + c] = g * d;
@@ -234,9 +239,57 @@ __global__ __launch_bounds__(256) void sqdiff_partials_kernel(const float* __res
   if (threadIdx.x == 0) partials[blockIdx.x] = sm[0];
 }
 
+__global__ __launch_bounds__(256) void log2_sum_partials_kernel(const float* __restrict__ x, int ld, long rows, int C, float* __restrict__ partials) {
+  __shared__ float sm[4];
+  const long total = rows * C;
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / C;
+    s += log2f(x[r * ld + (i - r * C)]);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+__global__ void scaled_recip_kernel(const float* __restrict__ x, int ld, long rows, int C, const float* __restrict__ g, float coef,
+                                    float* __restrict__ out, int ldo) {
+  const long total = rows * C;
+  const float k = g[0] * coef;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    out[r * ldo + c] = k / x[r * ld + c];
+  }
+}
+__global__ void scaled_diff_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, const float* __restrict__ g, float coef,
+                                   float* __restrict__ out) {
+  const float k = g[0] * coef;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = k * (a[i] - b[i]);
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
+
+extern "C" int clc_log2_sum_partials(const float* x, int ld, long rows, int C, float* partials, int n_partials, clc_stream_t stream) {
+  CLC_CHECK(x && partials && rows > 0 && C > 0 && n_partials > 0 && n_partials <= kMaxBlocks, "clc_log2_sum_partials: bad args");
+  hipLaunchKernelGGL(log2_sum_partials_kernel, dim3(n_partials), dim3(256), 0, ST, x, ld, rows, C, partials);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int clc_scaled_recip(const float* x, int ld, long rows, int C, const float* g_dev, float coef, float* out, int ldo, clc_stream_t stream) {
+  CLC_CHECK(x && g_dev && out && rows > 0 && C > 0, "clc_scaled_recip: bad args");
+  hipLaunchKernelGGL(scaled_recip_kernel, dim3(grid_for(rows * C, 1024)), dim3(256), 0, ST, x, ld, rows, C, g_dev, coef, out, ldo);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int clc_scaled_diff(const float* a, const float* b, long n, const float* g_dev, float coef, float* out, clc_stream_t stream) {
+  CLC_CHECK(a && b && g_dev && out && n > 0, "clc_scaled_diff: bad args");
+  hipLaunchKernelGGL(scaled_diff_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, ST, a, b, n, g_dev, coef, out);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int clc_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, float* mean,
                                  float* rstd, long rows, int C, clc_stream_t stream) {
@@ -271,6 +324,7 @@ extern "C" int clc_act_bwd(const float* dy, int lddy, const float* saved, int ld
                            int C, clc_stream_t stream) {
   CLC_CHECK(dy && saved && dz && rows > 0 && C > 0, "clc_act_bwd: bad args");
   CLC_CHECK(!(act == CLC_ACT_GELU && !use_pre), "clc_act_bwd: GELU needs the pre-activation");
+  CLC_CHECK(act >= CLC_ACT_NONE && act <= CLC_ACT_HALFTANH, "clc_act_bwd: unknown activation %d", act);
   hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(rows * C, 1024)), dim3(256), 0, ST, dy, lddy, saved, lds, use_pre, act, dz, lddz, rows, C);
   CLC_LAUNCH_CHECK();
   return 0;

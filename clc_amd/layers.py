@@ -1,0 +1,301 @@
+"""MI355X-native layer library with the CompressAI / reference module surface.
+
+Same class names, constructor arguments, parameter / buffer names and shapes as
+``compressai.layers`` and the in-tree blocks of
+/root/reference/models/CLC_run.py:108-313, so ``state_dict`` round-trips with reference
+checkpoints — but every forward runs on the HIP kernels of libclc_hip.so through
+``clc_amd.ops`` with the blocks' elementwise tails fused into conv epilogues:
+
+  ResidualBlockWithStride   conv3x3/s2+LeakyReLU | conv3x3 | GDN(+skip) — GDN = 1x1 conv with square-on-load
+                            and x*rsqrt(.) epilogue, the skip branch added in the same epilogue
+  ResidualBlockUpsample     subpel conv (PixelShuffle fused in the store)+LeakyReLU | conv3x3 | IGDN(+upsample)
+  ResidualBlock             second conv carries LeakyReLU + k*identity in its epilogue
+  ResidualUnit              relu(conv(x) + x) in the last 1x1's epilogue
+  Block                     LN | qkv GEMM | window attention | proj(+residual) | LN | fc1+GELU | fc2(+residual)
+
+Activations stay logical NCHW in channels_last memory (= NHWC), so no permute ever runs.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, CL
+
+
+class _LowerBoundFn(torch.autograd.Function):
+    """max(x, bound); gradient passes where x >= bound or the gradient pushes x up (CompressAI LowerBound)."""
+
+    @staticmethod
+    def forward(ctx, x, bound):
+        ctx.save_for_backward(x, bound)
+        return torch.max(x, bound)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, bound = ctx.saved_tensors
+        return ((x >= bound) | (g < 0)).type(g.dtype) * g, None
+
+
+class LowerBound(nn.Module):
+    def __init__(self, bound: float):
+        super().__init__()
+        self.register_buffer("bound", torch.Tensor([float(bound)]))
+
+    def forward(self, x):
+        return _LowerBoundFn.apply(x, self.bound)
+
+
+class NonNegativeParametrizer(nn.Module):
+    def __init__(self, minimum: float = 0, reparam_offset: float = 2 ** -18):
+        super().__init__()
+        pedestal = float(reparam_offset) ** 2
+        self.register_buffer("pedestal", torch.Tensor([pedestal]))
+        self.lower_bound = LowerBound((float(minimum) + pedestal) ** 0.5)
+
+    def init(self, x):
+        return torch.sqrt(torch.max(x + self.pedestal, self.pedestal))
+
+    def forward(self, x):
+        return self.lower_bound(x) ** 2 - self.pedestal
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d parameters (weight kept channels_last = [Cout][kh][kw][Cin]); forward on the implicit-GEMM kernel."""
+
+    def __init__(self, in_ch, out_ch, kernel_size, stride=1, padding=None, bias=True):
+        padding = kernel_size // 2 if padding is None else padding
+        if kernel_size not in (1, 3) or padding != kernel_size // 2 or stride not in (1, 2):
+            raise ValueError("clc_amd.layers.Conv2d supports 1x1 / 3x3 'same' convolutions with stride 1 or 2")
+        super().__init__(in_ch, out_ch, kernel_size, stride=stride, padding=padding, bias=bias)
+        self.weight.data = self.weight.data.contiguous(memory_format=CL)
+
+    def forward(self, x, act=ACT_NONE, res=None, res_scale=1.0, res_first=False, shuffle=False):
+        return ops.conv2d(x, self.weight, self.bias, stride=self.stride[0], act=act, res=res, res_scale=res_scale,
+                          res_first=res_first, shuffle=shuffle)
+
+
+class Linear(nn.Linear):
+    """nn.Linear over the channel dim of a pixel-major [N,C,H,W] tensor (tokens are pixels)."""
+
+    def forward(self, x, act=ACT_NONE, res=None):
+        return ops.linear(x, self.weight, self.bias, act=act, res=res)
+
+
+class LayerNorm(nn.LayerNorm):
+    def forward(self, x):
+        return ops.layernorm(x, self.weight, self.bias)
+
+
+class GELU(nn.Module):
+    """Placeholder keeping the reference's Sequential indices (``mlp.1`` / ``*.1``, ``*.3``); fused into the producer."""
+
+    def forward(self, x):  # pragma: no cover - never called, the producer conv applies it
+        raise RuntimeError("GELU is fused into the preceding layer's epilogue")
+
+
+class PixelShuffle2(nn.Module):
+    """Placeholder for nn.PixelShuffle(2) (fused into the producing conv's store)."""
+
+    def forward(self, x):  # pragma: no cover
+        raise RuntimeError("PixelShuffle is fused into the preceding conv's store")
+
+
+def conv3x3(i, o, stride=1):
+    return Conv2d(i, o, 3, stride=stride)
+
+
+def conv1x1(i, o, stride=1):
+    return Conv2d(i, o, 1, stride=stride)
+
+
+class SubpelConv3x3(nn.Sequential):
+    """Sequential(Conv2d(i, o*r^2, 3), PixelShuffle(r)) — parameter names ``0.weight`` / ``0.bias``."""
+
+    def __init__(self, i, o, r=2):
+        assert r == 2
+        super().__init__(Conv2d(i, o * r * r, 3), PixelShuffle2())
+
+    def forward(self, x, act=ACT_NONE, res=None):
+        return self[0](x, act=act, res=res, shuffle=True)
+
+
+def subpel_conv3x3(i, o, r=1):
+    return SubpelConv3x3(i, o, r)
+
+
+class GDN(nn.Module):
+    def __init__(self, in_channels, inverse=False, beta_min=1e-6, gamma_init=0.1):
+        super().__init__()
+        self.inverse = bool(inverse)
+        self.beta_reparam = NonNegativeParametrizer(minimum=float(beta_min))
+        self.beta = nn.Parameter(self.beta_reparam.init(torch.ones(in_channels)))
+        self.gamma_reparam = NonNegativeParametrizer()
+        self.gamma = nn.Parameter(self.gamma_reparam.init(float(gamma_init) * torch.eye(in_channels)))
+
+    def forward(self, x, res=None):
+        beta = self.beta_reparam(self.beta)      # [C]   tiny parameter-sized torch ops
+        gamma = self.gamma_reparam(self.gamma)   # [C,C]
+        return ops.gdn(x, gamma, beta, inverse=self.inverse, res=res)
+
+
+class ResidualBlockWithStride(nn.Module):
+    def __init__(self, in_ch, out_ch, stride=2):
+        super().__init__()
+        self.conv1 = conv3x3(in_ch, out_ch, stride=stride)
+        self.leaky_relu = nn.LeakyReLU(inplace=True)
+        self.conv2 = conv3x3(out_ch, out_ch)
+        self.gdn = GDN(out_ch)
+        self.skip = conv1x1(in_ch, out_ch, stride=stride) if (stride != 1 or in_ch != out_ch) else None
+
+    def forward(self, x):
+        t = self.conv2(self.conv1(x, act=ACT_LRELU))
+        identity = self.skip(x) if self.skip is not None else x
+        return self.gdn(t, res=identity)
+
+
+class ResidualBlockUpsample(nn.Module):
+    def __init__(self, in_ch, out_ch, upsample=2):
+        super().__init__()
+        self.subpel_conv = subpel_conv3x3(in_ch, out_ch, upsample)
+        self.leaky_relu = nn.LeakyReLU(inplace=True)
+        self.conv = conv3x3(out_ch, out_ch)
+        self.igdn = GDN(out_ch, inverse=True)
+        self.upsample = subpel_conv3x3(in_ch, out_ch, upsample)
+
+    def forward(self, x):
+        t = self.conv(self.subpel_conv(x, act=ACT_LRELU))
+        return self.igdn(t, res=self.upsample(x))
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.conv1 = conv3x3(in_ch, out_ch)
+        self.leaky_relu = nn.LeakyReLU(inplace=True)
+        self.conv2 = conv3x3(out_ch, out_ch)
+        self.skip = conv1x1(in_ch, out_ch) if in_ch != out_ch else None
+
+    def forward(self, x, extra_identity=0.0):
+        """lrelu(conv2(lrelu(conv1 x))) + identity (+ extra_identity * x, used by ConvTransBlock's `+ conv_x`)."""
+        t = self.conv1(x, act=ACT_LRELU)
+        if self.skip is None:
+            return self.conv2(t, act=ACT_LRELU, res=x, res_scale=1.0 + extra_identity)
+        out = self.conv2(t, act=ACT_LRELU, res=self.skip(x))
+        return out + extra_identity * x if extra_identity else out
+
+
+class ResidualUnit(nn.Module):
+    def __init__(self, N):
+        super().__init__()
+        self.conv = nn.Sequential(conv1x1(N, N // 2), nn.ReLU(inplace=True), conv3x3(N // 2, N // 2), nn.ReLU(inplace=True),
+                                  conv1x1(N // 2, N))
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        t = self.conv[0](x, act=ACT_RELU)
+        t = self.conv[2](t, act=ACT_RELU)
+        return self.conv[4](t, act=ACT_RELU, res=x, res_first=True)
+
+
+class AttentionBlock(nn.Module):
+    def __init__(self, N):
+        super().__init__()
+        self.conv_a = nn.Sequential(ResidualUnit(N), ResidualUnit(N), ResidualUnit(N))
+        self.conv_b = nn.Sequential(ResidualUnit(N), ResidualUnit(N), ResidualUnit(N), conv1x1(N, N))
+
+    def forward(self, x):
+        return ops.gate(self.conv_a(x), self.conv_b(x), x)
+
+
+# ----------------------------------------------------------------------------- Swin-style blocks
+
+
+class WMSA(nn.Module):
+    """Window multi-head self-attention (/root/reference/models/CLC_run.py:108-169) on pixel-major tensors."""
+
+    def __init__(self, input_dim, output_dim, head_dim, window_size, type):
+        super().__init__()
+        self.input_dim, self.output_dim, self.head_dim = input_dim, output_dim, head_dim
+        self.n_heads = input_dim // head_dim
+        self.window_size, self.type = window_size, type
+        self.scale = head_dim ** -0.5
+        self.embedding_layer = Linear(input_dim, 3 * input_dim, bias=True)
+        self.relative_position_params = nn.Parameter(
+            torch.nn.init.trunc_normal_(torch.zeros(self.n_heads, 2 * window_size - 1, 2 * window_size - 1), std=0.02))
+        self.linear = Linear(input_dim, output_dim)
+
+    def forward(self, x, res=None):
+        qkv = self.embedding_layer(x)
+        a = ops.window_attention(qkv, self.relative_position_params, self.n_heads, self.window_size, self.type != "W")
+        return self.linear(a, res=res)
+
+
+class Block(nn.Module):
+    def __init__(self, input_dim, output_dim, head_dim, window_size, drop_path, type="W", input_resolution=None):
+        super().__init__()
+        assert type in ("W", "SW")
+        if drop_path:
+            raise ValueError("drop_path > 0 is not supported (the reference always passes 0)")
+        self.type = type
+        self.ln1 = LayerNorm(input_dim)
+        self.msa = WMSA(input_dim, input_dim, head_dim, window_size, type)
+        self.drop_path = nn.Identity()
+        self.ln2 = LayerNorm(input_dim)
+        self.mlp = nn.Sequential(Linear(input_dim, 4 * input_dim), GELU(), Linear(4 * input_dim, output_dim))
+
+    def forward(self, x):
+        x = self.msa(self.ln1(x), res=x)
+        h = self.mlp[0](self.ln2(x), act=ACT_GELU)
+        return self.mlp[2](h, res=x)
+
+
+class ConvTransBlock(nn.Module):
+    def __init__(self, conv_dim, trans_dim, head_dim, window_size, drop_path, type="W"):
+        super().__init__()
+        self.conv_dim, self.trans_dim = conv_dim, trans_dim
+        self.trans_block = Block(trans_dim, trans_dim, head_dim, window_size, drop_path, type)
+        self.conv1_1 = Conv2d(conv_dim + trans_dim, conv_dim + trans_dim, 1)
+        self.conv1_2 = Conv2d(conv_dim + trans_dim, conv_dim + trans_dim, 1)
+        self.conv_block = ResidualBlock(conv_dim, conv_dim)
+
+    def forward(self, x):
+        u = self.conv1_1(x)
+        c, t = u[:, : self.conv_dim], u[:, self.conv_dim:]   # channel-slice views, read in place by the kernels
+        c = self.conv_block(c, extra_identity=1.0)
+        t = self.trans_block(t)
+        return self.conv1_2(torch.cat((c, t), dim=1), res=x)
+
+
+class SwinBlock(nn.Module):
+    def __init__(self, input_dim, output_dim, head_dim, window_size, drop_path):
+        super().__init__()
+        self.block_1 = Block(input_dim, output_dim, head_dim, window_size, drop_path, type="W")
+        self.block_2 = Block(input_dim, output_dim, head_dim, window_size, drop_path, type="SW")
+        self.window_size = window_size
+
+    def forward(self, x):
+        if x.size(-1) <= self.window_size or x.size(-2) <= self.window_size:
+            raise ValueError("SwinBlock: feature map must be larger than the window (input must be >= 256x256)")
+        return self.block_2(self.block_1(x))
+
+
+class SWAtten(AttentionBlock):
+    def __init__(self, input_dim, output_dim, head_dim, window_size, drop_path, inter_dim=192):
+        if inter_dim is not None:
+            super().__init__(N=inter_dim)
+            self.non_local_block = SwinBlock(inter_dim, inter_dim, head_dim, window_size, drop_path)
+            self.in_conv = conv1x1(input_dim, inter_dim)
+            self.out_conv = conv1x1(inter_dim, output_dim)
+        else:
+            super().__init__(N=input_dim)
+            self.non_local_block = SwinBlock(input_dim, input_dim, head_dim, window_size, drop_path)
+            self.in_conv = self.out_conv = None
+
+    def forward(self, x):
+        if self.in_conv is not None:
+            x = self.in_conv(x)
+        z = self.non_local_block(x)
+        out = ops.gate(self.conv_a(x), self.conv_b(z), x)
+        return self.out_conv(out) if self.out_conv is not None else out

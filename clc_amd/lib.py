@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclc_hip.so")
 
-ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU = 0, 1, 2, 3
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU, ACT_HALFTANH = 0, 1, 2, 3, 4
 IN_NONE, IN_SQUARE = 0, 1
 NORM_NONE, NORM_GDN, NORM_IGDN = 0, 1, 2
 
@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
                 ("norm", C.c_int), ("mul", fp), ("ldm", C.c_int),
                 ("res", fp), ("ldr", C.c_int), ("res_scale", C.c_float),
                 ("y_pre", fp), ("ldp", C.c_int),
-                ("shuffle", C.c_int)]
+                ("shuffle", C.c_int), ("res_first", C.c_int)]
 
 
 class WgradDesc(C.Structure):
@@ -76,6 +76,9 @@ SIGNATURES = {
     "clc_eb_lik_bwd": (_i, [fp, _i, fp, _i, fp, _i, fp, _pp, _pp, _pp, _pp, _pp, _pp, fp, _i, _l, _i, _i, fp]),
     "clc_eb_aux": (_i, [fp, _pp, _pp, _pp, fp, fp, fp, _i, fp]),
     "clc_quantize_build_indexes": (_i, [fp, _i, fp, _i, fp, _i, fp, _i, fp, fp, fp, _i, _l, _i, fp]),
+    "clc_log2_sum_partials": (_i, [fp, _i, _l, _i, fp, _i, fp]),
+    "clc_scaled_recip": (_i, [fp, _i, _l, _i, fp, _f, fp, _i, fp]),
+    "clc_scaled_diff": (_i, [fp, fp, _l, fp, _f, fp, fp]),
     "clc_sum_partials": (_i, [fp, _i, _f, fp, _i, fp]),
     "clc_sqdiff_partials": (_i, [fp, fp, _l, fp, _i, fp]),
     "clc_optim_chunk_elems": (_i, []),

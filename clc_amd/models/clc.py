@@ -1,0 +1,347 @@
+"""CLC / TCM compression models on the MI355X engine — same surface as the reference classes.
+
+Mirrors /root/reference/models/CLC_run.py:316-814 (CLC) and /root/reference/models/tcm.py:310-626 (TCM):
+constructor signature, ``forward(x, ref_frames=None)`` output dict, ``compress`` / ``decompress`` /
+``update`` / ``aux_loss`` / ``load_state_dict`` and every parameter / buffer name,
+so ``train_CLC.py`` / ``eval_CLC.py`` can construct and drive it unchanged.
+
+What is different underneath (MI355X-first, not a translation):
+  * activations are channels_last (NHWC) end to end; ``y.chunk`` / ``split`` are strided views the kernels
+    read through their leading dimension; no Rearrange/permute/roll/mask tensor is ever built;
+  * the R reference images go through the shared ReferenceEncoder as ONE batched call;
+  * per slice, likelihood + STE rounding is one kernel, the LRP head's ``0.5*tanh(.) + y_hat`` is the
+    last conv's epilogue, GELU/LeakyReLU/ReLU/GDN/residual adds are conv epilogues;
+  * compress(): symbols and CDF indexes come from one integer kernel per slice into int32 buffers, the CDF
+    tables are copied to the host once per model (not ``.tolist()`` per call), and the C++ rANS coder works
+    on those arrays directly.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ans, ops
+from ..entropy_models import EntropyBottleneck, GaussianConditional
+from ..layers import (GELU, ConvTransBlock, Conv2d, ResidualBlockUpsample, ResidualBlockWithStride, SWAtten, conv1x1,
+                      conv3x3, subpel_conv3x3)
+from ..ops import ACT_GELU, ACT_HALFTANH, ACT_NONE, CL
+
+SCALES_MIN, SCALES_MAX, SCALES_LEVELS = 0.11, 256, 64
+
+
+def get_scale_table(min=SCALES_MIN, max=SCALES_MAX, levels=SCALES_LEVELS):
+    return torch.exp(torch.linspace(math.log(min), math.log(max), levels))
+
+
+class SliceTransform(nn.Sequential):
+    """conv3x3 -> GELU -> conv3x3 -> GELU -> conv3x3 (``cc_*`` / ``lrp_*`` nets, CLC_run.py:412-474); names 0, 2, 4."""
+
+    def __init__(self, cin, cout):
+        super().__init__(Conv2d(cin, 224, 3), GELU(), Conv2d(224, 128, 3), GELU(), Conv2d(128, cout, 3))
+
+    def forward(self, x, final_act=ACT_NONE, res=None):
+        t = self[0](x, act=ACT_GELU)
+        t = self[2](t, act=ACT_GELU)
+        return self[4](t, act=final_act, res=res)
+
+
+class PointwiseMLP(nn.Sequential):
+    """conv1x1 -> GELU -> conv1x1 (``ref_feature_adapter``, ``multi_ref_fusion``, CLM.fusion); names 0, 2."""
+
+    def __init__(self, cin, mid, cout):
+        super().__init__(conv1x1(cin, mid), GELU(), conv1x1(mid, cout))
+
+    def forward(self, x):
+        return self[2](self[0](x, act=ACT_GELU))
+
+
+class ReferenceEncoder(nn.Module):
+    def __init__(self, N=128, M=320):
+        super().__init__()
+        self.encoder = nn.Sequential(ResidualBlockWithStride(3, N, stride=2), ResidualBlockWithStride(N, N, stride=2),
+                                     ResidualBlockWithStride(N, M, stride=2), conv3x3(M, M, stride=2))
+
+    def forward(self, x):
+        return self.encoder(x)
+
+
+class CLM(nn.Module):
+    """In-file CLM of the reference (CLC_run.py:284-313): constructed for state_dict parity, never called there."""
+
+    def __init__(self, channels, head_dim=8, window_size=8):
+        super().__init__()
+        self.channels = channels
+        self.alignment = SWAtten(channels * 2, channels, head_dim, window_size, 0, inter_dim=channels)
+        self.fusion = PointwiseMLP(channels * 2, channels, channels)
+
+    def forward(self, x, ref_feat):
+        aligned = self.alignment(torch.cat([x, ref_feat], dim=1))
+        return self.fusion(torch.cat([x, aligned], dim=1))
+
+
+def _stage(N, head_dim, ws, tail):
+    return [ConvTransBlock(N, N, head_dim, ws, 0.0, "W" if i % 2 == 0 else "SW") for i in range(2)] + [tail]
+
+
+def _resize_registered_buffers(module, module_name, names, state_dict):
+    for n in names:
+        key = f"{module_name}.{n}"
+        if key in state_dict:
+            buf = dict(module.named_buffers()).get(n)
+            if buf is None:
+                raise ValueError(f'Invalid buffer name "{n}"')
+            if buf.numel() == 0:
+                buf.resize_(state_dict[key].size())
+
+
+class CompressionModel(nn.Module):
+    """compressai.models.CompressionModel surface (legacy kwarg as used at CLC_run.py:319)."""
+
+    def __init__(self, entropy_bottleneck_channels=None, init_weights=None):
+        super().__init__()
+        if entropy_bottleneck_channels is not None:
+            self.entropy_bottleneck = EntropyBottleneck(entropy_bottleneck_channels)
+
+    def aux_loss(self):
+        return sum(m.loss() for m in self.modules() if isinstance(m, EntropyBottleneck))
+
+    def update(self, scale_table=None, force=False):
+        if scale_table is None:
+            scale_table = get_scale_table()
+        updated = False
+        for m in self.modules():
+            if isinstance(m, GaussianConditional):
+                updated |= m.update_scale_table(scale_table, force=force)
+            if isinstance(m, EntropyBottleneck):
+                updated |= m.update(force=force)
+        return updated
+
+
+class _SliceCodec(CompressionModel):
+    """Shared backbone + channel-slice entropy model of TCM and CLC."""
+
+    def _build_backbone(self, N, M, head_dim):
+        ws = self.window_size
+        self.g_a = nn.Sequential(
+            ResidualBlockWithStride(3, 2 * N, 2),
+            *_stage(N, head_dim[0], ws, ResidualBlockWithStride(2 * N, 2 * N, stride=2)),
+            *_stage(N, head_dim[1], ws, ResidualBlockWithStride(2 * N, 2 * N, stride=2)),
+            *_stage(N, head_dim[2], ws, conv3x3(2 * N, M, stride=2)))
+        self.g_s = nn.Sequential(
+            ResidualBlockUpsample(M, 2 * N, 2),
+            *_stage(N, head_dim[3], ws, ResidualBlockUpsample(2 * N, 2 * N, 2)),
+            *_stage(N, head_dim[4], ws, ResidualBlockUpsample(2 * N, 2 * N, 2)),
+            *_stage(N, head_dim[5], ws, subpel_conv3x3(2 * N, 3, 2)))
+
+    def _build_hyper(self, N):
+        self.h_a = nn.Sequential(ResidualBlockWithStride(320, 2 * N, 2), *_stage(N, 32, 4, conv3x3(2 * N, 192, stride=2)))
+        self.h_mean_s = nn.Sequential(ResidualBlockUpsample(192, 2 * N, 2), *_stage(N, 32, 4, subpel_conv3x3(2 * N, 320, 2)))
+        self.h_scale_s = nn.Sequential(ResidualBlockUpsample(192, 2 * N, 2), *_stage(N, 32, 4, subpel_conv3x3(2 * N, 320, 2)))
+
+    def _w(self, i, extra=0):
+        return 320 + (320 // self.num_slices) * min(i + extra, 5 + extra)
+
+    def _swatten(self, i):
+        return nn.Sequential(SWAtten(self._w(i), self._w(i), 16, self.window_size, 0, inter_dim=128))
+
+    # ------------------------------------------------------------------ shared slice machinery
+    def _ref(self, ref_frames):
+        return None
+
+    def _slice_params(self, i, latent_means, latent_scales, y_hat_slices, ref_features, y_shape):
+        support = y_hat_slices if self.max_support_slices < 0 else y_hat_slices[: self.max_support_slices]
+        mean_support = self.atten_mean[i](torch.cat([latent_means] + support, dim=1))
+        scale_support = self.atten_scale[i](torch.cat([latent_scales] + support, dim=1))
+        if ref_features is not None:
+            mu = self.ref_cc_mean_transforms[i](torch.cat([mean_support, ref_features], dim=1))
+            scale = self.ref_cc_scale_transforms[i](torch.cat([scale_support, ref_features], dim=1))
+        else:
+            mu = self.cc_mean_transforms[i](mean_support)
+            scale = self.cc_scale_transforms[i](scale_support)
+        if mu.shape[2] != y_shape[0] or mu.shape[3] != y_shape[1]:
+            mu, scale = mu[:, :, : y_shape[0], : y_shape[1]], scale[:, :, : y_shape[0], : y_shape[1]]
+        return mean_support, mu, scale
+
+    def _refine(self, i, mean_support, y_hat_slice, ref_features):
+        """y_hat_slice + 0.5*tanh(lrp(...)) with the tanh and the add fused in the last conv's epilogue."""
+        if ref_features is not None:
+            return self.ref_lrp_transforms[i](torch.cat([mean_support, y_hat_slice, ref_features], dim=1), final_act=ACT_HALFTANH, res=y_hat_slice)
+        return self.lrp_transforms[i](torch.cat([mean_support, y_hat_slice], dim=1), final_act=ACT_HALFTANH, res=y_hat_slice)
+
+    @staticmethod
+    def _prep(x):
+        if not x.is_cuda:
+            raise ops._lib.ClcError("clc_amd models run on the GPU only (no CPU fallback by design); move the model and inputs to 'cuda'")
+        return x.float().contiguous(memory_format=CL)
+
+    def forward(self, x, ref_frames=None):
+        x = self._prep(x)
+        ref_features = self._ref(ref_frames)
+        y = self.g_a(x)
+        y_shape = y.shape[2:]
+        z = self.h_a(y)
+        z_likelihoods, z_hat = self.entropy_bottleneck.likelihood_and_ste(z)
+        latent_scales = self.h_scale_s(z_hat)
+        latent_means = self.h_mean_s(z_hat)
+        y_hat_slices, y_lik, mus, scales = [], [], [], []
+        for i, y_slice in enumerate(y.chunk(self.num_slices, 1)):
+            mean_support, mu, scale = self._slice_params(i, latent_means, latent_scales, y_hat_slices, ref_features, y_shape)
+            mus.append(mu)
+            scales.append(scale)
+            lik, y_hat_slice = self.gaussian_conditional.likelihood_and_ste(y_slice, scale, mu)
+            y_lik.append(lik)
+            y_hat_slices.append(self._refine(i, mean_support, y_hat_slice, ref_features))
+        x_hat = self.g_s(torch.cat(y_hat_slices, dim=1))
+        return {"x_hat": x_hat,
+                "likelihoods": {"y": torch.cat(y_lik, dim=1), "z": z_likelihoods},
+                "para": {"means": torch.cat(mus, dim=1), "scales": torch.cat(scales, dim=1), "y": y}}
+
+    @torch.no_grad()
+    def compress(self, x, ref_frames=None):
+        x = self._prep(x)
+        ref_features = self._ref(ref_frames)
+        y = self.g_a(x)
+        y_shape = y.shape[2:]
+        z = self.h_a(y)
+        z_strings = self.entropy_bottleneck.compress(z)
+        z_hat = self.entropy_bottleneck.decompress(z_strings, z.size()[-2:])
+        latent_scales = self.h_scale_s(z_hat)
+        latent_means = self.h_mean_s(z_hat)
+        gc = self.gaussian_conditional
+        cdf, cdf_len, off = gc.host_tables()
+        sym_parts, idx_parts, y_hat_slices = [], [], []
+        for i, y_slice in enumerate(y.chunk(self.num_slices, 1)):
+            mean_support, mu, scale = self._slice_params(i, latent_means, latent_scales, y_hat_slices, ref_features, y_shape)
+            sym, idx, y_hat_slice = gc.quantize_and_index(y_slice, mu, scale)
+            sym_parts.append(sym)
+            idx_parts.append(idx)
+            y_hat_slices.append(self._refine(i, mean_support, y_hat_slice, ref_features))
+        # ONE D2H copy for all slices; element order inside a slice is the reference's NCHW reshape(-1)
+        sym_all = torch.stack([s.contiguous() for s in sym_parts]).cpu().numpy().reshape(-1)
+        idx_all = torch.stack([s.contiguous() for s in idx_parts]).cpu().numpy().reshape(-1)
+        y_string = ans.encode(sym_all, idx_all, cdf, cdf_len, off)
+        return {"strings": [[y_string], z_strings], "shape": z.size()[-2:]}
+
+    @torch.no_grad()
+    def decompress(self, strings, shape, ref_frames=None):
+        ref_features = self._ref(ref_frames)
+        z_hat = self.entropy_bottleneck.decompress(strings[1], shape)
+        latent_scales = self.h_scale_s(z_hat)
+        latent_means = self.h_mean_s(z_hat)
+        y_shape = [z_hat.shape[2] * 4, z_hat.shape[3] * 4]
+        gc = self.gaussian_conditional
+        cdf, cdf_len, off = gc.host_tables()
+        dec = ans.RansDecoder()
+        dec.set_stream(strings[0][0])
+        y_hat_slices = []
+        for i in range(self.num_slices):
+            mean_support, mu, scale = self._slice_params(i, latent_means, latent_scales, y_hat_slices, ref_features, y_shape)
+            index = gc.build_indexes(scale)
+            rv = dec.decode_stream(index.contiguous().cpu().numpy().reshape(-1), cdf, cdf_len, off)
+            rv = torch.from_numpy(rv.astype(np.float32)).reshape(1, -1, y_shape[0], y_shape[1]).to(mu.device).contiguous(memory_format=CL)
+            y_hat_slice = rv + mu
+            y_hat_slices.append(self._refine(i, mean_support, y_hat_slice, ref_features))
+        x_hat = self.g_s(torch.cat(y_hat_slices, dim=1)).clamp_(0, 1)
+        return {"x_hat": x_hat}
+
+
+class CLC(_SliceCodec):
+    def __init__(self, config=[2, 2, 2, 2, 2, 2], head_dim=[8, 16, 32, 32, 16, 8], drop_path_rate=0, N=128, M=320,
+                 num_slices=5, max_support_slices=5, num_ref_frames=3, use_ref=True, **kwargs):
+        super().__init__(entropy_bottleneck_channels=N)
+        if list(config) != [2] * 6 or drop_path_rate != 0 or M != 320 or num_slices != 5:
+            raise ValueError("clc_amd.CLC supports the reference configuration: config=[2]*6, drop_path_rate=0, M=320, num_slices=5")
+        self.config, self.head_dim, self.window_size = config, head_dim, 8
+        self.num_slices, self.max_support_slices = num_slices, max_support_slices
+        self.num_ref_frames, self.use_ref, self.M = num_ref_frames, use_ref, M
+        S = 320 // num_slices
+        self._build_backbone(N, M, head_dim)
+        self.ref_encoder = ReferenceEncoder(N, M)
+        self.feature_alignment = nn.ModuleList([CLM(192, head_dim=32, window_size=4) for _ in range(num_ref_frames)])
+        self.multi_ref_fusion = PointwiseMLP(192 * (num_ref_frames + 1), 256, 192)
+        self._build_hyper(N)
+        self.atten_mean = nn.ModuleList(self._swatten(i) for i in range(num_slices))
+        self.atten_scale = nn.ModuleList(self._swatten(i) for i in range(num_slices))
+        self.ref_cc_mean_transforms = nn.ModuleList(SliceTransform(self._w(i) + 64, S) for i in range(num_slices))
+        self.ref_cc_scale_transforms = nn.ModuleList(SliceTransform(self._w(i) + 64, S) for i in range(num_slices))
+        self.cc_mean_transforms = nn.ModuleList(SliceTransform(self._w(i), S) for i in range(num_slices))
+        self.cc_scale_transforms = nn.ModuleList(SliceTransform(self._w(i), S) for i in range(num_slices))
+        self.lrp_transforms = nn.ModuleList(SliceTransform(self._w(i, 1), S) for i in range(num_slices))
+        self.ref_lrp_transforms = nn.ModuleList(SliceTransform(self._w(i, 1) + 64, S) for i in range(num_slices))
+        self.ref_feature_adapter = PointwiseMLP(M * num_ref_frames, 128, 64)
+        self.entropy_bottleneck = EntropyBottleneck(192)
+        self.gaussian_conditional = GaussianConditional(None)
+
+    def _ref(self, ref_frames):
+        if ref_frames is None or not self.use_ref:
+            return None
+        R = len(ref_frames)
+        if R != self.num_ref_frames:
+            raise ValueError(f"expected {self.num_ref_frames} reference frames, got {R}")
+        refs = self._prep(torch.cat(list(ref_frames), dim=0)) if R > 1 else self._prep(ref_frames[0])
+        feats = self.ref_encoder(refs)                      # one batched pass over all R references
+        if R > 1:
+            feats = torch.cat(feats.chunk(R, dim=0), dim=1)  # [B, R*M, h, w] in reference order
+        return self.ref_feature_adapter(feats)
+
+    extract_ref_features = _ref
+
+    def update(self, scale_table=None, force=False):
+        if scale_table is None:
+            scale_table = get_scale_table()
+        updated = self.gaussian_conditional.update_scale_table(scale_table, force=force)
+        updated |= self.entropy_bottleneck.update(force=force)
+        return updated
+
+    def load_state_dict(self, state_dict, strict=False):
+        own = self.state_dict()
+        filtered = {k: v for k, v in state_dict.items() if k in own}
+        _resize_registered_buffers(self.gaussian_conditional, "gaussian_conditional",
+                                   ["_quantized_cdf", "_offset", "_cdf_length", "scale_table"], state_dict)
+        _resize_registered_buffers(self.entropy_bottleneck, "entropy_bottleneck", ["_quantized_cdf", "_offset", "_cdf_length"], state_dict)
+        return nn.Module.load_state_dict(self, filtered, strict=False)
+
+
+class TCM(_SliceCodec):
+    def __init__(self, config=[2, 2, 2, 2, 2, 2], head_dim=[8, 16, 32, 32, 16, 8], drop_path_rate=0, N=128, M=320,
+                 num_slices=5, max_support_slices=5, **kwargs):
+        super().__init__(entropy_bottleneck_channels=N)
+        if list(config) != [2] * 6 or drop_path_rate != 0 or M != 320 or num_slices != 5:
+            raise ValueError("clc_amd.TCM supports the reference configuration: config=[2]*6, drop_path_rate=0, M=320, num_slices=5")
+        self.config, self.head_dim, self.window_size = config, head_dim, 8
+        self.num_slices, self.max_support_slices, self.M = num_slices, max_support_slices, M
+        S = 320 // num_slices
+        self._build_backbone(N, M, head_dim)
+        self._build_hyper(N)
+        self.atten_mean = nn.ModuleList(self._swatten(i) for i in range(num_slices))
+        self.atten_scale = nn.ModuleList(self._swatten(i) for i in range(num_slices))
+        self.cc_mean_transforms = nn.ModuleList(SliceTransform(self._w(i), S) for i in range(num_slices))
+        self.cc_scale_transforms = nn.ModuleList(SliceTransform(self._w(i), S) for i in range(num_slices))
+        self.lrp_transforms = nn.ModuleList(SliceTransform(self._w(i, 1), S) for i in range(num_slices))
+        self.entropy_bottleneck = EntropyBottleneck(192)
+        self.gaussian_conditional = GaussianConditional(None)
+
+    def forward(self, x, ref_frames=None):
+        return super().forward(x, None)
+
+    def compress(self, x, ref_frames=None):
+        return super().compress(x, None)
+
+    def decompress(self, strings, shape, ref_frames=None):
+        return super().decompress(strings, shape, None)
+
+    def update(self, scale_table=None, force=False):
+        if scale_table is None:
+            scale_table = get_scale_table()
+        updated = self.gaussian_conditional.update_scale_table(scale_table, force=force)
+        updated |= self.entropy_bottleneck.update(force=force)
+        return updated
+
+    def load_state_dict(self, state_dict, strict=True):
+        _resize_registered_buffers(self.gaussian_conditional, "gaussian_conditional",
+                                   ["_quantized_cdf", "_offset", "_cdf_length", "scale_table"], state_dict)
+        _resize_registered_buffers(self.entropy_bottleneck, "entropy_bottleneck", ["_quantized_cdf", "_offset", "_cdf_length"], state_dict)
+        return nn.Module.load_state_dict(self, state_dict, strict=strict)

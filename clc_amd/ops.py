@@ -18,7 +18,8 @@ import torch
 from torch.autograd import Function
 
 from . import lib as _lib
-from .lib import ACT_GELU, ACT_LRELU, ACT_NONE, ACT_RELU, IN_NONE, IN_SQUARE, NORM_GDN, NORM_IGDN, NORM_NONE
+from .lib import (ACT_GELU, ACT_HALFTANH, ACT_LRELU, ACT_NONE, ACT_RELU, IN_NONE, IN_SQUARE, NORM_GDN, NORM_IGDN,
+                  NORM_NONE)
 
 CL = torch.channels_last
 
@@ -83,7 +84,7 @@ def to_kernel_weight(w: torch.Tensor) -> torch.Tensor:
 
 
 def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_NONE, norm=NORM_NONE, mul=None,
-             res=None, res_scale=1.0, y_pre=None, shuffle=False, transposed=False, out=None, out_hw=None):
+             res=None, res_scale=1.0, res_first=False, y_pre=None, shuffle=False, transposed=False, out=None, out_hw=None):
     """One clc_conv2d launch. ``w`` must already be in kernel layout [Cout][ks][ks][Cin]."""
     _require_gpu(x, "conv2d")
     x, xp, N, H, W, Cin, ldx = nhwc(x)
@@ -111,7 +112,7 @@ def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_
         keep.append(m)
     if res is not None:
         r, rp, *_r, ldr = nhwc(res)
-        d.res, d.ldr, d.res_scale = rp, ldr, float(res_scale)
+        d.res, d.ldr, d.res_scale, d.res_first = rp, ldr, float(res_scale), int(res_first)
         keep.append(r)
     if y_pre is not None:
         q, qp, *_r, ldp = nhwc(y_pre)
@@ -165,11 +166,11 @@ class _ConvFn(Function):
     """y = act(conv(x, w) + b) + res_scale * res, optionally PixelShuffle(2)-stored."""
 
     @staticmethod
-    def forward(ctx, x, w, b, res, ks, stride, act, res_scale, shuffle):
+    def forward(ctx, x, w, b, res, ks, stride, act, res_scale, shuffle, res_first):
         wk = to_kernel_weight(w)
         need_grad = any(ctx.needs_input_grad)
         # the activation derivative needs the pre-activation whenever the output does not determine it
-        save_pre = need_grad and (act == ACT_GELU or (act in (ACT_LRELU, ACT_RELU) and res is not None))
+        save_pre = need_grad and (act == ACT_GELU or (act in (ACT_LRELU, ACT_RELU, ACT_HALFTANH) and res is not None and not res_first))
         N, _, H, W = x.shape
         Cout = w.shape[0]
         pad = ks // 2
@@ -177,23 +178,24 @@ class _ConvFn(Function):
         y_pre = None
         if save_pre:
             y_pre = new_act(N, Cout // 4, 2 * OH, 2 * OW, x) if shuffle else new_act(N, Cout, OH, OW, x)
-        y = conv_raw(x, wk, b, ks=ks, stride=stride, act=act, res=res, res_scale=res_scale, y_pre=y_pre, shuffle=shuffle)
-        ctx.cfg = (ks, stride, act, res_scale, shuffle, b is not None, res is not None)
-        saved_act = y_pre if save_pre else (y if act in (ACT_LRELU, ACT_RELU) else None)
+        y = conv_raw(x, wk, b, ks=ks, stride=stride, act=act, res=res, res_scale=res_scale, res_first=res_first, y_pre=y_pre, shuffle=shuffle)
+        ctx.cfg = (ks, stride, act, res_scale, shuffle, b is not None, res is not None, res_first)
+        saved_act = y_pre if save_pre else (y if act in (ACT_LRELU, ACT_RELU, ACT_HALFTANH) else None)
         ctx.use_pre = save_pre
         ctx.save_for_backward(x, w, saved_act)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        ks, stride, act, res_scale, shuffle, has_b, has_res = ctx.cfg
+        ks, stride, act, res_scale, shuffle, has_b, has_res, res_first = ctx.cfg
         x, w, saved_act = ctx.saved_tensors
         Cout, Cin = w.shape[0], w.shape[1]
         need_x, need_w, need_b, need_res = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_b and ctx.needs_input_grad[2], has_res and ctx.needs_input_grad[3]
+        dz = act_bwd(dy, saved_act, ctx.use_pre, act) if act != ACT_NONE else dy
         dres = None
         if need_res:
-            dres = dy if res_scale == 1.0 else dy * res_scale
-        dz = act_bwd(dy, saved_act, ctx.use_pre, act) if act != ACT_NONE else dy
+            dsrc = dz if res_first else dy  # residual added before / after the activation
+            dres = dsrc if res_scale == 1.0 else dsrc * res_scale
         if shuffle:  # undo PixelShuffle(2): [N, C/4, 2H, 2W] -> [N, C, H, W] (strided copy; TODO fuse into the gathers)
             dz = torch.nn.functional.pixel_unshuffle(dz, 2).contiguous(memory_format=CL)
         dx = dw = db = None
@@ -204,17 +206,17 @@ class _ConvFn(Function):
         if need_x:
             wt = filter_transpose(to_kernel_weight(w), Cout, ks * ks, Cin)
             dx = conv_raw(dz, wt.view(Cin, -1), None, ks=ks, stride=stride, pad=pad, transposed=True, out_hw=(x.shape[2], x.shape[3]))
-        return dx, dw, db, dres, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None
 
 
-def conv2d(x, w, b=None, *, stride=1, act=ACT_NONE, res=None, res_scale=1.0, shuffle=False):
+def conv2d(x, w, b=None, *, stride=1, act=ACT_NONE, res=None, res_scale=1.0, shuffle=False, res_first=False):
     ks = w.shape[2] if w.dim() == 4 else 1
-    return _ConvFn.apply(x, w, b, res, ks, stride, act, float(res_scale), bool(shuffle))
+    return _ConvFn.apply(x, w, b, res, ks, stride, act, float(res_scale), bool(shuffle), bool(res_first))
 
 
 def linear(x, w, b=None, *, act=ACT_NONE, res=None):
     """nn.Linear on channels (tokens are pixels): x [N,Cin,H,W] pixel-major, w [Cout,Cin]."""
-    return _ConvFn.apply(x, w, b, res, 1, 1, act, 1.0, False)
+    return _ConvFn.apply(x, w, b, res, 1, 1, act, 1.0, False, False)
 
 
 # ------------------------------------------------------------------------------------------- GDN
@@ -376,17 +378,18 @@ class _GaussLikFn(Function):
         mu, mp, *_b, ldmu = nhwc(mu)
         rows = N * H * W
         lik = new_act(N, Cc, H, W, y)
+        y_hat = new_act(N, Cc, H, W, y)
         npn, ldn = (None, 0)
         if training:
             noise, npn, *_c, ldn = nhwc(noise)
-        _lib.check(_L().clc_gauss_lik_fwd(yp, ldy, mp, ldmu, sp, ldsc, npn, ldn, lik.data_ptr(), Cc, None, 0, rows, Cc,
+        _lib.check(_L().clc_gauss_lik_fwd(yp, ldy, mp, ldmu, sp, ldsc, npn, ldn, lik.data_ptr(), Cc, y_hat.data_ptr(), Cc, rows, Cc,
                                           0 if training else 1, None, 0, _stream()), "clc_gauss_lik_fwd")
         ctx.training = training
         ctx.save_for_backward(y, scale, mu, noise if training else None)
-        return lik
+        return lik, y_hat
 
     @staticmethod
-    def backward(ctx, dlik):
+    def backward(ctx, dlik, dyhat):
         y, scale, mu, noise = ctx.saved_tensors
         y, yp, N, H, W, Cc, ldy = nhwc(y)
         scale, sp, *_a, ldsc = nhwc(scale)
@@ -402,10 +405,14 @@ class _GaussLikFn(Function):
         _lib.check(_L().clc_gauss_lik_bwd(dlp, lddl, yp, ldy, mp, ldmu, sp, ldsc, npn, ldn,
                                           dy.data_ptr() if dy is not None else None, Cc, dmu.data_ptr() if dmu is not None else None, Cc,
                                           dsc.data_ptr(), Cc, rows, Cc, 0 if ctx.training else 1, _stream()), "clc_gauss_lik_bwd")
+        # y_hat = round(y - mu) + mu with the straight-through estimator: d y_hat/dy = 1, d y_hat/dmu = 0
+        if dyhat is not None:
+            dy = dyhat if dy is None else dy + dyhat
         return dy, dsc, dmu, None, None
 
 
 def gaussian_likelihood(y, scale, mu, noise, training):
+    """-> (likelihood, y_hat) with y_hat = ste_round(y - mu) + mu  (CLC_run.py:569-571)."""
     return _GaussLikFn.apply(y, scale, mu, noise, bool(training))
 
 
@@ -423,18 +430,19 @@ class _EBLikFn(Function):
         z, zp, N, H, W, Cc, ldz = nhwc(z)
         rows = N * H * W
         lik = new_act(N, Cc, H, W, z)
+        z_hat = new_act(N, Cc, H, W, z)
         npn, ldn = (None, 0)
         if training:
             noise, npn, *_c, ldn = nhwc(noise)
         pm, pb, pf = _eb_ptrs(mats, biases, factors)
-        _lib.check(_L().clc_eb_lik_fwd(zp, ldz, npn, ldn, quantiles.data_ptr(), pm, pb, pf, lik.data_ptr(), Cc, None, 0, rows, Cc,
+        _lib.check(_L().clc_eb_lik_fwd(zp, ldz, npn, ldn, quantiles.data_ptr(), pm, pb, pf, lik.data_ptr(), Cc, z_hat.data_ptr(), Cc, rows, Cc,
                                        0 if training else 1, _stream()), "clc_eb_lik_fwd")
         ctx.training = training
         ctx.save_for_backward(z, noise if training else None, quantiles, *params)
-        return lik
+        return lik, z_hat
 
     @staticmethod
-    def backward(ctx, dlik):
+    def backward(ctx, dlik, dzhat):
         z, noise, quantiles, *params = ctx.saved_tensors
         mats, biases, factors = params[0:5], params[5:10], params[10:14]
         z, zp, N, H, W, Cc, ldz = nhwc(z)
@@ -449,10 +457,13 @@ class _EBLikFn(Function):
         dz = new_act(N, Cc, H, W, z) if ctx.training else None
         _lib.check(_L().clc_eb_lik_bwd(dlp, lddl, zp, ldz, npn, ldn, quantiles.data_ptr(), pm, pb, pf, gm, gb, gf,
                                        dz.data_ptr() if dz is not None else None, Cc, rows, Cc, 0 if ctx.training else 1, _stream()), "clc_eb_lik_bwd")
+        if dzhat is not None:  # z_hat = ste_round(z - med) + med
+            dz = dzhat if dz is None else dz + dzhat
         return (dz, None, None, None, *grads)
 
 
 def eb_likelihood(z, noise, quantiles, training, mats, biases, factors):
+    """-> (likelihood, z_hat) with z_hat = ste_round(z - median) + median  (CLC_run.py:526-530)."""
     return _EBLikFn.apply(z, noise, quantiles, bool(training), *mats, *biases, *factors)
 
 
@@ -493,3 +504,63 @@ def quantize_build_indexes(y, mu, scale, scale_table):
                                                idx.data_ptr(), y_hat.data_ptr(), Cc, rows, Cc, _stream()), "clc_quantize_build_indexes")
     # logical NCHW views over the NHWC int buffers
     return sym.permute(0, 3, 1, 2), idx.permute(0, 3, 1, 2), y_hat
+
+
+# --------------------------------------------------------------------------------- RD loss pieces
+
+
+class _SumLog2Fn(Function):
+    """sum(log2(lik)) over a likelihood tensor, two-stage fixed-order reduction."""
+
+    @staticmethod
+    def forward(ctx, lik):
+        lik, lp, N, H, W, Cc, ld = nhwc(lik)
+        rows = N * H * W
+        nb = max(1, min(1024, (rows * Cc + 1023) // 1024))
+        part = torch.empty(nb, device=lik.device, dtype=torch.float32)
+        out = torch.empty(1, device=lik.device, dtype=torch.float32)
+        _lib.check(_L().clc_log2_sum_partials(lp, ld, rows, Cc, part.data_ptr(), nb, _stream()), "clc_log2_sum_partials")
+        _lib.check(_L().clc_sum_partials(part.data_ptr(), nb, 1.0, out.data_ptr(), 0, _stream()), "clc_sum_partials")
+        ctx.save_for_backward(lik)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (lik,) = ctx.saved_tensors
+        lik, lp, N, H, W, Cc, ld = nhwc(lik)
+        g = g.contiguous()
+        d = new_act(N, Cc, H, W, lik)
+        _lib.check(_L().clc_scaled_recip(lp, ld, N * H * W, Cc, g.data_ptr(), 1.0 / math.log(2.0), d.data_ptr(), Cc, _stream()), "clc_scaled_recip")
+        return d
+
+
+def sum_log2(lik):
+    return _SumLog2Fn.apply(lik)
+
+
+class _SqDiffSumFn(Function):
+    """sum((a - b)^2); gradient flows to ``a`` only (b is the target image)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = dense(a), dense(b)
+        n = a.numel()
+        nb = max(1, min(1024, (n + 4095) // 4096))
+        part = torch.empty(nb, device=a.device, dtype=torch.float32)
+        out = torch.empty(1, device=a.device, dtype=torch.float32)
+        _lib.check(_L().clc_sqdiff_partials(a.data_ptr(), b.data_ptr(), n, part.data_ptr(), nb, _stream()), "clc_sqdiff_partials")
+        _lib.check(_L().clc_sum_partials(part.data_ptr(), nb, 1.0, out.data_ptr(), 0, _stream()), "clc_sum_partials")
+        ctx.save_for_backward(a, b)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        d = new_act(*a.shape, a)
+        _lib.check(_L().clc_scaled_diff(a.data_ptr(), b.data_ptr(), a.numel(), g.data_ptr(), 2.0, d.data_ptr(), _stream()), "clc_scaled_diff")
+        return d, None
+
+
+def sqdiff_sum(a, b):
+    return _SqDiffSumFn.apply(a, b)

@@ -1,0 +1,331 @@
+"""Training-step engine for the CLC hot path on MI355X.
+
+Reference semantics reproduced (file:line into /root/reference):
+  RateDistortionLoss          train_CLC.py:36-59    bpp = sum log(lik) / (-ln2 * N*H*W); loss = lmbda*255^2*mse + bpp
+  configure_optimizers        train_CLC.py:81-117   AdamW(all but *.quantiles, lr) + AdamW(*.quantiles, aux lr)
+  train_one_epoch inner loop  train_CLC.py:137-183  zero_grad, forward, loss.backward, clip_grad_norm_(1.0), nan_to_num_,
+                                                    optimizer.step, aux_loss.backward, aux_optimizer.step
+  data parallelism            run_ddp.sh:1-7 / train_CLC.py:472-473   one process per GPU, gradient mean over ranks
+
+MI355X-first design of the step (not nn.DataParallel, not stock DDP):
+  * the parameters that actually receive gradients ("live": 49.4 M of 70.6 M at N=64, R=1 — the cc_*/lrp_* twins and
+    the dormant CLM modules never do) are re-homed into ONE flat fp32 arena, their .grad into a second
+    one, Adam moments into two more.  Views keep every tensor's shape and channels_last strides.
+  * clip_grad_norm_ + nan_to_num_ + AdamW for all live parameters = 3 launches over the arenas (clc_adamw_step).
+  * gradient exchange = a few large all-reduces over the flat gradient arena (RCCL over xGMI; ring all-reduce is
+    per-link bound, so buckets are big: 64 MiB), issued on a side stream and overlapped with the aux step.
+  * the whole step (fwd + bwd + exchange-free part + optimizer) is captured once into a hipGraph and replayed.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import lib as _lib
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------ loss
+
+
+def ms_ssim(X, Y, data_range=1.0, weights=(0.0448, 0.2856, 0.3001, 0.2363, 0.1333), K=(0.01, 0.03)):
+    """pytorch_msssim.ms_ssim semantics (train_CLC.py:33-34). Plain torch ops for now (depthwise 11-tap Gaussians);
+    only the MS-SSIM configs use it."""
+    import torch.nn.functional as F
+
+    size, sigma = 11, 1.5
+    coords = torch.arange(size, dtype=torch.float32, device=X.device) - size // 2
+    g = torch.exp(-(coords ** 2) / (2 * sigma ** 2))
+    g = g / g.sum()
+    C = X.shape[1]
+
+    def filt(t):
+        t = F.conv2d(t, g.view(1, 1, -1, 1).repeat(C, 1, 1, 1), groups=C)
+        return F.conv2d(t, g.view(1, 1, 1, -1).repeat(C, 1, 1, 1), groups=C)
+
+    C1, C2 = (K[0] * data_range) ** 2, (K[1] * data_range) ** 2
+    mcs = []
+    for i in range(len(weights)):
+        mu1, mu2 = filt(X), filt(Y)
+        s11, s22, s12 = filt(X * X) - mu1 * mu1, filt(Y * Y) - mu2 * mu2, filt(X * Y) - mu1 * mu2
+        cs_map = (2 * s12 + C2) / (s11 + s22 + C2)
+        ssim_map = ((2 * mu1 * mu2 + C1) / (mu1 ** 2 + mu2 ** 2 + C1)) * cs_map
+        if i < len(weights) - 1:
+            mcs.append(torch.relu(cs_map.flatten(2).mean(-1)))
+            pad = [s % 2 for s in X.shape[2:]]
+            X, Y = F.avg_pool2d(X, 2, padding=pad), F.avg_pool2d(Y, 2, padding=pad)
+        else:
+            last = torch.relu(ssim_map.flatten(2).mean(-1))
+    vals = torch.stack(mcs + [last], dim=0)
+    w = torch.tensor(weights, device=X.device, dtype=X.dtype).view(-1, 1, 1)
+    return torch.prod(vals ** w, dim=0).mean()
+
+
+class RateDistortionLoss(nn.Module):
+    """Same constructor / output dict as the reference's criterion (train_CLC.py:36-59)."""
+
+    def __init__(self, lmbda=1e-2, type="mse"):
+        super().__init__()
+        self.lmbda, self.type = lmbda, type
+
+    def forward(self, output, target):
+        N, _, H, W = target.size()
+        num_pixels = N * H * W
+        out = {}
+        # sum(log(l)) / (-ln2 * n) == sum(log2(l)) / (-n); the sums are fixed-order two-stage reductions
+        out["bpp_loss"] = sum(ops.sum_log2(l) for l in output["likelihoods"].values()) / (-num_pixels)
+        if self.type == "mse":
+            tgt = target.float().contiguous(memory_format=ops.CL)
+            out["mse_loss"] = ops.sqdiff_sum(output["x_hat"], tgt) / tgt.numel()
+            out["loss"] = self.lmbda * 255 ** 2 * out["mse_loss"] + out["bpp_loss"]
+        else:
+            out["ms_ssim_loss"] = ms_ssim(output["x_hat"], target, data_range=1.0)
+            out["loss"] = self.lmbda * (1 - out["ms_ssim_loss"]) + out["bpp_loss"]
+        return out
+
+
+def configure_optimizers(net, args):
+    """Reference-compatible (torch.optim.AdamW pair) — used when the reference trainer drives the model unchanged."""
+    params = {n for n, p in net.named_parameters() if not n.endswith(".quantiles") and p.requires_grad}
+    aux = {n for n, p in net.named_parameters() if n.endswith(".quantiles") and p.requires_grad}
+    d = dict(net.named_parameters())
+    assert not (params & aux) and len(params | aux) == len(d)
+    opt = torch.optim.AdamW((d[n] for n in sorted(params)), lr=args.learning_rate)
+    aux_opt = torch.optim.AdamW((d[n] for n in sorted(aux)), lr=args.aux_learning_rate)
+    return opt, aux_opt
+
+
+# ------------------------------------------------------------------------------- flat arenas
+
+
+class FlatArena:
+    """Re-homes a list of tensors into one flat buffer, keeping each tensor's shape and strides (device-agnostic)."""
+
+    def __init__(self, tensors: List[torch.Tensor], align: int = 64):
+        self.offsets, total = [], 0
+        for t in tensors:
+            self.offsets.append(total)
+            total += (t.numel() + align - 1) // align * align
+        self.numel = total
+        dev = tensors[0].device if tensors else "cpu"
+        self.flat = torch.zeros(max(total, 1), dtype=torch.float32, device=dev)
+        self.views = [self.view_like(i, t) for i, t in enumerate(tensors)]
+
+    def view_like(self, i, t):
+        seg = self.flat[self.offsets[i]: self.offsets[i] + t.numel()]
+        return seg.as_strided(t.shape, t.stride()) if t.numel() else seg.view(t.shape)
+
+
+def _dense_strides_ok(t: torch.Tensor) -> bool:
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
+class GradSync:
+    """Gradient mean over ranks as a few large all-reduces over a flat fp32 buffer (RCCL on GPU, gloo in CPU tests).
+
+    xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is bound by one link, so small buckets
+    only add latency — default bucket = 64 MiB.  ``start()`` launches asynchronously, ``finish()`` waits and scales.
+    """
+
+    def __init__(self, flat: torch.Tensor, bucket_bytes: int = 64 << 20, group=None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        n = max(1, bucket_bytes // 4)
+        self.buckets = [flat[i: i + n] for i in range(0, flat.numel(), n)]
+        self.pending = []
+
+    def start(self):
+        if self.world == 1:
+            return
+        self.pending = [self.dist.all_reduce(b, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets]
+
+    def finish(self):
+        if self.world == 1:
+            return
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        self.flat.mul_(1.0 / self.world)
+
+
+def broadcast_parameters(module: nn.Module, src: int = 0, group=None):
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        if t.numel():
+            dist.broadcast(t.data, src=src, group=group)
+
+
+# ------------------------------------------------------------------------------ fused optimizer
+
+
+class FusedAdamW:
+    """clip_grad_norm_ + nan_to_num_ + AdamW (PyTorch defaults) over flat arenas: 3 kernel launches for all parameters."""
+
+    def __init__(self, params: List[nn.Parameter], lr: float, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm: float = 0.0):
+        import ctypes as C
+        import numpy as np
+
+        for p in params:
+            if not _dense_strides_ok(p.data):
+                raise ValueError("FusedAdamW needs dense (contiguous or channels_last) parameters")
+        self.params = params
+        self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_norm
+        self.p_arena = FlatArena([p.data for p in params])
+        self.g_arena = FlatArena([p.data for p in params])
+        with torch.no_grad():
+            for p, pv, gv in zip(params, self.p_arena.views, self.g_arena.views):
+                pv.copy_(p.data)
+                p.data = pv           # parameter now lives in the arena (same shape / strides)
+                p.grad = gv           # persistent gradient view: autograd accumulates in place
+        n = self.p_arena.numel
+        dev = self.p_arena.flat.device
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.step_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.sqnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        L = _lib.load()
+        chunk = L.clc_optim_chunk_elems()
+        entry = _lib.ParamEntry(self.p_arena.flat.data_ptr(), self.g_arena.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), n)
+        self.table = torch.frombuffer(bytearray(bytes(entry)), dtype=torch.uint8).to(dev)
+        self.n_chunks = (n + chunk - 1) // chunk
+        chunks = np.zeros((self.n_chunks, 2), dtype=np.int32)
+        chunks[:, 1] = np.arange(self.n_chunks, dtype=np.int64) * chunk
+        if n >= 2 ** 31:
+            raise ValueError("arena too large for int32 chunk offsets")
+        self.chunks = torch.from_numpy(chunks).to(dev)
+        self.partials = torch.empty(self.n_chunks, dtype=torch.float32, device=dev)
+
+    @property
+    def grad_flat(self):
+        return self.g_arena.flat
+
+    def zero_grad(self):
+        self.g_arena.flat.zero_()
+
+    def step(self):
+        L, st = _lib.load(), ops._stream()
+        _lib.check(L.clc_scalar_add(self.step_dev.data_ptr(), 1.0, st), "clc_scalar_add")
+        sq = None
+        if self.max_norm > 0:
+            _lib.check(L.clc_grad_sqnorm_partials(self.table.data_ptr(), self.chunks.data_ptr(), self.n_chunks, self.partials.data_ptr(), st), "clc_grad_sqnorm_partials")
+            _lib.check(L.clc_sum_partials(self.partials.data_ptr(), self.n_chunks, 1.0, self.sqnorm.data_ptr(), 0, st), "clc_sum_partials")
+            sq = self.sqnorm.data_ptr()
+        _lib.check(L.clc_adamw_step(self.table.data_ptr(), self.chunks.data_ptr(), self.n_chunks, sq, float(self.max_norm), float(self.lr),
+                                    float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), self.step_dev.data_ptr(), st), "clc_adamw_step")
+
+
+# ------------------------------------------------------------------------------------ the engine
+
+
+class TrainEngine:
+    """One data-parallel training step of the reference loop (train_CLC.py:137-183), hipGraph-captured.
+
+    engine = TrainEngine(model, lmbda=0.0067, lr=1e-4, aux_lr=1e-3, clip_max_norm=1.0)
+    out = engine.step(x, refs)      # dict of device scalars: loss, bpp_loss, mse_loss, aux_loss
+    """
+
+    def __init__(self, model: nn.Module, lmbda: float, loss_type: str = "mse", lr: float = 1e-4, aux_lr: float = 1e-3,
+                 clip_max_norm: float = 1.0, use_graph: bool = True, with_optimizer: bool = True):
+        self.model, self.criterion = model, RateDistortionLoss(lmbda, loss_type)
+        self.lr, self.aux_lr, self.clip = lr, aux_lr, clip_max_norm
+        self.use_graph, self.with_optimizer = use_graph, with_optimizer
+        self.opt: Optional[FusedAdamW] = None
+        self.aux_opt: Optional[FusedAdamW] = None
+        self.sync: Optional[GradSync] = None
+        self.graph = None
+        self._static = None
+        self._out = None
+
+    # -- discovery: which parameters does this (model, inputs) combination actually train?
+    def _discover(self, x, refs):
+        self.model.train()
+        for p in self.model.parameters():
+            p.grad = None
+        out = self.criterion(self.model(x, refs), x)
+        out["loss"].backward()
+        live = [p for n, p in self.model.named_parameters() if p.grad is not None and not n.endswith(".quantiles")]
+        aux = [p for n, p in self.model.named_parameters() if n.endswith(".quantiles")]
+        self.opt = FusedAdamW(live, lr=self.lr, max_norm=self.clip)
+        self.aux_opt = FusedAdamW(aux, lr=self.aux_lr, max_norm=0.0)
+        self.sync = GradSync(self.opt.grad_flat)
+        self.aux_sync = GradSync(self.aux_opt.grad_flat)
+
+    def _fwd_bwd(self, x, refs):
+        self.opt.zero_grad()
+        self.aux_opt.zero_grad()
+        out = self.criterion(self.model(x, refs), x)
+        out["loss"].backward()
+        return out
+
+    def _opt_steps(self, out):
+        if self.with_optimizer:
+            self.opt.step()
+        aux_loss = self.model.aux_loss()
+        aux_loss.backward()
+        out["aux_loss"] = aux_loss.detach()
+        return out
+
+    def _finish(self, out):
+        if self.with_optimizer:
+            self.aux_sync.start()
+            self.aux_sync.finish()
+            self.aux_opt.step()
+        return {k: v.detach() for k, v in out.items()}
+
+    def _eager_step(self, x, refs):
+        out = self._fwd_bwd(x, refs)
+        self.sync.start()
+        self.sync.finish()
+        out = self._opt_steps(out)
+        return self._finish(out)
+
+    def step(self, x, refs=None):
+        refs = list(refs) if refs is not None else None
+        if self.opt is None:
+            self._discover(x, refs)
+        single = self.sync.world == 1
+        if not self.use_graph:
+            return self._eager_step(x, refs)
+        if self.graph is None:
+            # warm up on a side stream (allocator + lazy kernel attributes), then capture
+            self._static = (x.clone(), [r.clone() for r in refs] if refs is not None else None)
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    self._eager_step(*self._static)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            if single:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self._out = self._eager_step(*self._static)
+            else:
+                # collectives stay outside the graphs: graph A = fwd+bwd, exchange, graph B = optimizer + aux
+                self.graph = (torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph())
+                with torch.cuda.graph(self.graph[0]):
+                    self._mid = self._fwd_bwd(*self._static)
+                with torch.cuda.graph(self.graph[1], pool=self.graph[0].pool()):
+                    self._out2 = self._opt_steps(dict(self._mid))
+        sx, srefs = self._static
+        sx.copy_(x, non_blocking=True)
+        if refs is not None:
+            for d, r in zip(srefs, refs):
+                d.copy_(r, non_blocking=True)
+        if single:
+            self.graph.replay()
+            return self._out
+        self.graph[0].replay()
+        self.sync.start()
+        self.sync.finish()
+        self.graph[1].replay()
+        return self._finish(dict(self._out2))

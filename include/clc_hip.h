@@ -37,7 +37,7 @@ const char* clc_last_error(void);
 int clc_version(void);
 
 /* ---- activation / epilogue codes ---------------------------------------------------- */
-enum { CLC_ACT_NONE = 0, CLC_ACT_LRELU = 1, CLC_ACT_RELU = 2, CLC_ACT_GELU = 3 };
+enum { CLC_ACT_NONE = 0, CLC_ACT_LRELU = 1, CLC_ACT_RELU = 2, CLC_ACT_GELU = 3, CLC_ACT_HALFTANH = 4 /* 0.5*tanh(v), LRP head */ };
 /* input prologue applied to the gathered activations */
 enum { CLC_IN_NONE = 0, CLC_IN_SQUARE = 1 };
 /* norm modes of the epilogue: out = mul * rsqrt(v) (GDN) or mul * sqrt(v) (inverse GDN) */
@@ -50,6 +50,7 @@ enum { CLC_NORM_NONE = 0, CLC_NORM_GDN = 1, CLC_NORM_IGDN = 2 };
  *
  * y[n,oh,ow,co] = epi( sum_{kh,kw,ci} in_op(x[n, oh*s-pad+kh, ow*s-pad+kw, ci]) * w[co,kh,kw,ci] )
  * epi(v): v += bias[co]; (y_pre <- v); v = norm(v, mul); v = act(v); v += res_scale*res
+ *         (res_first = 1: the residual is added BEFORE the activation: v = act(v + res_scale*res), y_pre includes it)
  * transposed = 1 computes the data gradient of that conv instead: "x" is dY
  * [N,H,W,Cin=Cout_fwd], "y" is dX [N,OH,OW,Cout=Cin_fwd] and w must be the transposed
  * filter [Cin_fwd][KH][KW][Cout_fwd] (clc_filter_transpose).
@@ -68,6 +69,7 @@ typedef struct {
   const float* res; int ldr; float res_scale;
   float* y_pre; int ldp;     /* optional pre-activation copy (training) */
   int shuffle;
+  int res_first;
 } clc_conv_desc;
 
 int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream);
@@ -182,6 +184,13 @@ int clc_quantize_build_indexes(const float* y, int ldy, const float* mu, int ldm
                                const float* scale_table, int n_scales, int32_t* symbols, int32_t* indexes,
                                float* y_hat, int ldh, long rows, int C, clc_stream_t stream);
 
+/* rate / distortion reductions and their gradients (train_CLC.py:43-57). g_dev points at the upstream
+ * gradient of the loss (a device scalar), so the backward never reads back to the host. */
+int clc_log2_sum_partials(const float* x, int ld, long rows, int C, float* partials, int n_partials, clc_stream_t stream);
+int clc_scaled_recip(const float* x, int ld, long rows, int C, const float* g_dev, float coef, float* out, int ldo,
+                     clc_stream_t stream);                       /* out = g*coef / x   */
+int clc_scaled_diff(const float* a, const float* b, long n, const float* g_dev, float coef, float* out,
+                    clc_stream_t stream);                        /* out = g*coef*(a-b) */
 /* sum of n floats (fixed order) -> out[0] (+)= scale * sum */
 int clc_sum_partials(const float* partials, int n, float scale, float* out, int accumulate, clc_stream_t stream);
 /* sum((a-b)^2) partials */

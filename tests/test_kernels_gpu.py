@@ -187,7 +187,8 @@ def _ref_wmsa_core(qkv_nchw, relbias, heads, ws, shift):
     N, C3, H, W = qkv_nchw.shape
     C = C3 // 3
     m = WMSA(C, C, C // heads, ws, "SW" if shift else "W")
-    m.relative_position_params = torch.nn.Parameter(relbias)
+    del m.relative_position_params
+    m.relative_position_params = relbias  # plain tensor so that autograd reaches the caller's leaf
     x = qkv_nchw.permute(0, 2, 3, 1)
     sh = ws // 2
     if shift:
@@ -261,8 +262,9 @@ def test_gaussian_likelihood(dev, training):
     w = torch.rand(lik.shape, generator=torch.Generator().manual_seed(5)) - 0.7  # mixed-sign upstream grads (LowerBound rule)
     (lik * w).sum().backward()
     yd, md, sd = (_dev(t.detach(), dev, grad=True) for t in (y, mu, sc))
-    l2 = ops.gaussian_likelihood(yd, sd, md, _dev(noise, dev) if training else None, training)
+    l2, y_hat = ops.gaussian_likelihood(yd, sd, md, _dev(noise, dev) if training else None, training)
     _close(l2, lik, 1e-5, "gauss lik")
+    assert torch.equal(y_hat.cpu(), (torch.round(y - mu) + mu).detach()), "ste-rounded y_hat"
     # relative check in log domain for the tails
     assert (torch.log(l2.cpu()) - torch.log(lik.detach())).abs().max() < 2e-3
     (l2 * _dev(w, dev)).sum().backward()
@@ -298,8 +300,9 @@ def test_entropy_bottleneck_likelihood(dev, training):
     md, bd, fd = ([_dev(t.detach(), dev, cl=False, grad=True) for t in ts] for ts in (mats, biases, factors))
     zd = _dev(z.detach(), dev, grad=True)
     qd = _dev(eb.quantiles.detach(), dev, cl=False)
-    l2 = ops.eb_likelihood(zd, _dev(noise, dev) if training else None, qd, training, md, bd, fd)
+    l2, z_hat = ops.eb_likelihood(zd, _dev(noise, dev) if training else None, qd, training, md, bd, fd)
     _close(l2, lik, 1e-5, "eb lik")
+    assert torch.equal(z_hat.cpu(), (torch.round(z - med) + med).detach()), "ste-rounded z_hat"
     (l2 * _dev(w, dev)).sum().backward()
     for k in range(5):
         _close(md[k].grad, mats[k].grad, 2e-4, f"eb dmatrix{k}")
