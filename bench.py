@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the CLC hot path on MI355X (BASELINE.json: images/sec fwd+bwd @256x256 bs8).
+
+One "step" = one full training step of the reference loop (/root/reference/train_CLC.py:137-183) on one
+synthetic batch already resident in HBM: forward (CLC N=64, lambda=0.0067, n_refs=1) + RD loss + backward +
+clip_grad_norm_(1.0) + nan_to_num_ + AdamW + aux-loss step, fp32, through the HIP kernels of libclc_hip.so.
+
+  python bench.py --gpus N --steps K --warmup W
+For N > 1 the driver launches it under torch.distributed.run (one rank per GPU, RCCL): every rank draws its
+own synthetic shard (weak scaling), gradients are averaged with all-reduce over the flat gradient arena.
+Rank 0 prints ONE JSON line (contract in the task description) with the extra objects
+  "roofline"      dominant kernel's algorithmic FLOP / measured duration (HIP events on the launch stream) vs the
+                  f32-MFMA peak of gfx950 (157.3 TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md)
+  "cpu_baseline"  the CPU oracle (plain PyTorch restatement of the reference graph) timed on the host cores on
+                  a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_batch(batch, size, seed, device):
+    """uint8 noise / 255 (mirrors normalize_to_tensor, /root/reference/dataloader_ref_cluster.py:182-194)."""
+    import torch
+
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randint(0, 256, (batch, 3, size, size), generator=g, dtype=torch.uint8).float() / 255.0
+    return x.to(device)
+
+
+def cpu_baseline(n_refs: int, sample_batch: int, size: int):
+    """Oracle fwd + RD loss + bwd on the host cores (checker used as the reported baseline, never as the product)."""
+    import torch
+
+    from oracle import graph as og
+    from oracle.loss import RateDistortionLoss
+    from oracle.recipe import apply_weight_recipe
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    m = og.CLC(N=64, num_ref_frames=n_refs).train()
+    apply_weight_recipe(m, 0)
+    crit = RateDistortionLoss(0.0067)
+    x = synthetic_batch(sample_batch, size, 100, "cpu")
+    refs = [synthetic_batch(sample_batch, size, 101 + i, "cpu") for i in range(n_refs)]
+
+    def one():
+        for p in m.parameters():
+            p.grad = None
+        out = crit(m(x, refs), x)
+        out["loss"].backward()
+
+    one()  # warm-up (first iteration pays allocator / thread-pool start-up)
+    t0 = time.perf_counter()
+    one()
+    dt = time.perf_counter() - t0
+    return {"value": sample_batch / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle (plain PyTorch CPU restatement of the reference graph) fwd+RD-loss+bwd, 1 warm-up + 1 timed step at batch {sample_batch} "
+                      f"({size}x{size}, n_refs={n_refs}), {cores} torch threads, fp32; {dt:.2f} s"}
+
+
+def roofline_leg(engine, x, refs):
+    """One eager (non-graph) step with every conv / wgrad launch bracketed by HIP events on its launch stream."""
+    import torch
+
+    from clc_amd import ops
+
+    torch.cuda.synchronize()
+    ops.PROFILE = []
+    try:
+        engine._eager_step(x, refs)
+        torch.cuda.synchronize()
+        rec = ops.PROFILE
+    finally:
+        ops.PROFILE = None
+    agg = {}
+    for fam, variant, flops, e0, e1 in rec:
+        key = f"{fam}<{variant // 1000},{variant % 1000}>" if variant >= 1000 else fam
+        a = agg.setdefault(key, [0.0, 0.0, 0])
+        a[0] += flops
+        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[2] += 1
+    total_t = sum(a[1] for a in agg.values())
+    total_f = sum(a[0] for a in agg.values())
+    dom = max(agg.items(), key=lambda kv: kv[1][1])
+    name, (f, t, n) = dom
+    achieved = f / t / 1e12
+    table = {k: {"launches": v[2], "gflop": round(v[0] / 1e9, 2), "ms": round(v[1] * 1e3, 3), "tflops": round(v[0] / v[1] / 1e12, 2)} for k, v in agg.items()}
+    return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "launches_per_step": n, "avg_launch_ms": round(t / n * 1e3, 4),
+            "all_mfma_kernels": {"tflops": round(total_f / total_t / 1e12, 2), "ms_per_step": round(total_t * 1e3, 2), "gflop_per_step": round(total_f / 1e9, 1)},
+            "per_kernel": table}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--n-refs", type=int, default=1)
+    ap.add_argument("--lmbda", type=float, default=0.0067)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched as: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from clc_amd import models
+    from clc_amd.train import TrainEngine, broadcast_parameters
+    from oracle.recipe import apply_weight_recipe  # checker-side weight recipe: same named weights as the cpu_baseline leg
+
+    torch.manual_seed(0)
+    model = models.CLC(N=64, num_ref_frames=args.n_refs)
+    apply_weight_recipe(model, 0)
+    model = model.to(dev).train()
+    broadcast_parameters(model)
+    x = synthetic_batch(args.batch, args.size, 100 + rank, dev)
+    refs = [synthetic_batch(args.batch, args.size, 1000 + 10 * rank + i, dev) for i in range(args.n_refs)]
+
+    engine = TrainEngine(model, lmbda=args.lmbda, lr=1e-4, aux_lr=1e-3, clip_max_norm=1.0, use_graph=not args.no_graph)
+    for _ in range(max(1, args.warmup)):
+        out = engine.step(x, refs)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = engine.step(x, refs)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(out["loss"].item())
+
+    result = {
+        "metric": "images/sec fwd+bwd @256x256 bs8; bpp+PSNR parity vs ref",
+        "value": world * args.batch * args.steps / dt,
+        "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"CLC N=64 lambda={args.lmbda} MSE, {args.size}x{args.size} bs{args.batch}/GPU, n_refs={args.n_refs}: "
+                               "fwd + RD loss + bwd + clip_grad_norm + AdamW + aux step (configs[1])",
+                   "global_batch": world * args.batch, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
+                   "final_loss": loss},
+    }
+    if not args.no_roofline:  # every rank runs it (the eager step contains the gradient all-reduce); rank 0 reports
+        result["roofline"] = roofline_leg(engine, x, refs)
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.n_refs, args.cpu_sample_batch, args.size)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

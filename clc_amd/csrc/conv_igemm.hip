@@ -230,7 +230,7 @@ int launch(const ConvParams& p, int classes, hipStream_t st) {
   }
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(64 * WM * WN), lds, st, p);
   CLC_LAUNCH_CHECK();
-  return 0;
+  return BM * 1000 + BN;  // kernel-variant id (>= 0): lets callers attribute time per template instantiation
 }
 
 // small-Cin (image, Cin<=4, unaligned) direct convolution: one thread per (pixel, 4 output channels)
@@ -344,7 +344,7 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
     const long total = (long)p.M * cgroups;
     hipLaunchKernelGGL(conv_direct_small_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
     CLC_LAUNCH_CHECK();
-    return 0;
+    return 1;  // variant id of the direct small-Cin kernel
   }
   // tile selection: depends on (M, Cout) only for speed; numerics are tile-independent (see header)
   const long M = p.M;

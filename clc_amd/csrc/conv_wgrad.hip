@@ -282,5 +282,5 @@ extern "C" int clc_conv2d_wgrad(const clc_wgrad_desc* d, clc_stream_t stream) {
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((d->Cout + 255) / 256), dim3(256), 0, st, p.bias_partial, d->dbias, (long)d->Cout, pl.splits, d->accumulate);
     CLC_LAUNCH_CHECK();
   }
-  return 0;
+  return pl.small ? 1 : pl.bm * 1000 + pl.bn;  // kernel-variant id
 }

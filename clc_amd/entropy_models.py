@@ -133,14 +133,15 @@ class EntropyBottleneck(EntropyModel):
         m, b, f = self._params()
         return ops.eb_aux_loss(self.quantiles, self.target, m, b, f)
 
-    # ---- table construction (host-side logic, once per model; same arithmetic as SURVEY.md A.2) ----
-    def _logits_cumulative(self, inputs):
+    # ---- table construction: host-side, once per model.  Always evaluated on the HOST CPU in fp32 so
+    # that encoder and decoder build bit-identical integer tables whatever device the model lives on. ----
+    def _logits_cumulative_host(self, inputs):
         logits = inputs
         for i in range(len(self.filters) + 1):
-            logits = torch.matmul(torch.nn.functional.softplus(getattr(self, f"_matrix{i:d}").detach()), logits)
-            logits = logits + getattr(self, f"_bias{i:d}").detach()
+            logits = torch.matmul(torch.nn.functional.softplus(getattr(self, f"_matrix{i:d}").detach().cpu()), logits)
+            logits = logits + getattr(self, f"_bias{i:d}").detach().cpu()
             if i < len(self.filters):
-                logits = logits + torch.tanh(getattr(self, f"_factor{i:d}").detach()) * torch.tanh(logits)
+                logits = logits + torch.tanh(getattr(self, f"_factor{i:d}").detach().cpu()) * torch.tanh(logits)
         return logits
 
     @torch.no_grad()
@@ -148,20 +149,21 @@ class EntropyBottleneck(EntropyModel):
         if self._offset.numel() > 0 and not force:
             return False
         dev = self.quantiles.device
-        medians = self.quantiles[:, 0, 1]
-        minima = torch.clamp(torch.ceil(medians - self.quantiles[:, 0, 0]).int(), min=0)
-        maxima = torch.clamp(torch.ceil(self.quantiles[:, 0, 2] - medians).int(), min=0)
-        self._offset = -minima
+        q = self.quantiles.detach().cpu()
+        medians = q[:, 0, 1]
+        minima = torch.clamp(torch.ceil(medians - q[:, 0, 0]).int(), min=0)
+        maxima = torch.clamp(torch.ceil(q[:, 0, 2] - medians).int(), min=0)
         pmf_start = medians - minima
         pmf_length = maxima + minima + 1
         max_length = int(pmf_length.max().item())
-        samples = torch.arange(max_length, device=dev)[None, :] + pmf_start[:, None, None]
-        lower = self._logits_cumulative(samples - 0.5)
-        upper = self._logits_cumulative(samples + 0.5)
+        samples = torch.arange(max_length)[None, :] + pmf_start[:, None, None]
+        lower = self._logits_cumulative_host(samples - 0.5)
+        upper = self._logits_cumulative_host(samples + 0.5)
         sign = -torch.sign(lower + upper)
         pmf = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))[:, 0, :]
         tail_mass = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
-        self._quantized_cdf = self._pmf_to_cdf(pmf, tail_mass, pmf_length.cpu(), max_length).to(dev)
+        self._offset = (-minima).to(dev)
+        self._quantized_cdf = self._pmf_to_cdf(pmf, tail_mass, pmf_length, max_length).to(dev)
         self._cdf_length = (pmf_length + 2).to(dev)
         self._host_tables = None
         return True

@@ -23,6 +23,10 @@ from .lib import (ACT_GELU, ACT_HALFTANH, ACT_LRELU, ACT_NONE, ACT_RELU, IN_NONE
 
 CL = torch.channels_last
 
+# when set to a list, every conv / wgrad launch is bracketed by HIP events on the launch stream and recorded as
+# (kernel family, tile-variant id, algorithmic FLOPs, start event, end event) — used by bench.py's roofline leg
+PROFILE = None
+
 
 def _L():
     return _lib.load()
@@ -118,7 +122,15 @@ def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_
         q, qp, *_r, ldp = nhwc(y_pre)
         assert q is y_pre
         d.y_pre, d.ldp = qp, ldp
-    _lib.check(_L().clc_conv2d(C.byref(d), _stream()), "clc_conv2d")
+    if PROFILE is None:
+        _lib.check(_L().clc_conv2d(C.byref(d), _stream()), "clc_conv2d")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        variant = _lib.check(_L().clc_conv2d(C.byref(d), _stream()), "clc_conv2d")
+        e1.record()
+        pix = N * H * W if transposed else N * OH * OW
+        PROFILE.append(("conv_igemm" if variant != 1 else "conv_direct_small", variant, 2.0 * pix * ks * ks * Cin * Cout, e0, e1))
     return out
 
 
@@ -142,7 +154,14 @@ def wgrad_raw(x, dy, *, ks, stride, pad, Cout, Cin, want_bias, in_op=IN_NONE):
     nbytes = _L().clc_conv2d_wgrad_workspace_bytes(C.byref(d))
     ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
     d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
-    _lib.check(_L().clc_conv2d_wgrad(C.byref(d), _stream()), "clc_conv2d_wgrad")
+    if PROFILE is None:
+        _lib.check(_L().clc_conv2d_wgrad(C.byref(d), _stream()), "clc_conv2d_wgrad")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        variant = _lib.check(_L().clc_conv2d_wgrad(C.byref(d), _stream()), "clc_conv2d_wgrad")
+        e1.record()
+        PROFILE.append(("conv_wgrad" if variant != 1 else "wgrad_small", variant, 2.0 * N * OH * OW * ks * ks * Cin * Cout, e0, e1))
     return dw, db
 
 

@@ -16,8 +16,9 @@
  *  - Every function enqueues work on `stream` and returns immediately: no allocation,
  *    no synchronisation, no host read-back -> capturable in a hipGraph.  The caller owns
  *    every buffer including workspaces (sizes from the *_workspace_bytes helpers).
- *  - Return value: 0 = ok, negative = error; clc_last_error() gives the message
- *    (thread-local).  No C++ exception crosses the ABI.
+ *  - Return value: >= 0 = ok (clc_conv2d / clc_conv2d_wgrad return the id BM*1000+BN of the
+ *    tile variant they launched, 1 = small-Cin kernel), negative = error; clc_last_error()
+ *    gives the message (thread-local).  No C++ exception crosses the ABI.
  *  - Results are run-to-run deterministic (no floating-point atomics anywhere) and do not
  *    depend on the batch size for a given image (per-output accumulation order is fixed),
  *    which the encoder/decoder agreement of compress()/decompress() relies on.

@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ (numbers only — never reference source).
+
+Runs in the BUILD CONTAINER (needs /root/reference); the fixtures it writes are what travels.
+  graph_*.npz   outputs of the reference's OWN model classes (imported through tools/ref_shim.py, i.e.
+                genuine CLC/TCM/WMSA/Block/ConvTransBlock/SWAtten code over the oracle's restated leaves)
+                on recipe weights (oracle/recipe.py) and seeded inputs  -> pins the oracle's graph wiring
+  blocks.npz    outputs of the reference's WMSA / Block / SwinBlock / ConvTransBlock classes -> pins window
+                attention, shift mask, relative-position indexing, LN/MLP exactly
+  rans_kat.json known-answer bitstreams from the pure-Python coder (oracle/rans_py.py) incl. bypass escapes,
+                and a digest of the Gaussian CDF tables
+Usage: python tools/make_golden.py
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import leaves, rans_py  # noqa: E402
+from oracle.loss import RateDistortionLoss  # noqa: E402
+from oracle.recipe import apply_weight_recipe, synthetic_image  # noqa: E402
+from tools import ref_shim  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def summarize(out, x):
+    crit = RateDistortionLoss(0.0067)(out, x)
+    xh, ly, lz = out["x_hat"], out["likelihoods"]["y"], out["likelihoods"]["z"]
+    p = out["para"]
+    return {
+        "bpp": np.float64(crit["bpp_loss"].item()), "mse": np.float64(crit["mse_loss"].item()), "loss": np.float64(crit["loss"].item()),
+        "x_hat_patch": xh[0, :, 96:112, 96:112].numpy(), "x_hat_mean": np.float64(xh.double().mean().item()),
+        "x_hat_abs_sum": np.float64(xh.double().abs().sum().item()),
+        "lik_y_logsum": np.float64(torch.log(ly.double()).sum().item()), "lik_z_logsum": np.float64(torch.log(lz.double()).sum().item()),
+        "lik_y_patch": ly[0, ::40, 4:8, 4:8].numpy(), "lik_z": lz[0, ::16].numpy(),
+        "y_patch": p["y"][0, ::32, :8, :8].numpy(), "means_patch": p["means"][0, ::32, :8, :8].numpy(),
+        "scales_patch": p["scales"][0, ::32, :8, :8].numpy(),
+    }
+
+
+def graph_goldens(ref):
+    for name, R in (("clc_r1", 1), ("clc_r3", 3), ("tcm", 0)):
+        torch.manual_seed(0)
+        m = (ref.CLC(N=64, num_ref_frames=R) if R else ref.TCM(N=64)).eval()
+        apply_weight_recipe(m, 0)
+        x = synthetic_image(1, 256, 256, 100, smooth=True)
+        refs = [synthetic_image(1, 256, 256, 101 + i, smooth=True) for i in range(R)]
+        with torch.no_grad():
+            out = m(x, refs) if R else m(x)
+        s = summarize(out, x)
+        s["n_params"] = np.int64(sum(p.numel() for p in m.parameters()))
+        s["n_state"] = np.int64(len(m.state_dict()))
+        # which parameters receive a gradient (decides the live set of the fused optimizer / DDP buckets)
+        m.zero_grad()
+        o2 = m(x, refs) if R else m(x)
+        RateDistortionLoss(0.0067)(o2, x)["loss"].backward()
+        dormant = sorted({n.split(".")[0] for n, p in m.named_parameters() if p.grad is None})
+        s["dormant_prefixes"] = np.array(",".join(dormant))
+        s["n_live"] = np.int64(sum(p.numel() for p in m.parameters() if p.grad is not None))
+        np.savez_compressed(os.path.join(OUT, f"graph_{name}.npz"), **s)
+        print(name, {k: (float(v) if np.ndim(v) == 0 and v.dtype.kind == "f" else None) for k, v in s.items() if np.ndim(v) == 0 and v.dtype.kind == "f"},
+              "dormant:", dormant, "live:", int(s["n_live"]))
+
+
+def block_goldens(ref):
+    mod = sys.modules["models.CLC_run"]
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    for typ in ("W", "SW"):
+        for (C, hd, ws, H, W) in ((64, 8, 8, 16, 24), (64, 32, 4, 8, 8), (128, 16, 8, 16, 16)):
+            tag = f"{typ}_{C}_{hd}_{ws}_{H}x{W}"
+            x = torch.randn(2, H, W, C, generator=g)
+            msa = mod.WMSA(C, C, hd, ws, typ).eval()
+            apply_weight_recipe(msa, 1)
+            blk = mod.Block(C, C, hd, ws, 0, typ).eval()
+            apply_weight_recipe(blk, 2)
+            with torch.no_grad():
+                out[f"wmsa_{tag}_x"] = x.numpy()
+                out[f"wmsa_{tag}_y"] = msa(x).numpy()
+                out[f"block_{tag}_y"] = blk(x).numpy()
+    xs = torch.randn(1, 128, 16, 16, generator=g)
+    ctb = mod.ConvTransBlock(64, 64, 16, 8, 0, "SW").eval()
+    apply_weight_recipe(ctb, 3)
+    swa = mod.SWAtten(384, 384, 16, 8, 0, inter_dim=128).eval()
+    apply_weight_recipe(swa, 4)
+    xa = torch.randn(1, 384, 16, 16, generator=g)
+    with torch.no_grad():
+        out["ctb_x"], out["ctb_y"] = xs.numpy(), ctb(xs).numpy()
+        out["swatten_x"], out["swatten_y"] = xa.numpy(), swa(xa).numpy()
+    np.savez_compressed(os.path.join(OUT, "blocks.npz"), **out)
+    print("blocks:", len(out), "arrays")
+
+
+def rans_goldens():
+    gc = leaves.GaussianConditional(None)
+    gc.update_scale_table(leaves.get_scale_table())
+    cdf, ln, off = gc.quantized_cdf.tolist(), gc.cdf_length.tolist(), gc.offset.tolist()
+    arr = gc.quantized_cdf.numpy().astype(np.int32)
+    kat = {"gaussian_cdf_sha256": hashlib.sha256(arr.tobytes()).hexdigest(), "gaussian_cdf_shape": list(arr.shape),
+           "cdf_row0": cdf[0][:6], "cdf_len_first_last": [ln[0], ln[-1]], "offset_first_last": [off[0], off[-1]],
+           "cdf_row20_head": cdf[20][:12], "scale_table_sha256": hashlib.sha256(gc.scale_table.numpy().tobytes()).hexdigest(), "cases": []}
+    rng = np.random.default_rng(1234)
+    cases = [
+        ("empty", [], []),
+        ("single_zero", [0], [0]),
+        ("in_range_small", [0, 1, -1, 2, -2, 0, 0, 1], [5, 5, 9, 12, 12, 0, 63, 30]),
+        ("escapes", [100, -100, 5000, -5000, 70000, -70000, 2 ** 20, -(2 ** 20), 0], [0, 0, 3, 3, 10, 10, 63, 63, 1]),
+        ("long_unary_escape", [2 ** 27, -(2 ** 27) - 1], [0, 63]),
+    ]
+    idx = rng.integers(0, 64, 4000).astype(np.int32)
+    sig = gc.scale_table.numpy()[idx]
+    sym = np.round(rng.normal(0, sig)).astype(np.int32)
+    sym[rng.random(4000) < 0.02] = rng.integers(-3000, 3000, int((rng.random(4000) < 0.02).sum()) or 1)[0]
+    cases.append(("random_4000", sym.tolist(), idx.tolist()))
+    for name, s, i in cases:
+        stream = rans_py.RansEncoder().encode_with_indexes(s, i, cdf, ln, off)
+        dec = rans_py.RansDecoder().decode_with_indexes(stream, i, cdf, ln, off)
+        assert dec == list(s), name
+        kat["cases"].append({"name": name, "symbols": list(map(int, s)), "indexes": list(map(int, i)), "stream_hex": stream.hex()})
+    # CDF quantiser known answers
+    kat["pmf_cases"] = []
+    for n in (2, 3, 7, 40):
+        p = rng.random(n).astype(np.float32) ** 3
+        p[rng.integers(0, n)] = 0.0  # force a zero-width bin -> frequency stealing
+        p /= p.sum()
+        kat["pmf_cases"].append({"pmf": [float(v) for v in p], "cdf": rans_py.pmf_to_quantized_cdf(p.tolist(), 16)})
+    with open(os.path.join(OUT, "rans_kat.json"), "w") as f:
+        json.dump(kat, f)
+    print("rans kat:", [c["name"] for c in kat["cases"]])
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = ref_shim.import_reference_models()
+    graph_goldens(ref)
+    block_goldens(ref)
+    rans_goldens()
+
+
+if __name__ == "__main__":
+    main()
