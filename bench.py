@@ -47,7 +47,10 @@ def cpu_baseline(n_refs: int, sample_batch: int, size: int):
     from oracle.loss import RateDistortionLoss
     from oracle.recipe import apply_weight_recipe
 
-    cores = os.cpu_count() or 1
+    # threads actually usable by this process (affinity mask; os.cpu_count() over-reports inside a cpuset) and what
+    # torch's intra-op pool was sized to — never oversubscribe, that makes the "baseline" arbitrarily slow
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(usable, torch.get_num_threads()))
     torch.set_num_threads(cores)
     m = og.CLC(N=64, num_ref_frames=n_refs).train()
     apply_weight_recipe(m, 0)
