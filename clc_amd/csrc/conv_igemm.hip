@@ -7,23 +7,36 @@
 // GEMM view:  M = output pixels, N = output channels, K = (tap, input channel).
 //   A[m][k] is gathered from the NHWC input (zero outside the image), B[n][k] is the filter
 //   row [Cout][tap][Cin] — both K-contiguous, so one LDS image serves both: [rows][32+4] floats,
-//   16-B global loads -> ds_write_b128, fragments by ds_read_b128.
+//   16-B loads -> ds_write_b128, fragments by ds_read_b128 (the +4 pad = 9 sixteen-byte slots
+//   per row makes every 16-lane read group hit 16 distinct slots: conflict-free).
+// Loads are `buffer_load_dwordx4` through an SRD with hardware range checking: halo pixels,
+// rows past M and channels past Cin/Cout get an out-of-range offset and come back as zeros —
+// no branch, no exec-mask juggling, no wait in front of the MFMAs (branches around loads make
+// hipcc wait vmcnt(0) at every join: measured 3x slower).
 // The f32 MFMA takes ONE float per lane per operand (lane l: A[i=l&31][k=l>>5]); a lane reads 4
 // consecutive k with one ds_read_b128 and feeds 4 MFMAs from it, i.e. MFMA step (t,s) contracts
-// the physical k pair {8t+s, 8t+4+s}.  A and B use the same pairing, so the sum is exact; only
-// the (fixed, shape-independent) accumulation order differs from a k-ascending loop.
-// The accumulation order per output element depends only on (ks, Cin) — never on the tile
-// shape, the batch size or the launch grid — so results are identical across tile configs.
+// the physical k pair {8t+s, 8t+4+s}.  A and B use the same pairing, so the sum is exact.
+// Summation order per output element is a function of (ks, Cin) and of the kernel FAMILY only;
+// the family is chosen from the per-image map size and channel counts — never from the batch
+// size — so an image's result does not depend on what else is in the batch.
 //
-// f32 MFMA runs at the f32 vector rate (64 cyc per 32x32x2): the kernel is MFMA-bound, LDS and
-// HBM traffic are far from their limits (arithmetic intensity >> the 25 FLOP/B ridge), so the
-// structure is a plain double-buffered LDS pipeline with register prefetch, 2 workgroups/CU.
+// Two families:
+//   conv_igemm_kernel<BM,BN,WM,WN>   block-cooperative tiles, double-buffered LDS, register
+//                                    prefetch of K-tile k+1 under the MFMAs of tile k, 2 WG/CU.
+//   conv_igemm_splitk_kernel<BN>     small maps (<= 16x16 per image): 4 waves per 32xBN tile,
+//                                    each wave streams every 4th K-tile through its OWN LDS
+//                                    ring (no workgroup barrier in the loop, 4x the loads in
+//                                    flight, 4x shorter dependent chain), fixed-order
+//                                    ((w0+w1)+(w2+w3)) combine through LDS.
 #include "common.h"
 
 namespace {
 
 constexpr int BK = 32;   // K-tile (floats)
-constexpr int LD = 36;   // LDS row stride (floats): 9 16-B slots -> conflict-free b128 reads
+constexpr int LD = 36;   // LDS row stride (floats)
+constexpr unsigned kOOB = 0x80000000u;  // >= num_records of every SRD -> load returns 0
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvParams {
   const float* x; const float* w; const float* bias; float* y;
@@ -35,15 +48,97 @@ struct ConvParams {
   float res_scale;
   int M;                       // rows per class (transposed&stride2: per parity class)
   int kc_tiles;                // ceil(Cin/32)
+  unsigned x_bytes, w_bytes;
 };
 
-template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0));
+}
+
+// Block-uniform description of the live filter taps: a (nkh x nkw) grid kh = kh0 + step*j.
+struct TapGrid { int kh0, kw0, step, nkh, nkw; };
+__device__ __forceinline__ TapGrid make_taps(const ConvParams& p, int ph, int pw) {
+  TapGrid t;
+  if (p.transposed && p.stride == 2) {   // data-gradient of a stride-2 conv: only taps of the class's parity
+    t.kh0 = (ph + p.pad) & 1; t.kw0 = (pw + p.pad) & 1; t.step = 2;
+    t.nkh = (p.ks - t.kh0 + 1) >> 1; t.nkw = (p.ks - t.kw0 + 1) >> 1;
+  } else {
+    t.kh0 = t.kw0 = 0; t.step = 1; t.nkh = t.nkw = p.ks;
+  }
+  return t;
+}
+
+// Per-thread gather state for one A row (fixed over the K loop).
+struct RowState { int base, y0, x0; bool ok; };
+template <bool TR>
+__device__ __forceinline__ RowState make_row(const ConvParams& p, int m, int DH, int DW, int ph, int pw) {
+  RowState r;
+  r.ok = m < p.M;
+  const int mm = r.ok ? m : 0;
+  const int n = mm / (DH * DW), q = mm - n * (DH * DW);
+  int oy = q / DW, ox = q - oy * DW;
+  if (TR) {
+    if (p.stride == 2) { oy = 2 * oy + ph; ox = 2 * ox + pw; }
+    r.y0 = oy + p.pad; r.x0 = ox + p.pad;
+  } else {
+    r.y0 = oy * p.stride - p.pad; r.x0 = ox * p.stride - p.pad;
+  }
+  r.base = n * p.H * p.W;
+  return r;
+}
+// byte offset of (row, tap kh/kw, channel c) in x, or kOOB
+template <bool TR>
+__device__ __forceinline__ unsigned a_offset(const ConvParams& p, const RowState& r, int kh, int kw, int c, bool c_ok) {
+  int iy, ix;
+  bool ok = r.ok && c_ok;
+  if (TR) {
+    const int sh = p.stride - 1;                 // parity already guaranteed by the tap grid
+    const int ty = r.y0 - kh, tx = r.x0 - kw;
+    iy = ty >> sh; ix = tx >> sh;
+    ok = ok && ty >= 0 && tx >= 0;
+  } else {
+    iy = r.y0 + kh; ix = r.x0 + kw;
+  }
+  ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+  const unsigned off = ((unsigned)(r.base + iy * p.W + ix) * (unsigned)p.ldx + (unsigned)c) * 4u;
+  return ok ? off : kOOB;
+}
+
+// Shared epilogue for one accumulator element.
+__device__ __forceinline__ void epilogue_store(const ConvParams& p, float acc, float bv, int m, int co, int DH, int DW, int ph, int pw) {
+  size_t pix; int ch = co;
+  if (p.transposed && p.stride == 2) {
+    const int n = m / (DH * DW), rr = m - n * (DH * DW);
+    const int oy = rr / DW, ox = rr - oy * DW;
+    pix = (size_t)(n * p.OH + 2 * oy + ph) * p.OW + 2 * ox + pw;
+  } else if (p.shuffle) {
+    const int n = m / (p.OH * p.OW), rr = m - n * (p.OH * p.OW);
+    const int oy = rr / p.OW, ox = rr - oy * p.OW;
+    ch = co >> 2;
+    pix = (size_t)(n * 2 * p.OH + 2 * oy + ((co >> 1) & 1)) * (2 * p.OW) + 2 * ox + (co & 1);
+  } else {
+    pix = (size_t)m;
+  }
+  float v = acc + bv;
+  if (p.res && p.res_first) v += p.res_scale * p.res[pix * p.ldr + ch];
+  if (p.y_pre) p.y_pre[pix * p.ldp + ch] = v;
+  if (p.norm != CLC_NORM_NONE) {
+    const float mv = p.mul[pix * p.ldm + ch];
+    v = (p.norm == CLC_NORM_GDN) ? mv * rsqrtf(v) : mv * sqrtf(v);
+  }
+  v = apply_act(v, p.act);
+  if (p.res && !p.res_first) v += p.res_scale * p.res[pix * p.ldr + ch];
+  p.y[pix * p.ldy + ch] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool TR>
 __global__ __launch_bounds__(64 * WM * WN, (64 * WM * WN) >= 256 ? 2 : 4)
 void conv_igemm_kernel(const ConvParams p) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int A_P = (BM * 8 + NT - 1) / NT, B_P = (BN * 8 + NT - 1) / NT;
-  static_assert(TM >= 1 && TN >= 1, "tile");
+  constexpr int A_P = BM * 8 / NT, B_P = BN * 8 / NT;
+  static_assert(TM >= 1 && TN >= 1 && A_P * NT == BM * 8 && B_P * NT == BN * 8, "tile");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                    // [2][BM][LD]
   float* Bs = smem + 2 * BM * LD;      // [2][BN][LD]
@@ -51,75 +146,46 @@ void conv_igemm_kernel(const ConvParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  // parity class for the transposed stride-2 case (dgrad of a strided conv)
-  const int cls = blockIdx.z, ph = cls >> 1, pw = cls & 1;
-  const int s = p.stride;
-  const int DH = (p.transposed && s == 2) ? p.OH / 2 : p.OH;   // decode dims of m
-  const int DW = (p.transposed && s == 2) ? p.OW / 2 : p.OW;
+  const int cls = blockIdx.z, ph = cls >> 1, pw = cls & 1;   // parity class (transposed stride 2 only)
+  const bool half = p.transposed && p.stride == 2;
+  const int DH = half ? p.OH / 2 : p.OH, DW = half ? p.OW / 2 : p.OW;
+  const TapGrid tg = make_taps(p, ph, pw);
 
-  // ---- per-thread gather rows (fixed over the K loop) ----
-  int a_base[A_P], a_y0[A_P], a_x0[A_P];
-  bool a_ok[A_P];
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+
+  RowState rows[A_P];
 #pragma unroll
-  for (int i = 0; i < A_P; ++i) {
-    const int piece = tid + i * NT, row = piece >> 3;
-    const int m = m0 + row;
-    a_ok[i] = (row < BM) && (m < p.M);
-    const int mm = a_ok[i] ? m : 0;
-    const int n = mm / (DH * DW), r = mm - n * (DH * DW);
-    int oy = r / DW, ox = r - oy * DW;
-    if (p.transposed) {
-      if (s == 2) { oy = 2 * oy + ph; ox = 2 * ox + pw; }
-      a_y0[i] = oy + p.pad; a_x0[i] = ox + p.pad;
-    } else {
-      a_y0[i] = oy * s - p.pad; a_x0[i] = ox * s - p.pad;
-    }
-    a_base[i] = n * p.H * p.W;
+  for (int i = 0; i < A_P; ++i) rows[i] = make_row<TR>(p, m0 + ((tid + i * NT) >> 3), DH, DW, ph, pw);
+  unsigned b_row_off[B_P];
+  bool b_ok[B_P];
+#pragma unroll
+  for (int i = 0; i < B_P; ++i) {
+    const int co = n0 + ((tid + i * NT) >> 3);
+    b_ok[i] = co < p.Cout;
+    b_row_off[i] = (unsigned)co * (unsigned)p.ldw;
   }
   const int c4 = (tid & 7) * 4;
+  const bool sq = p.in_op == CLC_IN_SQUARE;
 
   f32x4 a_reg[A_P], b_reg[B_P];
-
   auto load_tile = [&](int kh, int kw, int kc) {
     const int c = kc * BK + c4;
     const bool c_ok = c < p.Cin;
 #pragma unroll
-    for (int i = 0; i < A_P; ++i) {
-      int iy, ix; bool ok = a_ok[i] && c_ok;
-      if (p.transposed) {
-        const int ty = a_y0[i] - kh, tx = a_x0[i] - kw;
-        ok = ok && ty >= 0 && tx >= 0 && ((ty | tx) & (s - 1)) == 0;
-        iy = ty >> (s - 1); ix = tx >> (s - 1);
-        ok = ok && iy < p.H && ix < p.W;
-      } else {
-        iy = a_y0[i] + kh; ix = a_x0[i] + kw;
-        ok = ok && iy >= 0 && ix >= 0 && iy < p.H && ix < p.W;
-      }
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4*>(p.x + (size_t)(a_base[i] + iy * p.W + ix) * p.ldx + c);
-      if (p.in_op == CLC_IN_SQUARE) v = v * v;
-      a_reg[i] = v;
-    }
-    const int tap = kh * p.ks + kw;
+    for (int i = 0; i < A_P; ++i) a_reg[i] = buf_load4(xr, a_offset<TR>(p, rows[i], kh, kw, c, c_ok));
+    const unsigned tap_off = (unsigned)((kh * p.ks + kw) * p.Cin + c);
 #pragma unroll
-    for (int i = 0; i < B_P; ++i) {
-      const int piece = tid + i * NT, row = piece >> 3, co = n0 + row;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < BN && co < p.Cout && c_ok) v = *reinterpret_cast<const f32x4*>(p.w + (size_t)co * p.ldw + tap * p.Cin + c);
-      b_reg[i] = v;
-    }
+    for (int i = 0; i < B_P; ++i) b_reg[i] = buf_load4(wr, (b_ok[i] && c_ok) ? (b_row_off[i] + tap_off) * 4u : kOOB);
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
-      const int piece = tid + i * NT, row = piece >> 3;
-      if (row < BM) *reinterpret_cast<f32x4*>(As + (buf * BM + row) * LD + c4) = a_reg[i];
+      const f32x4 v = sq ? a_reg[i] * a_reg[i] : a_reg[i];
+      *reinterpret_cast<f32x4*>(As + (buf * BM + ((tid + i * NT) >> 3)) * LD + c4) = v;
     }
 #pragma unroll
-    for (int i = 0; i < B_P; ++i) {
-      const int piece = tid + i * NT, row = piece >> 3;
-      if (row < BN) *reinterpret_cast<f32x4*>(Bs + (buf * BN + row) * LD + c4) = b_reg[i];
-    }
+    for (int i = 0; i < B_P; ++i) *reinterpret_cast<f32x4*>(Bs + (buf * BN + ((tid + i * NT) >> 3)) * LD + c4) = b_reg[i];
   };
 
   f32x16 acc[TM][TN];
@@ -130,32 +196,20 @@ void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // ---- K loop over (tap, channel tile); taps of the wrong parity are skipped block-uniformly ----
-  const int ntaps = p.ks * p.ks;
-  auto tap_live = [&](int t) -> bool {
-    if (!(p.transposed && s == 2)) return true;
-    const int kh = t / p.ks, kw = t - kh * p.ks;
-    return (((ph + p.pad - kh) & 1) == 0) && (((pw + p.pad - kw) & 1) == 0);
+  // K loop over (tap row j, tap col i, channel tile kc)
+  const int total = tg.nkh * tg.nkw * p.kc_tiles;
+  int tj = 0, ti = 0, kc = 0;
+  auto advance = [&]() {
+    if (++kc == p.kc_tiles) { kc = 0; if (++ti == tg.nkw) { ti = 0; ++tj; } }
   };
-  int total = 0;
-  for (int t = 0; t < ntaps; ++t) total += tap_live(t) ? p.kc_tiles : 0;
-
-  int t_cur = 0, kc_cur = 0;
-  auto advance = [&]() {  // move (t_cur, kc_cur) to the next live tile
-    if (++kc_cur == p.kc_tiles) { kc_cur = 0; ++t_cur; while (t_cur < ntaps && !tap_live(t_cur)) ++t_cur; }
-  };
-  while (t_cur < ntaps && !tap_live(t_cur)) ++t_cur;
-
-  if (total > 0) {
-    load_tile(t_cur / p.ks, t_cur % p.ks, kc_cur);
-    store_tile(0);
-    __syncthreads();
-  }
+  load_tile(tg.kh0, tg.kw0, 0);
+  store_tile(0);
+  __syncthreads();
   const int frag_col = 4 * (lane >> 5);
   for (int it = 0; it < total; ++it) {
     const int buf = it & 1;
-    const bool more = it + 1 < total;
-    if (more) { advance(); load_tile(t_cur / p.ks, t_cur % p.ks, kc_cur); }
+    advance();
+    if (it + 1 < total) load_tile(tg.kh0 + tg.step * tj, tg.kw0 + tg.step * ti, kc);   // block-uniform branch
     const float* Ab = As + (buf * BM + wm * (BM / WM) + (lane & 31)) * LD + frag_col;
     const float* Bb = Bs + (buf * BN + wn * (BN / WN) + (lane & 31)) * LD + frag_col;
 #pragma unroll
@@ -173,64 +227,179 @@ void conv_igemm_kernel(const ConvParams p) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][ss], bf[j][ss], acc[i][j], 0, 0, 0);
     }
-    if (more) store_tile(buf ^ 1);
+    if (it + 1 < total) store_tile(buf ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue: C/D map col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel) ----
-  const int col = lane & 31, rhalf = 4 * (lane >> 5);
+  // epilogue: stage the C tile in LDS (the operand tiles are dead now), then stream it out with a compact loop —
+  // consecutive threads = consecutive channels of one pixel -> fully coalesced stores, no 64x unrolled flag checks.
+  // C/D map of the MFMA: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel).
+  constexpr int LDC = BN + 4;
+  float* Cs = smem;   // [BM][LDC]  (fits: BM*LDC <= 2*(BM+BN)*LD for every tile variant)
+  {
+    const int col = lane & 31, rhalf = 4 * (lane >> 5);
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int co = n0 + wn * (BN / WN) + j * 32 + col;
-    if (co >= p.Cout) continue;
-    const float bv = p.bias ? p.bias[co] : 0.f;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + rhalf;
-        const int m = m0 + wm * (BM / WM) + i * 32 + row;
-        if (m >= p.M) continue;
-        size_t pix; int ch = co;
-        if (p.transposed && s == 2) {
-          const int n = m / (DH * DW), rr = m - n * (DH * DW);
-          const int oy = rr / DW, ox = rr - oy * DW;
-          pix = (size_t)(n * p.OH + 2 * oy + ph) * p.OW + 2 * ox + pw;
-        } else if (p.shuffle) {
-          const int n = m / (p.OH * p.OW), rr = m - n * (p.OH * p.OW);
-          const int oy = rr / p.OW, ox = rr - oy * p.OW;
-          ch = co >> 2;
-          pix = (size_t)(n * 2 * p.OH + 2 * oy + ((co >> 1) & 1)) * (2 * p.OW) + 2 * ox + (co & 1);
-        } else {
-          pix = (size_t)m;
-        }
-        float v = acc[i][j][r] + bv;
-        if (p.res && p.res_first) v += p.res_scale * p.res[pix * p.ldr + ch];
-        if (p.y_pre) p.y_pre[pix * p.ldp + ch] = v;
-        if (p.norm != CLC_NORM_NONE) {
-          const float mv = p.mul[pix * p.ldm + ch];
-          v = (p.norm == CLC_NORM_GDN) ? mv * rsqrtf(v) : mv * sqrtf(v);
-        }
-        v = apply_act(v, p.act);
-        if (p.res && !p.res_first) v += p.res_scale * p.res[pix * p.ldr + ch];
-        p.y[pix * p.ldy + ch] = v;
-      }
-    }
+        for (int r = 0; r < 16; ++r)
+          Cs[(wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf) * LDC + wn * (BN / WN) + j * 32 + col] = acc[i][j][r];
+  }
+  __syncthreads();
+  for (int e = tid; e < BM * BN; e += NT) {
+    const int row = e / BN, cc = e - row * BN;
+    const int m = m0 + row, co = n0 + cc;
+    if (m < p.M && co < p.Cout) epilogue_store(p, Cs[row * LDC + cc], p.bias ? p.bias[co] : 0.f, m, co, DH, DW, ph, pw);
   }
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch(const ConvParams& p, int classes, hipStream_t st) {
+// ------------------------------------------------------------------------------------------------
+// Small maps: one 32 x BN output tile per workgroup of 4 waves; wave w owns K-tiles w, w+4, ...
+template <int BN, bool TR>
+__global__ __launch_bounds__(256, 2)
+void conv_igemm_splitk_kernel(const ConvParams p) {
+  constexpr int BM = 32, TN = BN / 32, KW = 4;
+  constexpr int A_P = BM * 8 / 64, B_P = BN * 8 / 64;     // float4 pieces per lane per K-tile
+  constexpr int WAVE_LDS = (BM + BN) * LD;               // floats: ONE private tile per wave (LDS ops of a wave are in order,
+                                                         // so the write of tile k+1 cannot overtake the reads of tile k)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* As = smem + wave * WAVE_LDS;      // [BM][LD]
+  float* Bs = As + BM * LD;                // [BN][LD]
+
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int cls = blockIdx.z, ph = cls >> 1, pw = cls & 1;
+  const bool half = p.transposed && p.stride == 2;
+  const int DH = half ? p.OH / 2 : p.OH, DW = half ? p.OW / 2 : p.OW;
+  const TapGrid tg = make_taps(p, ph, pw);
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+
+  RowState rows[A_P];
+#pragma unroll
+  for (int i = 0; i < A_P; ++i) rows[i] = make_row<TR>(p, m0 + ((lane + i * 64) >> 3), DH, DW, ph, pw);
+  unsigned b_row_off[B_P];
+  bool b_ok[B_P];
+#pragma unroll
+  for (int i = 0; i < B_P; ++i) {
+    const int co = n0 + ((lane + i * 64) >> 3);
+    b_ok[i] = co < p.Cout;
+    b_row_off[i] = (unsigned)co * (unsigned)p.ldw;
+  }
+  const int c4 = (lane & 7) * 4;
+  const bool sq = p.in_op == CLC_IN_SQUARE;
+
+  f32x4 a_reg[A_P], b_reg[B_P];
+  auto load_tile = [&](int it) {   // it = global K-tile index -> (tap, kc)
+    const int t = it / p.kc_tiles, kc = it - t * p.kc_tiles;
+    const int tj = t / tg.nkw, ti = t - tj * tg.nkw;
+    const int kh = tg.kh0 + tg.step * tj, kw = tg.kw0 + tg.step * ti;
+    const int c = kc * BK + c4;
+    const bool c_ok = c < p.Cin;
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) a_reg[i] = buf_load4(xr, a_offset<TR>(p, rows[i], kh, kw, c, c_ok));
+    const unsigned tap_off = (unsigned)((kh * p.ks + kw) * p.Cin + c);
+#pragma unroll
+    for (int i = 0; i < B_P; ++i) b_reg[i] = buf_load4(wr, (b_ok[i] && c_ok) ? (b_row_off[i] + tap_off) * 4u : kOOB);
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) {
+      const f32x4 v = sq ? a_reg[i] * a_reg[i] : a_reg[i];
+      *reinterpret_cast<f32x4*>(As + ((lane + i * 64) >> 3) * LD + c4) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_P; ++i) *reinterpret_cast<f32x4*>(Bs + ((lane + i * 64) >> 3) * LD + c4) = b_reg[i];
+  };
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int total = tg.nkh * tg.nkw * p.kc_tiles;
+  const int frag_col = 4 * (lane >> 5);
+  int it = wave;
+  if (it < total) { load_tile(it); store_tile(); }
+  // the tile is wave-private: LDS writes and reads of one wave are ordered by its own lgkmcnt waits -> no s_barrier here
+  const float* Ab = As + (lane & 31) * LD + frag_col;
+  const float* Bb = Bs + (lane & 31) * LD + frag_col;
+  for (; it < total; it += KW) {
+    const bool more = it + KW < total;
+    if (more) load_tile(it + KW);          // wave-uniform branch; lands while the MFMAs below run
+    f32x4 af[4], bf[4][TN];
+#pragma unroll
+    for (int t8 = 0; t8 < 4; ++t8) {
+      af[t8] = *reinterpret_cast<const f32x4*>(Ab + t8 * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[t8][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LD + t8 * 8);
+    }
+#pragma unroll
+    for (int t8 = 0; t8 < 4; ++t8)
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t8][ss], bf[t8][j][ss], acc[j], 0, 0, 0);
+    if (more) store_tile();                // all fragment reads of this tile were issued above (in-order LDS)
+  }
+
+  // fixed-order combine ((w0 + w1) + (w2 + w3)) through LDS, then every wave finishes a quarter of the rows
+  __syncthreads();
+  float* red = smem;   // [KW][TN][16][64] floats  (<= 32 KB, inside the tiles' footprint)
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((wave * TN + j) * 16 + r) * 64 + lane] = acc[j][r];
+  __syncthreads();
+  for (int e = tid; e < BM * BN; e += 256) {
+    const int row = e / BN, cc = e - row * BN;          // row = (r&3) + 8*(r>>2) + 4*h ; cc = j*32 + (lane&31)
+    const int j = cc >> 5, r = (row & 3) + 4 * (row >> 3), ln = (cc & 31) + 32 * ((row >> 2) & 1);
+    const float s01 = red[((0 * TN + j) * 16 + r) * 64 + ln] + red[((1 * TN + j) * 16 + r) * 64 + ln];
+    const float s23 = red[((2 * TN + j) * 16 + r) * 64 + ln] + red[((3 * TN + j) * 16 + r) * 64 + ln];
+    const int m = m0 + row, co = n0 + cc;
+    if (m < p.M && co < p.Cout) epilogue_store(p, s01 + s23, p.bias ? p.bias[co] : 0.f, m, co, DH, DW, ph, pw);
+  }
+}
+
+template <int BM, int BN, int WM, int WN, bool TR>
+int launch_t(const ConvParams& p, int classes, hipStream_t st) {
   dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, classes);
   const size_t lds = (size_t)2 * (BM + BN) * LD * sizeof(float);
+  static_assert(BM * (BN + 4) <= 2 * (BM + BN) * LD, "C tile must fit in the operand tiles' LDS");
   static bool attr_set = false;  // >64 KiB of dynamic LDS needs an explicit opt-in (first call happens before any graph capture)
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(64 * WM * WN), lds, st, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, TR>), grid, dim3(64 * WM * WN), lds, st, p);
   CLC_LAUNCH_CHECK();
   return BM * 1000 + BN;  // kernel-variant id (>= 0): lets callers attribute time per template instantiation
+}
+template <int BM, int BN, int WM, int WN>
+int launch(const ConvParams& p, int classes, hipStream_t st) {
+  return p.transposed ? launch_t<BM, BN, WM, WN, true>(p, classes, st) : launch_t<BM, BN, WM, WN, false>(p, classes, st);
+}
+
+template <int BN, bool TR>
+int launch_splitk_t(const ConvParams& p, int classes, hipStream_t st) {
+  dim3 grid((p.M + 31) / 32, (p.Cout + BN - 1) / BN, classes);
+  const size_t lds = (size_t)4 * (32 + BN) * LD * sizeof(float);
+  static_assert(4 * (BN / 32) * 16 * 64 <= 4 * (32 + BN) * LD, "combine buffer must fit");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_splitk_kernel<BN, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_splitk_kernel<BN, TR>), grid, dim3(256), lds, st, p);
+  CLC_LAUNCH_CHECK();
+  return 32 * 1000 + BN + 500;  // 32x<BN> split-K family
+}
+template <int BN>
+int launch_splitk(const ConvParams& p, int classes, hipStream_t st) {
+  return p.transposed ? launch_splitk_t<BN, true>(p, classes, st) : launch_splitk_t<BN, false>(p, classes, st);
 }
 
 // small-Cin (image, Cin<=4, unaligned) direct convolution: one thread per (pixel, 4 output channels)
@@ -265,22 +434,7 @@ __global__ void conv_direct_small_kernel(const ConvParams p) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int co = cg * 4 + q;
-    if (co >= p.Cout) continue;
-    float v = acc[q] + (p.bias ? p.bias[co] : 0.f);
-    size_t pix = (size_t)m; int ch = co;
-    if (p.shuffle) {
-      ch = co >> 2;
-      pix = (size_t)(n * 2 * p.OH + 2 * oy + ((co >> 1) & 1)) * (2 * p.OW) + 2 * ox + (co & 1);
-    }
-    if (p.res && p.res_first) v += p.res_scale * p.res[pix * p.ldr + ch];
-    if (p.y_pre) p.y_pre[pix * p.ldp + ch] = v;
-    if (p.norm != CLC_NORM_NONE) {
-      const float mv = p.mul[pix * p.ldm + ch];
-      v = (p.norm == CLC_NORM_GDN) ? mv * rsqrtf(v) : mv * sqrtf(v);
-    }
-    v = apply_act(v, p.act);
-    if (p.res && !p.res_first) v += p.res_scale * p.res[pix * p.ldr + ch];
-    p.y[pix * p.ldy + ch] = v;
+    if (co < p.Cout) epilogue_store(p, acc[q], p.bias ? p.bias[co] : 0.f, m, co, p.OH, p.OW, 0, 0);
   }
 }
 
@@ -323,7 +477,10 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   CLC_CHECK(d->norm == CLC_NORM_NONE || d->mul, "clc_conv2d: norm without mul");
   const int och = d->shuffle ? d->Cout / 4 : d->Cout;
   CLC_CHECK(d->ldy >= och, "clc_conv2d: ldy < channels");
-  CLC_CHECK((long)d->N * d->H * d->W < (1l << 31) / 1 && (long)d->N * d->OH * d->OW * (d->shuffle ? 4 : 1) < (1l << 31), "clc_conv2d: too many pixels");
+  const size_t x_bytes = ((size_t)d->N * d->H * d->W - 1) * d->ldx * 4 + (size_t)d->Cin * 4;
+  const size_t w_bytes = (size_t)d->Cout * d->ks * d->ks * d->Cin * 4;
+  CLC_CHECK(x_bytes < (1ull << 31) && w_bytes < (1ull << 31), "clc_conv2d: tensor larger than 2 GiB");
+  CLC_CHECK((size_t)d->N * d->OH * d->OW * (d->shuffle ? 4 : 1) < (1ull << 31), "clc_conv2d: too many pixels");
 
   ConvParams p;
   p.x = d->x; p.w = d->w; p.bias = d->bias; p.y = d->y; p.mul = d->mul; p.res = d->res; p.y_pre = d->y_pre;
@@ -333,6 +490,7 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   p.act = d->act; p.norm = d->norm; p.shuffle = d->shuffle; p.res_first = d->res_first;
   p.ldm = d->ldm; p.ldr = d->ldr; p.ldp = d->ldp; p.ldw = d->ks * d->ks * d->Cin; p.res_scale = d->res_scale;
   p.kc_tiles = (d->Cin + BK - 1) / BK;
+  p.x_bytes = (unsigned)x_bytes; p.w_bytes = (unsigned)w_bytes;
   int classes = 1;
   p.M = d->N * d->OH * d->OW;
   if (d->transposed && d->stride == 2) { classes = 4; p.M = d->N * (d->OH / 2) * (d->OW / 2); }
@@ -346,17 +504,21 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
     CLC_LAUNCH_CHECK();
     return 1;  // variant id of the direct small-Cin kernel
   }
-  // tile selection: depends on (M, Cout) only for speed; numerics are tile-independent (see header)
-  const long M = p.M;
+  // Family / tile selection from the PER-IMAGE map and the channel counts only (never the batch size), so an image's
+  // summation order — hence its bits — is the same in any batch.
+  const int img_pix = (d->transposed && d->stride == 2) ? (d->OH / 2) * (d->OW / 2) : d->OH * d->OW;
   const int C = d->Cout;
-  auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((C + bn - 1) / bn) * classes; };
-  const bool n128 = (C % 128 == 0) || C >= 384;
-  const bool n64 = (C % 64 == 0) || C > 64;
-  if (n128 && blocks(128, 128) >= 384) return launch<128, 128, 2, 2>(p, classes, st);
-  if (n64 && blocks(128, 64) >= 384) return launch<128, 64, 2, 2>(p, classes, st);
-  if (n64 && blocks(64, 64) >= 256) return launch<64, 64, 2, 2>(p, classes, st);
-  if (blocks(64, 32) >= 256 || M >= 4096) return launch<64, 32, 2, 1>(p, classes, st);
-  return launch<32, 32, 1, 1>(p, classes, st);
+  if (img_pix <= 256) {
+    if (C > 32) return launch_splitk<64>(p, classes, st);
+    return launch_splitk<32>(p, classes, st);
+  }
+  if (img_pix <= 1024) {
+    if (C >= 64) return launch<64, 64, 2, 2>(p, classes, st);
+    return launch<64, 32, 2, 1>(p, classes, st);
+  }
+  if (C % 128 == 0 || C >= 384) return launch<128, 128, 2, 2>(p, classes, st);
+  if (C > 32) return launch<128, 64, 2, 2>(p, classes, st);
+  return launch<64, 32, 2, 1>(p, classes, st);
 }
 
 extern "C" int clc_filter_transpose(const float* w, float* wt, int Cout, int T, int Cin, clc_stream_t stream) {

@@ -17,8 +17,15 @@ namespace {
 
 constexpr int BK = 32;
 
+constexpr unsigned kOOB = 0x80000000u;  // >= num_records of every SRD -> buffer load returns 0 (no branch around loads)
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0));
+}
+
 struct WgradParams {
   const float* x; const float* dy; float* partial; float* bias_partial;
+  unsigned x_bytes, dy_bytes;
   int N, H, W, Cin, ldx;
   int OH, OW, Cout, lddy;
   int ks, stride, pad, in_op;
@@ -53,32 +60,28 @@ void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
   for (int i = 0; i < A_P; ++i) bias_acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
+  const bool sq = p.in_op == CLC_IN_SQUARE;
   auto load_tile = [&](int kt) {
     const int kbase = k_begin + kt * BK;
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
       const int piece = tid + i * NT, row = piece / AQ, q = piece - row * AQ;
       const int pix = kbase + row, co = co0 + q * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < BK && pix < k_end && co < p.Cout) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)pix * p.lddy + co);
-      a_reg[i] = v;
-      if (do_bias) bias_acc[i] += v;
+      const bool ok = row < BK && pix < k_end && co < p.Cout;
+      a_reg[i] = buf_load4(dr, ok ? ((unsigned)pix * (unsigned)p.lddy + (unsigned)co) * 4u : kOOB);
     }
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
       const int piece = tid + i * NT, row = piece / BQ, q = piece - row * BQ;
       const int pix = kbase + row, ci = ci0 + q * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < BK && pix < k_end && ci < p.Cin) {
-        const int n = pix / (p.OH * p.OW), r = pix - n * (p.OH * p.OW);
-        const int oy = r / p.OW, ox = r - oy * p.OW;
-        const int iy = oy * p.stride - p.pad + kh, ix = ox * p.stride - p.pad + kw;
-        if (iy >= 0 && ix >= 0 && iy < p.H && ix < p.W) {
-          v = *reinterpret_cast<const f32x4*>(p.x + (size_t)((n * p.H + iy) * p.W + ix) * p.ldx + ci);
-          if (p.in_op == CLC_IN_SQUARE) v = v * v;
-        }
-      }
-      b_reg[i] = v;
+      const int pp = pix < k_end ? pix : k_begin;
+      const int n = pp / (p.OH * p.OW), r = pp - n * (p.OH * p.OW);
+      const int oy = r / p.OW, ox = r - oy * p.OW;
+      const int iy = oy * p.stride - p.pad + kh, ix = ox * p.stride - p.pad + kw;
+      const bool ok = row < BK && pix < k_end && ci < p.Cin && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      b_reg[i] = buf_load4(xr, ok ? ((unsigned)((n * p.H + iy) * p.W + ix) * (unsigned)p.ldx + (unsigned)ci) * 4u : kOOB);
     }
   };
   auto store_tile = [&](int buf) {
@@ -86,11 +89,12 @@ void conv_wgrad_kernel(const WgradParams p) {
     for (int i = 0; i < A_P; ++i) {
       const int piece = tid + i * NT, row = piece / AQ, q = piece - row * AQ;
       if (row < BK) *reinterpret_cast<f32x4*>(As + (buf * BK + row) * BM + q * 4) = a_reg[i];
+      if (do_bias) bias_acc[i] += a_reg[i];
     }
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
       const int piece = tid + i * NT, row = piece / BQ, q = piece - row * BQ;
-      if (row < BK) *reinterpret_cast<f32x4*>(Bs + (buf * BK + row) * BN + q * 4) = b_reg[i];
+      if (row < BK) *reinterpret_cast<f32x4*>(Bs + (buf * BK + row) * BN + q * 4) = sq ? b_reg[i] * b_reg[i] : b_reg[i];
     }
   };
 
@@ -262,6 +266,12 @@ extern "C" int clc_conv2d_wgrad(const clc_wgrad_desc* d, clc_stream_t stream) {
   p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout; p.lddy = d->lddy;
   p.ks = d->ks; p.stride = d->stride; p.pad = d->pad; p.in_op = d->in_op;
   p.K = d->N * d->OH * d->OW; p.k_per_split = pl.k_per_split; p.nci = pl.nci;
+  {
+    const size_t xb = ((size_t)d->N * d->H * d->W - 1) * d->ldx * 4 + (size_t)d->Cin * 4;
+    const size_t db = ((size_t)d->N * d->OH * d->OW - 1) * d->lddy * 4 + (size_t)d->Cout * 4;
+    CLC_CHECK(xb < (1ull << 31) && db < (1ull << 31), "clc_conv2d_wgrad: tensor larger than 2 GiB");
+    p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)db;
+  }
   if (pl.small) {
     CLC_CHECK(T * d->Cin <= 256, "clc_conv2d_wgrad: small path needs ks*ks*Cin <= 256");
     hipLaunchKernelGGL(wgrad_small_kernel, dim3(d->Cout, pl.splits), dim3(((T * d->Cin + 63) / 64) * 64), 0, st, p, pl.splits);
