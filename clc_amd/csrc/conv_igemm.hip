@@ -455,7 +455,41 @@ __global__ void filter_transpose_kernel(const float* __restrict__ w, float* __re
   }
 }
 
+// Batched form: one launch transposes every filter of the model (table resident on the device).
+// Workgroup b looks up its entry by binary search over the per-entry first-tile index.
+__global__ void filter_transpose_batched_kernel(const clc_transpose_entry* __restrict__ table, int n_entries) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = n_entries - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].tile_begin <= b) lo = mid; else hi = mid - 1;
+  }
+  const clc_transpose_entry e = table[lo];
+  const int nci = (e.Cin + 31) / 32, nco = (e.Cout + 31) / 32;
+  int local = b - e.tile_begin;
+  const int t = local / (nci * nco); local -= t * nci * nco;
+  const int co0 = (local / nci) * 32, ci0 = (local % nci) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    tile[r][tx] = (co < e.Cout && ci < e.Cin) ? e.w[((size_t)co * e.T + t) * e.Cin + ci] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < e.Cin && co < e.Cout) e.wt[((size_t)ci * e.T + t) * e.Cout + co] = tile[tx][r];
+  }
+}
+
 }  // namespace
+
+extern "C" int clc_filter_transpose_batched(const clc_transpose_entry* table_dev, int n_entries, int total_tiles, clc_stream_t stream) {
+  CLC_CHECK(table_dev && n_entries > 0 && total_tiles > 0, "clc_filter_transpose_batched: bad args");
+  hipLaunchKernelGGL(filter_transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, table_dev, n_entries);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;

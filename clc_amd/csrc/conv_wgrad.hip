@@ -177,30 +177,55 @@ __global__ void slab_reduce_kernel(const float* __restrict__ partial, float* __r
   out[i] = s;
 }
 
-// small / unaligned Cin (the RGB input conv): plain VALU, one workgroup per (co, split)
-__global__ void wgrad_small_kernel(const WgradParams p, int splits) {
-  // thread t handles column j = t (tap, ci) if j < T*Cin ; loops over the split's pixels
-  const int co = blockIdx.x, split = blockIdx.y;
+// small / unaligned Cin (the RGB input convs, T*Cin <= 32 columns): VALU kernel, LDS-tiled.
+// One workgroup per (pixel range = split, tile of 128 output channels): per chunk of 32 pixels the dy rows and the
+// gathered input patches are staged in LDS; thread (co, half) owns 16 of the <=32 (tap,ci) columns of filter row co.
+__global__ __launch_bounds__(256) void wgrad_small_kernel(const WgradParams p, int splits) {
+  __shared__ float dyS[32][128 + 1];
+  __shared__ float xS[32][32 + 1];
+  const int tid = threadIdx.x, co_l = tid & 127, jh = tid >> 7;
+  const int split = blockIdx.x, co0 = blockIdx.y * 128, co = co0 + co_l;
   const int T = p.ks * p.ks, ncol = T * p.Cin;
-  const int j = threadIdx.x;
   const int k_begin = split * p.k_per_split, k_end = min(p.K, k_begin + p.k_per_split);
-  float acc = 0.f, bsum = 0.f;
-  if (j < ncol) {
-    const int tap = j / p.Cin, ci = j - tap * p.Cin, kh = tap / p.ks, kw = tap - kh * p.ks;
-    for (int pix = k_begin; pix < k_end; ++pix) {
-      const float g = p.dy[(size_t)pix * p.lddy + co];
-      const int n = pix / (p.OH * p.OW), r = pix - n * (p.OH * p.OW);
-      const int oy = r / p.OW, ox = r - oy * p.OW;
-      const int iy = oy * p.stride - p.pad + kh, ix = ox * p.stride - p.pad + kw;
-      if (iy >= 0 && ix >= 0 && iy < p.H && ix < p.W) {
-        float xv = p.x[(size_t)((n * p.H + iy) * p.W + ix) * p.ldx + ci];
-        if (p.in_op == CLC_IN_SQUARE) xv *= xv;
-        acc = fmaf(g, xv, acc);
-      }
-      bsum += g;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  float bsum = 0.f;
+  for (int kb = k_begin; kb < k_end; kb += 32) {
+    __syncthreads();
+    for (int e = tid; e < 32 * 128; e += 256) {
+      const int k = e >> 7, c = e & 127, pix = kb + k;
+      dyS[k][c] = (pix < k_end && co0 + c < p.Cout) ? p.dy[(size_t)pix * p.lddy + co0 + c] : 0.f;
     }
-    p.partial[((size_t)split * p.Cout + co) * ncol + j] = acc;
-    if (j == 0 && p.bias_partial) p.bias_partial[(size_t)split * p.Cout + co] = bsum;
+    for (int e = tid; e < 32 * 32; e += 256) {
+      const int k = e >> 5, j = e & 31, pix = kb + k;
+      float v = 0.f;
+      if (pix < k_end && j < ncol) {
+        const int tap = j / p.Cin, ci = j - tap * p.Cin, kh = tap / p.ks, kw = tap - kh * p.ks;
+        const int n = pix / (p.OH * p.OW), r = pix - n * (p.OH * p.OW);
+        const int oy = r / p.OW, ox = r - oy * p.OW;
+        const int iy = oy * p.stride - p.pad + kh, ix = ox * p.stride - p.pad + kw;
+        if (iy >= 0 && ix >= 0 && iy < p.H && ix < p.W) {
+          v = p.x[(size_t)((n * p.H + iy) * p.W + ix) * p.ldx + ci];
+          if (p.in_op == CLC_IN_SQUARE) v *= v;
+        }
+      }
+      xS[k][j] = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < 32; ++k) {
+      const float g = dyS[k][co_l];
+      bsum += g;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] = fmaf(g, xS[k][jh * 16 + j], acc[j]);
+    }
+  }
+  if (co < p.Cout) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (jh * 16 + j < ncol) p.partial[((size_t)split * p.Cout + co) * ncol + jh * 16 + j] = acc[j];
+    if (jh == 0 && p.bias_partial) p.bias_partial[(size_t)split * p.Cout + co] = bsum;
   }
 }
 
@@ -213,9 +238,9 @@ Plan make_plan(const clc_wgrad_desc* d) {
   pl.small = !((d->Cin % 4 == 0) && (d->ldx % 4 == 0) && (d->Cout % 4 == 0) && (d->lddy % 4 == 0));
   if (pl.small) {
     pl.bm = pl.bn = 0; pl.nci = 1;
-    int splits = (int)((K + 2047) / 2048);
+    int splits = (int)((K + 255) / 256);
     if (splits < 1) splits = 1;
-    if (splits > 256) splits = 256;
+    if (splits > 512) splits = 512;
     long kps = (K + splits - 1) / splits;
     pl.k_per_split = (int)kps; pl.splits = (int)((K + kps - 1) / kps);
     return pl;
@@ -226,7 +251,10 @@ Plan make_plan(const clc_wgrad_desc* d) {
   pl.nci = (d->Cin + pl.bn - 1) / pl.bn;
   const long tiles = (long)((d->Cout + pl.bm - 1) / pl.bm) * pl.nci * T;
   long splits = (768 + tiles - 1) / tiles;          // aim for >= ~3 workgroups per CU
-  const long max_splits = (K + 511) / 512;           // >= 16 K-tiles per split
+  // K-tiles per split: >= 16 when there are plenty of tiles anyway, down to 2 for the tiny layers whose
+  // serial K chain would otherwise be the whole latency (e.g. 128->64 1x1 at 16x16: 2 tiles in total)
+  const long min_k = tiles >= 192 ? 512 : (tiles >= 48 ? 256 : (tiles >= 12 ? 128 : 64));
+  const long max_splits = (K + min_k - 1) / min_k;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   long kps = (K + splits - 1) / splits;
@@ -260,8 +288,9 @@ extern "C" int clc_conv2d_wgrad(const clc_wgrad_desc* d, clc_stream_t stream) {
   const size_t wsz = (size_t)d->Cout * T * d->Cin;
   WgradParams p;
   p.x = d->x; p.dy = d->dy;
-  p.partial = (float*)d->workspace;
-  p.bias_partial = d->dbias ? p.partial + (size_t)pl.splits * wsz : nullptr;
+  const bool direct = (pl.splits == 1) && !d->accumulate;   // one slab: write the result in place, no reduce launch
+  p.partial = direct ? d->dw : (float*)d->workspace;
+  p.bias_partial = d->dbias ? (direct ? d->dbias : (float*)d->workspace + (size_t)pl.splits * wsz) : nullptr;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.ldx = d->ldx;
   p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout; p.lddy = d->lddy;
   p.ks = d->ks; p.stride = d->stride; p.pad = d->pad; p.in_op = d->in_op;
@@ -273,8 +302,8 @@ extern "C" int clc_conv2d_wgrad(const clc_wgrad_desc* d, clc_stream_t stream) {
     p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)db;
   }
   if (pl.small) {
-    CLC_CHECK(T * d->Cin <= 256, "clc_conv2d_wgrad: small path needs ks*ks*Cin <= 256");
-    hipLaunchKernelGGL(wgrad_small_kernel, dim3(d->Cout, pl.splits), dim3(((T * d->Cin + 63) / 64) * 64), 0, st, p, pl.splits);
+    CLC_CHECK(T * d->Cin <= 32, "clc_conv2d_wgrad: small/unaligned path needs ks*ks*Cin <= 32 (got %d)", T * d->Cin);
+    hipLaunchKernelGGL(wgrad_small_kernel, dim3(pl.splits, (d->Cout + 127) / 128), dim3(256), 0, st, p, pl.splits);
     CLC_LAUNCH_CHECK();
   } else {
     CLC_CHECK(aligned16(d->x) && aligned16(d->dy), "clc_conv2d_wgrad: unaligned pointers");
@@ -286,6 +315,7 @@ extern "C" int clc_conv2d_wgrad(const clc_wgrad_desc* d, clc_stream_t stream) {
     else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2>), grid, dim3(256), lds, st, p);
     CLC_LAUNCH_CHECK();
   }
+  if (direct) return pl.small ? 1 : pl.bm * 1000 + pl.bn;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((wsz + 255) / 256)), dim3(256), 0, st, p.partial, d->dw, (long)wsz, pl.splits, d->accumulate);
   CLC_LAUNCH_CHECK();
   if (d->dbias) {

@@ -301,7 +301,7 @@ extern "C" int clc_layernorm_fwd(const float* x, int ldx, const float* gamma, co
   return 0;
 }
 
-static int ln_bwd_blocks(long rows) { long b = (rows + 63) / 64; return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }
+static int ln_bwd_blocks(long rows) { long b = (rows + 63) / 64; return (int)(b < 1 ? 1 : (b > 256 ? 256 : b)); }
 
 extern "C" size_t clc_layernorm_bwd_workspace_bytes(long rows, int C) { return (size_t)ln_bwd_blocks(rows) * 2 * C * sizeof(float); }
 

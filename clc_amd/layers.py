@@ -70,6 +70,7 @@ class Conv2d(nn.Conv2d):
             raise ValueError("clc_amd.layers.Conv2d supports 1x1 / 3x3 'same' convolutions with stride 1 or 2")
         super().__init__(in_ch, out_ch, kernel_size, stride=stride, padding=padding, bias=bias)
         self.weight.data = self.weight.data.contiguous(memory_format=CL)
+        self.weight._clc_is_filter = True
 
     def forward(self, x, act=ACT_NONE, res=None, res_scale=1.0, res_first=False, shuffle=False):
         return ops.conv2d(x, self.weight, self.bias, stride=self.stride[0], act=act, res=res, res_scale=res_scale,
@@ -78,6 +79,10 @@ class Conv2d(nn.Conv2d):
 
 class Linear(nn.Linear):
     """nn.Linear over the channel dim of a pixel-major [N,C,H,W] tensor (tokens are pixels)."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.weight._clc_is_filter = True
 
     def forward(self, x, act=ACT_NONE, res=None):
         return ops.linear(x, self.weight, self.bias, act=act, res=res)

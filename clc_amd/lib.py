@@ -39,6 +39,10 @@ class WgradDesc(C.Structure):
                 ("workspace", fp), ("workspace_bytes", C.c_size_t)]
 
 
+class TransposeEntry(C.Structure):
+    _fields_ = [("w", fp), ("wt", fp), ("Cout", C.c_int), ("T", C.c_int), ("Cin", C.c_int), ("tile_begin", C.c_int)]
+
+
 class ParamEntry(C.Structure):
     _fields_ = [("p", fp), ("g", fp), ("m", fp), ("v", fp), ("n", C.c_long)]
 
@@ -54,6 +58,7 @@ SIGNATURES = {
     "clc_conv2d_wgrad_workspace_bytes": (_sz, [C.POINTER(WgradDesc)]),
     "clc_conv2d_wgrad": (_i, [C.POINTER(WgradDesc), fp]),
     "clc_filter_transpose": (_i, [fp, fp, _i, _i, _i, fp]),
+    "clc_filter_transpose_batched": (_i, [fp, _i, _i, fp]),
     "clc_act_bwd": (_i, [fp, _i, fp, _i, _i, _i, fp, _i, _l, _i, fp]),
     "clc_colsum_workspace_bytes": (_sz, [_l, _i]),
     "clc_colsum": (_i, [fp, _i, _l, _i, fp, _i, fp, _sz, fp]),

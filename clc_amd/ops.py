@@ -140,17 +140,19 @@ def filter_transpose(w, Cout, T, Cin):
     return wt.view(Cin, T * Cout)
 
 
-def wgrad_raw(x, dy, *, ks, stride, pad, Cout, Cin, want_bias, in_op=IN_NONE):
-    """Returns (dw [Cout, ks*ks*Cin] flat kernel layout, dbias or None)."""
+def wgrad_raw(x, dy, *, ks, stride, pad, Cout, Cin, want_bias, in_op=IN_NONE, dw_out=None, db_out=None):
+    """Returns (dw [Cout, ks*ks*Cin] flat kernel layout, dbias or None).  With dw_out / db_out (persistent gradient
+    buffers in kernel layout) the result is ACCUMULATED into them and (None, None) is returned."""
     x, xp, N, H, W, _, ldx = nhwc(x)
     dy, dp, _, OH, OW, _, lddy = nhwc(dy)
-    dw = torch.empty(Cout * ks * ks * Cin, device=x.device, dtype=torch.float32)
-    db = torch.empty(Cout, device=x.device, dtype=torch.float32) if want_bias else None
+    direct = dw_out is not None
+    dw = dw_out if direct else torch.empty(Cout * ks * ks * Cin, device=x.device, dtype=torch.float32)
+    db = db_out if direct else (torch.empty(Cout, device=x.device, dtype=torch.float32) if want_bias else None)
     d = _lib.WgradDesc()
     d.x, d.N, d.H, d.W, d.Cin, d.ldx = xp, N, H, W, Cin, ldx
     d.dy, d.OH, d.OW, d.Cout, d.lddy = dp, OH, OW, Cout, lddy
-    d.dw, d.dbias = dw.data_ptr(), (db.data_ptr() if want_bias else None)
-    d.ks, d.stride, d.pad, d.in_op, d.accumulate = ks, stride, pad, in_op, 0
+    d.dw, d.dbias = dw.data_ptr(), (db.data_ptr() if db is not None else None)
+    d.ks, d.stride, d.pad, d.in_op, d.accumulate = ks, stride, pad, in_op, int(direct)
     nbytes = _L().clc_conv2d_wgrad_workspace_bytes(C.byref(d))
     ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
     d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
@@ -162,7 +164,17 @@ def wgrad_raw(x, dy, *, ks, stride, pad, Cout, Cin, want_bias, in_op=IN_NONE):
         variant = _lib.check(_L().clc_conv2d_wgrad(C.byref(d), _stream()), "clc_conv2d_wgrad")
         e1.record()
         PROFILE.append(("conv_wgrad" if variant != 1 else "wgrad_small", variant, 2.0 * N * OH * OW * ks * ks * Cin * Cout, e0, e1))
-    return dw, db
+    return (None, None) if direct else (dw, db)
+
+
+def _direct_grad(t):
+    """Persistent gradient buffer of a parameter laid out exactly like it (set up by clc_amd.train.FusedAdamW), or None."""
+    if t is None or not getattr(t, "_clc_direct", False):
+        return None
+    g = t.grad
+    if g is None or g.stride() != t.stride() or g.shape != t.shape:
+        return None
+    return g
 
 
 def _dw_to_param_layout(dw_flat, w_param):
@@ -201,6 +213,7 @@ class _ConvFn(Function):
         ctx.cfg = (ks, stride, act, res_scale, shuffle, b is not None, res is not None, res_first)
         saved_act = y_pre if save_pre else (y if act in (ACT_LRELU, ACT_RELU, ACT_HALFTANH) else None)
         ctx.use_pre = save_pre
+        ctx.bias_ref = b
         ctx.save_for_backward(x, w, saved_act)
         return y
 
@@ -220,10 +233,17 @@ class _ConvFn(Function):
         dx = dw = db = None
         pad = ks // 2
         if need_w or need_b:
-            dwf, db = wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=need_b)
-            dw = _dw_to_param_layout(dwf, w) if need_w else None
+            gw, gb = _direct_grad(w), (_direct_grad(ctx.bias_ref) if has_b else None)
+            if gw is not None and (gb is not None or not has_b) and to_kernel_weight(w) is w:
+                # write straight into the persistent gradient arena (accumulate) — no temporary, no autograd add kernel
+                wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb)
+            else:
+                dwf, db = wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=need_b)
+                dw = _dw_to_param_layout(dwf, w) if need_w else None
         if need_x:
-            wt = filter_transpose(to_kernel_weight(w), Cout, ks * ks, Cin)
+            wt = getattr(w, "_clc_wt", None)   # refreshed once per step by the batched transpose (clc_amd.train)
+            if wt is None:
+                wt = filter_transpose(to_kernel_weight(w), Cout, ks * ks, Cin)
             dx = conv_raw(dz, wt.view(Cin, -1), None, ks=ks, stride=stride, pad=pad, transposed=True, out_hw=(x.shape[2], x.shape[3]))
         return dx, dw, db, dres, None, None, None, None, None, None
 
@@ -295,6 +315,7 @@ class _LayerNormFn(Function):
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if need else None
         _lib.check(_L().clc_layernorm_fwd(xp, ldx, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), Cc,
                                           mean.data_ptr() if need else None, rstd.data_ptr() if need else None, rows, Cc, _stream()), "clc_layernorm_fwd")
+        ctx.beta_ref = beta
         ctx.save_for_backward(x, gamma, mean, rstd)
         return y
 
@@ -305,12 +326,14 @@ class _LayerNormFn(Function):
         dy, dyp, *_r, lddy = nhwc(dy)
         rows = N * H * W
         dx = new_act(N, Cc, H, W, x)
-        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+        gg, gb = _direct_grad(gamma), _direct_grad(ctx.beta_ref)
+        direct = gg is not None and gb is not None
+        dg, db = (gg, gb) if direct else (torch.empty_like(gamma), torch.empty_like(gamma))
         nbytes = _L().clc_layernorm_bwd_workspace_bytes(rows, Cc)
         ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
         _lib.check(_L().clc_layernorm_bwd(dyp, lddy, xp, ldx, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), Cc,
-                                          dg.data_ptr(), db.data_ptr(), 0, rows, Cc, ws.data_ptr(), nbytes, _stream()), "clc_layernorm_bwd")
-        return dx, dg, db
+                                          dg.data_ptr(), db.data_ptr(), int(direct), rows, Cc, ws.data_ptr(), nbytes, _stream()), "clc_layernorm_bwd")
+        return (dx, None, None) if direct else (dx, dg, db)
 
 
 def layernorm(x, gamma, beta):
@@ -331,6 +354,7 @@ class _WinAttnFn(Function):
         need = any(ctx.needs_input_grad)
         lse = torch.empty(N * H * W * heads, device=qkv.device, dtype=torch.float32) if need else None
         rb = relbias if relbias.is_contiguous() else relbias.contiguous()
+        ctx.rb_param = relbias if rb is relbias else None
         _lib.check(_L().clc_winattn_fwd(qp, ldq, rb.data_ptr(), out.data_ptr(), Cc, lse.data_ptr() if need else None,
                                         N, H, W, Cc, heads, ws, int(shift), _stream()), "clc_winattn_fwd")
         ctx.cfg = (heads, ws, shift)
@@ -345,12 +369,13 @@ class _WinAttnFn(Function):
         Cc = C3 // 3
         dout, dop, *_r, lddo = nhwc(dout)
         dqkv = new_act(N, C3, H, W, qkv)
-        drb = torch.empty_like(rb)
+        grb = _direct_grad(ctx.rb_param)
+        drb = grb if grb is not None else torch.empty_like(rb)
         nbytes = _L().clc_winattn_bwd_workspace_bytes(N, H, W, heads, ws)
         wsb = torch.empty((nbytes + 3) // 4, device=qkv.device, dtype=torch.float32)
         _lib.check(_L().clc_winattn_bwd(dop, lddo, qp, ldq, rb.data_ptr(), out.data_ptr(), Cc, lse.data_ptr(), dqkv.data_ptr(), C3,
-                                        drb.data_ptr(), 0, N, H, W, Cc, heads, ws, int(shift), wsb.data_ptr(), nbytes, _stream()), "clc_winattn_bwd")
-        return dqkv, drb, None, None, None
+                                        drb.data_ptr(), int(grb is not None), N, H, W, Cc, heads, ws, int(shift), wsb.data_ptr(), nbytes, _stream()), "clc_winattn_bwd")
+        return dqkv, (None if grb is not None else drb), None, None, None
 
 
 def window_attention(qkv, relbias, heads, ws, shift):

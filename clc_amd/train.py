@@ -186,6 +186,7 @@ class FusedAdamW:
                 pv.copy_(p.data)
                 p.data = pv           # parameter now lives in the arena (same shape / strides)
                 p.grad = gv           # persistent gradient view: autograd accumulates in place
+                p._clc_direct = True  # ops' backward kernels may accumulate straight into p.grad (no add kernels)
         n = self.p_arena.numel
         dev = self.p_arena.flat.device
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -226,6 +227,36 @@ class FusedAdamW:
 # ------------------------------------------------------------------------------------ the engine
 
 
+class FilterTransposer:
+    """Keeps [Cin][T][Cout] copies of every conv / linear filter for the data-gradient kernels, refreshed by ONE launch
+    per step (clc_filter_transpose_batched) instead of one small launch per layer inside backward."""
+
+    def __init__(self, params: List[nn.Parameter]):
+        ws = [p for p in params if p.dim() in (2, 4) and getattr(p, "_clc_is_filter", False)]
+        self.n = len(ws)
+        if not ws:
+            return
+        dev = ws[0].device
+        total = sum(p.numel() for p in ws)
+        self.buf = torch.empty(total, dtype=torch.float32, device=dev)
+        entries, off, tiles = [], 0, 0
+        for p in ws:
+            Cout, Cin = p.shape[0], p.shape[1]
+            T = p.shape[2] * p.shape[3] if p.dim() == 4 else 1
+            wt = self.buf[off: off + p.numel()].view(Cin, T * Cout)
+            off += p.numel()
+            p._clc_wt = wt
+            entries.append(_lib.TransposeEntry(p.data_ptr(), wt.data_ptr(), Cout, T, Cin, tiles))
+            tiles += T * ((Cout + 31) // 32) * ((Cin + 31) // 32)
+        self.total_tiles = tiles
+        raw = b"".join(bytes(e) for e in entries)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+
+    def refresh(self):
+        if self.n:
+            _lib.check(_lib.load().clc_filter_transpose_batched(self.table.data_ptr(), self.n, self.total_tiles, ops._stream()), "clc_filter_transpose_batched")
+
+
 class TrainEngine:
     """One data-parallel training step of the reference loop (train_CLC.py:137-183), hipGraph-captured.
 
@@ -234,10 +265,11 @@ class TrainEngine:
     """
 
     def __init__(self, model: nn.Module, lmbda: float, loss_type: str = "mse", lr: float = 1e-4, aux_lr: float = 1e-3,
-                 clip_max_norm: float = 1.0, use_graph: bool = True, with_optimizer: bool = True):
+                 clip_max_norm: float = 1.0, use_graph: bool = True, with_optimizer: bool = True, train_mode: bool = True):
         self.model, self.criterion = model, RateDistortionLoss(lmbda, loss_type)
         self.lr, self.aux_lr, self.clip = lr, aux_lr, clip_max_norm
         self.use_graph, self.with_optimizer = use_graph, with_optimizer
+        self.train_mode = train_mode   # False: deterministic rounding instead of noise (tests)
         self.opt: Optional[FusedAdamW] = None
         self.aux_opt: Optional[FusedAdamW] = None
         self.sync: Optional[GradSync] = None
@@ -247,7 +279,7 @@ class TrainEngine:
 
     # -- discovery: which parameters does this (model, inputs) combination actually train?
     def _discover(self, x, refs):
-        self.model.train()
+        self.model.train(self.train_mode)
         for p in self.model.parameters():
             p.grad = None
         out = self.criterion(self.model(x, refs), x)
@@ -256,12 +288,14 @@ class TrainEngine:
         aux = [p for n, p in self.model.named_parameters() if n.endswith(".quantiles")]
         self.opt = FusedAdamW(live, lr=self.lr, max_norm=self.clip)
         self.aux_opt = FusedAdamW(aux, lr=self.aux_lr, max_norm=0.0)
+        self.transposer = FilterTransposer(live)
         self.sync = GradSync(self.opt.grad_flat)
         self.aux_sync = GradSync(self.aux_opt.grad_flat)
 
     def _fwd_bwd(self, x, refs):
         self.opt.zero_grad()
         self.aux_opt.zero_grad()
+        self.transposer.refresh()
         out = self.criterion(self.model(x, refs), x)
         out["loss"].backward()
         return out

@@ -93,6 +93,10 @@ int clc_conv2d_wgrad(const clc_wgrad_desc* d, clc_stream_t stream);
 
 /* [Cout][T][Cin] -> [Cin][T][Cout]  (T = ks*ks) */
 int clc_filter_transpose(const float* w, float* wt, int Cout, int T, int Cin, clc_stream_t stream);
+/* all filters of a model in ONE launch: device table of entries; tile_begin = running sum of
+ * T*ceil(Cout/32)*ceil(Cin/32) over the preceding entries, total_tiles = the grand total */
+typedef struct { const float* w; float* wt; int Cout, T, Cin, tile_begin; } clc_transpose_entry;
+int clc_filter_transpose_batched(const clc_transpose_entry* table_dev, int n_entries, int total_tiles, clc_stream_t stream);
 
 /* ---- elementwise / normalisation ------------------------------------------------------ */
 /* dz = dy * act'(saved); saved = pre-activation (use_pre=1) or the activation output */
