@@ -23,6 +23,25 @@ from .lib import (ACT_GELU, ACT_HALFTANH, ACT_LRELU, ACT_NONE, ACT_RELU, IN_NONE
 
 CL = torch.channels_last
 
+# Side stream for weight-gradient kernels: in backward the data-gradient chain is the critical path, the filter
+# gradients are only needed by the optimizer, so they run concurrently on WGRAD_STREAM (fork per layer, one join before the
+# optimizer: ops.join_side_streams()).  Tensors the side stream still reads are kept alive in _KEEPALIVE until the join,
+# so the caching allocator cannot hand their memory to main-stream work in the meantime.
+WGRAD_STREAM = None
+_KEEPALIVE = []
+
+
+def enable_wgrad_stream(enable=True):
+    global WGRAD_STREAM
+    WGRAD_STREAM = torch.cuda.Stream() if enable else None
+
+
+def join_side_streams():
+    if WGRAD_STREAM is not None:
+        torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
+    _KEEPALIVE.clear()
+
+
 # when set to a list, every conv / wgrad launch is bracketed by HIP events on the launch stream and recorded as
 # (kernel family, tile-variant id, algorithmic FLOPs, start event, end event) — used by bench.py's roofline leg
 PROFILE = None
@@ -236,7 +255,14 @@ class _ConvFn(Function):
             gw, gb = _direct_grad(w), (_direct_grad(ctx.bias_ref) if has_b else None)
             if gw is not None and (gb is not None or not has_b) and to_kernel_weight(w) is w:
                 # write straight into the persistent gradient arena (accumulate) — no temporary, no autograd add kernel
-                wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb)
+                if WGRAD_STREAM is not None and PROFILE is None:
+                    cur = torch.cuda.current_stream()
+                    WGRAD_STREAM.wait_stream(cur)
+                    _KEEPALIVE.append((x, dz))
+                    with torch.cuda.stream(WGRAD_STREAM):
+                        wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb)
+                else:
+                    wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb)
             else:
                 dwf, db = wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=need_b)
                 dw = _dw_to_param_layout(dwf, w) if need_w else None

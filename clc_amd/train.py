@@ -265,11 +265,12 @@ class TrainEngine:
     """
 
     def __init__(self, model: nn.Module, lmbda: float, loss_type: str = "mse", lr: float = 1e-4, aux_lr: float = 1e-3,
-                 clip_max_norm: float = 1.0, use_graph: bool = True, with_optimizer: bool = True, train_mode: bool = True):
+                 clip_max_norm: float = 1.0, use_graph: bool = True, with_optimizer: bool = True, train_mode: bool = True, side_stream: bool = True):
         self.model, self.criterion = model, RateDistortionLoss(lmbda, loss_type)
         self.lr, self.aux_lr, self.clip = lr, aux_lr, clip_max_norm
         self.use_graph, self.with_optimizer = use_graph, with_optimizer
         self.train_mode = train_mode   # False: deterministic rounding instead of noise (tests)
+        self.side_stream = side_stream # filter gradients on a second stream, concurrent with the data-gradient chain
         self.opt: Optional[FusedAdamW] = None
         self.aux_opt: Optional[FusedAdamW] = None
         self.sync: Optional[GradSync] = None
@@ -286,6 +287,8 @@ class TrainEngine:
         out["loss"].backward()
         live = [p for n, p in self.model.named_parameters() if p.grad is not None and not n.endswith(".quantiles")]
         aux = [p for n, p in self.model.named_parameters() if n.endswith(".quantiles")]
+        if self.side_stream:
+            ops.enable_wgrad_stream(True)
         self.opt = FusedAdamW(live, lr=self.lr, max_norm=self.clip)
         self.aux_opt = FusedAdamW(aux, lr=self.aux_lr, max_norm=0.0)
         self.transposer = FilterTransposer(live)
@@ -298,6 +301,7 @@ class TrainEngine:
         self.transposer.refresh()
         out = self.criterion(self.model(x, refs), x)
         out["loss"].backward()
+        ops.join_side_streams()   # filter gradients computed on the side stream are complete from here on
         return out
 
     def _opt_steps(self, out):

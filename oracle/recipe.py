@@ -45,7 +45,7 @@ def apply_weight_recipe(model: torch.nn.Module, seed: int = 0) -> None:
             w = 3.0 + 4.0 * torch.rand(shape[0], 1, 2, generator=g)
             v = torch.cat([med - w[..., :1], med, med + w[..., 1:]], dim=-1)
         elif leaf.startswith("_matrix"):
-            v = t.clone() + 0.2 * torch.randn(shape, generator=g)
+            v = t.detach().cpu().clone() + 0.2 * torch.randn(shape, generator=g)
         elif leaf.startswith("_bias"):
             v = torch.rand(shape, generator=g) - 0.5
         elif leaf.startswith("_factor"):
