@@ -26,6 +26,7 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
 struct WgradParams {
   const float* x; const float* dy; float* partial; float* bias_partial;
   unsigned x_bytes, dy_bytes;
+  int rmw;          // single-split direct mode with accumulation: slab[i] += acc (one writer per element -> deterministic)
   int N, H, W, Cin, ldx;
   int OH, OW, Cout, lddy;
   int ks, stride, pad, in_op;
@@ -148,7 +149,10 @@ void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
-        if (co < p.Cout) slab[((size_t)co * T + tap) * p.Cin + ci] = acc[i][j][r];
+        if (co < p.Cout) {
+          float* dst = slab + ((size_t)co * T + tap) * p.Cin + ci;
+          *dst = p.rmw ? *dst + acc[i][j][r] : acc[i][j][r];
+        }
       }
   }
 
@@ -164,17 +168,36 @@ void conv_wgrad_kernel(const WgradParams p) {
     for (int c = tid; c < BM; c += NT) {
       float s = 0.f;
       for (int r = 0; r < BK; ++r) s += red[r * BM + c];
-      if (co0 + c < p.Cout) p.bias_partial[(size_t)split * p.Cout + co0 + c] = s;
+      if (co0 + c < p.Cout) {
+        float* dst = p.bias_partial + (size_t)split * p.Cout + co0 + c;
+        *dst = p.rmw ? *dst + s : s;
+      }
     }
   }
 }
 
-__global__ void slab_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, long n, int splits, int accumulate) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = accumulate ? out[i] : 0.f;
-  for (int k = 0; k < splits; ++k) s += partial[(size_t)k * n + i];
-  out[i] = s;
+// out[i] (+)= sum_k partial[k][i], fixed order: 4 interleaved groups (k mod 4) summed ascending, then ((g0+g1)+(g2+g3)).
+// Block = 64 column-threads (float4 each) x 4 groups, so a 128-way split is a chain of 32 loads per thread, 4 in flight.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, long n, int splits, int accumulate) {
+  __shared__ f32x4 sm[4][64];
+  const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long i = ((long)blockIdx.x * 64 + tx) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i < n) {
+    const bool vec = (i + 3 < n) && ((n & 3) == 0);
+    for (int k = g; k < splits; k += 4) {
+      const float* src = partial + (size_t)k * n + i;
+      if (vec) s += *reinterpret_cast<const f32x4*>(src);
+      else for (int e = 0; e < 4; ++e) if (i + e < n) s[e] += src[e];
+    }
+  }
+  sm[g][tx] = s;
+  __syncthreads();
+  if (g == 0 && i < n) {
+    f32x4 t = (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]);
+    for (int e = 0; e < 4; ++e)
+      if (i + e < n) out[i + e] = (accumulate ? out[i + e] : 0.f) + t[e];
+  }
 }
 
 // small / unaligned Cin (the RGB input convs, T*Cin <= 32 columns): VALU kernel, LDS-tiled.
@@ -224,8 +247,14 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const WgradParams p, i
   if (co < p.Cout) {
 #pragma unroll
     for (int j = 0; j < 16; ++j)
-      if (jh * 16 + j < ncol) p.partial[((size_t)split * p.Cout + co) * ncol + jh * 16 + j] = acc[j];
-    if (jh == 0 && p.bias_partial) p.bias_partial[(size_t)split * p.Cout + co] = bsum;
+      if (jh * 16 + j < ncol) {
+        float* dst = p.partial + ((size_t)split * p.Cout + co) * ncol + jh * 16 + j;
+        *dst = p.rmw ? *dst + acc[j] : acc[j];
+      }
+    if (jh == 0 && p.bias_partial) {
+      float* dst = p.bias_partial + (size_t)split * p.Cout + co;
+      *dst = p.rmw ? *dst + bsum : bsum;
+    }
   }
 }
 
@@ -245,18 +274,30 @@ Plan make_plan(const clc_wgrad_desc* d) {
     pl.k_per_split = (int)kps; pl.splits = (int)((K + kps - 1) / kps);
     return pl;
   }
-  pl.bm = (d->Cout >= 128) ? 128 : 64;
-  pl.bn = (d->Cin >= 128 && d->Cin % 128 == 0) ? 128 : 64;
-  if (pl.bm == 128 && pl.bn == 128 && (long)((d->Cout + 127) / 128) * ((d->Cin + 127) / 128) * T < 8 && K < 16384) pl.bn = 64;
+  // Tile and K-split choice by a small cost model (cycles): time = max(longest MFMA chain of one workgroup,
+  // total MFMA work / 256 CUs) + slab traffic of the fixed-order reduce (launch + 2 x splits x |dW| bytes at ~4 TB/s).
+  const int bms[2] = {128, 64}, bns[2] = {128, 64};
+  const long wsz = (long)d->Cout * T * d->Cin;
+  long best_cost = -1, splits = 1;
+  pl.bm = 64; pl.bn = 64;
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      const int bm = bms[a], bn = bns[b];
+      if (bm == 128 && d->Cout < 128) continue;
+      if (bn == 128 && (d->Cin < 128 || d->Cin % 128 != 0)) continue;
+      const long tiles = (long)((d->Cout + bm - 1) / bm) * ((d->Cin + bn - 1) / bn) * T;
+      const long mfma_per_ktile = (long)(bm / 32) * (bn / 32) / 4 * 16 * 64;   // cycles per K-tile per workgroup
+      const long max_sp = K / 64 > 0 ? K / 64 : 1;
+      for (long sp = 1; sp <= 256 && sp <= max_sp; sp *= 2) {
+        const long ktiles = (K / sp + BK - 1) / BK;
+        const long chain = ktiles * mfma_per_ktile + 6000;
+        const long work = tiles * sp * ktiles * mfma_per_ktile / 256;
+        const long slab = sp > 1 ? 12000 + sp * wsz / 200 : 0;
+        const long cost = (chain > work ? chain : work) + slab;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; pl.bm = bm; pl.bn = bn; splits = sp; }
+      }
+    }
   pl.nci = (d->Cin + pl.bn - 1) / pl.bn;
-  const long tiles = (long)((d->Cout + pl.bm - 1) / pl.bm) * pl.nci * T;
-  long splits = (768 + tiles - 1) / tiles;          // aim for >= ~3 workgroups per CU
-  // K-tiles per split: >= 16 when there are plenty of tiles anyway, down to 2 for the tiny layers whose
-  // serial K chain would otherwise be the whole latency (e.g. 128->64 1x1 at 16x16: 2 tiles in total)
-  const long min_k = tiles >= 192 ? 512 : (tiles >= 48 ? 256 : (tiles >= 12 ? 128 : 64));
-  const long max_splits = (K + min_k - 1) / min_k;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
   long kps = (K + splits - 1) / splits;
   kps = (kps + BK - 1) / BK * BK;
   pl.k_per_split = (int)kps;
@@ -288,7 +329,8 @@ extern "C" int clc_conv2d_wgrad(const clc_wgrad_desc* d, clc_stream_t stream) {
   const size_t wsz = (size_t)d->Cout * T * d->Cin;
   WgradParams p;
   p.x = d->x; p.dy = d->dy;
-  const bool direct = (pl.splits == 1) && !d->accumulate;   // one slab: write the result in place, no reduce launch
+  const bool direct = (pl.splits == 1);   // one slab: write / accumulate the result in place, no reduce launch
+  p.rmw = direct && d->accumulate;
   p.partial = direct ? d->dw : (float*)d->workspace;
   p.bias_partial = d->dbias ? (direct ? d->dbias : (float*)d->workspace + (size_t)pl.splits * wsz) : nullptr;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.ldx = d->ldx;

@@ -163,8 +163,9 @@ def test_train_engine_steps(dev):
                     if d > 1e-12:
                         worst = max(worst, (p.grad - ref_grads[n]).abs().max().item() / d)
             assert worst < 1e-5, f"direct-write gradients differ from autograd: {worst}"
-        seq = [eng.step(xd, rd)["loss"].item() for _ in range(6)]
+        seq = [eng.step(xd, rd)["loss"].item() for _ in range(8 if not use_graph else 6)]
         assert all(math.isfinite(v) for v in seq), seq
         losses[use_graph] = seq
-    assert losses[False] == losses[True], (losses[False], losses[True])
-    assert min(losses[True][3:]) < losses[True][0], losses[True]
+    # the graph path runs 2 eager warm-up steps before capturing, so its i-th replay is the eager path's (i+2)-th step
+    assert losses[False][2:8] == losses[True][0:6], (losses[False], losses[True])
+    assert min(losses[False][3:]) < losses[False][0], losses[False]
