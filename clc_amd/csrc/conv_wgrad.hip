@@ -286,7 +286,10 @@ Plan make_plan(const clc_wgrad_desc* d) {
       if (bm == 128 && d->Cout < 128) continue;
       if (bn == 128 && (d->Cin < 128 || d->Cin % 128 != 0)) continue;
       const long tiles = (long)((d->Cout + bm - 1) / bm) * ((d->Cin + bn - 1) / bn) * T;
-      const long mfma_per_ktile = (long)(bm / 32) * (bn / 32) / 4 * 16 * 64;   // cycles per K-tile per workgroup
+      // cycles per K-tile per workgroup, de-rated by the measured efficiency of the tile shape (operand re-use:
+      // 128x128 reaches ~80 TF, 64x64 ~45 TF on large layers)
+      const long eff_pct = (bm == 128 && bn == 128) ? 100 : ((bm == 128 || bn == 128) ? 80 : 55);
+      const long mfma_per_ktile = (long)(bm / 32) * (bn / 32) / 4 * 16 * 64 * 100 / eff_pct;
       const long max_sp = K / 64 > 0 ? K / 64 : 1;
       for (long sp = 1; sp <= 256 && sp <= max_sp; sp *= 2) {
         const long ktiles = (K / sp + BK - 1) / BK;

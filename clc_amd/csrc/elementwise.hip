@@ -19,8 +19,65 @@ inline int grid_for(long n, int per_block) {
 }
 
 // ---------------------------------------------------------------- LayerNorm
-// one wave per row; C <= 64*LN_MAX_PER_LANE
+// C in {64,128,256}: a row is handled by G = C/4 lanes holding one float4 each, so a wave covers 64/G rows per
+// instruction (4 rows at C=64) — 4x the bytes in flight of a lane-per-element layout. Row statistics by xor-shuffles
+// inside the G-lane group.  General C (<= 512) falls back to one wave per row.
 constexpr int LN_MAX_PER_LANE = 8;
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int G>   // G lanes per row, C = 4*G
+__global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ y, int ldy,
+                                                              float* __restrict__ mean, float* __restrict__ rstd, long rows) {
+  constexpr int C = 4 * G, RPB = 256 / G;   // rows per block pass
+  const int sub = threadIdx.x % G, rl = threadIdx.x / G;
+  const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + sub * 4), bt = *reinterpret_cast<const f32x4*>(beta + sub * 4);
+  for (long r = (long)blockIdx.x * RPB + rl; r < rows; r += (long)gridDim.x * RPB) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + sub * 4);
+    const float mu = group_sum<G>((v[0] + v[1]) + (v[2] + v[3])) / (float)C;
+    const f32x4 d = v - mu;
+    const float rs = rsqrtf(group_sum<G>((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) / (float)C + 1e-5f);
+    *reinterpret_cast<f32x4*>(y + r * ldy + sub * 4) = d * rs * gm + bt;
+    if (sub == 0 && mean) { mean[r] = mu; rstd[r] = rs; }
+  }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, float* __restrict__ dx, int lddx,
+                                                              float* __restrict__ ws, long rows) {
+  constexpr int C = 4 * G, RPB = 256 / G;
+  __shared__ f32x4 sm[2][RPB][G];
+  const int sub = threadIdx.x % G, rl = threadIdx.x / G;
+  const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + sub * 4);
+  f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
+  for (long r = (long)blockIdx.x * RPB + rl; r < rows; r += (long)gridDim.x * RPB) {
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dy + r * lddy + sub * 4);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ldx + sub * 4);
+    const float mu = mean[r], rs = rstd[r];
+    const f32x4 xh = (xv - mu) * rs, g = d * gm;
+    dg += d * xh;
+    db += d;
+    const float s1 = group_sum<G>((g[0] + g[1]) + (g[2] + g[3])) / (float)C;
+    const float s2 = group_sum<G>((g[0] * xh[0] + g[1] * xh[1]) + (g[2] * xh[2] + g[3] * xh[3])) / (float)C;
+    *reinterpret_cast<f32x4*>(dx + r * lddx + sub * 4) = rs * (g - s1 - xh * s2);
+  }
+  sm[0][rl][sub] = dg; sm[1][rl][sub] = db;
+  __syncthreads();
+  if (threadIdx.x < 2 * G) {   // fixed-order sum over the block's row lanes
+    const int which = threadIdx.x / G, c = threadIdx.x % G;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < RPB; ++q) t += sm[which][q][c];
+    *reinterpret_cast<f32x4*>(ws + ((size_t)blockIdx.x * 2 + which) * C + c * 4) = t;
+  }
+}
 
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ y, int ldy,
@@ -103,15 +160,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
 }
 
-// out[c] (+)= sum_b ws[b][which][c]
-__global__ void ln_param_reduce_kernel(const float* __restrict__ ws, int nblocks, int C, float* dgamma, float* dbeta, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * C) return;
-  const int which = c / C, cc = c - which * C;
-  float* out = which == 0 ? dgamma : dbeta;
-  float s = accumulate ? out[cc] : 0.f;
-  for (int b = 0; b < nblocks; ++b) s += ws[((size_t)b * 2 + which) * C + cc];
-  out[cc] = s;
+// out[c] (+)= sum_b ws[b][which][c]; 4 interleaved block groups per column, combined ((g0+g1)+(g2+g3)) (fixed order)
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ ws, int nblocks, int C, float* dgamma, float* dbeta, int accumulate) {
+  __shared__ float sm[4][64];
+  const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  float s = 0.f;
+  if (c < 2 * C) {
+    const int which = c / C, cc = c - which * C;
+    for (int b = g; b < nblocks; b += 4) s += ws[((size_t)b * 2 + which) * C + cc];
+  }
+  sm[g][tx] = s;
+  __syncthreads();
+  if (g == 0 && c < 2 * C) {
+    const int which = c / C, cc = c - which * C;
+    float* out = which == 0 ? dgamma : dbeta;
+    out[cc] = (accumulate ? out[cc] : 0.f) + ((sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]));
+  }
 }
 
 // ---------------------------------------------------------------- activation backward
@@ -296,12 +361,16 @@ extern "C" int clc_layernorm_fwd(const float* x, int ldx, const float* gamma, co
   CLC_CHECK(x && gamma && beta && y && rows > 0 && C > 0, "clc_layernorm_fwd: bad args");
   CLC_CHECK(C <= 64 * LN_MAX_PER_LANE, "clc_layernorm_fwd: C=%d too large", C);
   CLC_CHECK((mean == nullptr) == (rstd == nullptr), "clc_layernorm_fwd: mean/rstd must both be given or both NULL");
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, ST, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, C);
+  const bool vec = (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta);
+  if (vec && C == 64) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<16>, dim3(grid_for(rows, 16)), dim3(256), 0, ST, x, ldx, gamma, beta, y, ldy, mean, rstd, rows);
+  else if (vec && C == 128) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<32>, dim3(grid_for(rows, 8)), dim3(256), 0, ST, x, ldx, gamma, beta, y, ldy, mean, rstd, rows);
+  else if (vec && C == 256) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<64>, dim3(grid_for(rows, 4)), dim3(256), 0, ST, x, ldx, gamma, beta, y, ldy, mean, rstd, rows);
+  else hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, ST, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, C);
   CLC_LAUNCH_CHECK();
   return 0;
 }
 
-static int ln_bwd_blocks(long rows) { long b = (rows + 63) / 64; return (int)(b < 1 ? 1 : (b > 256 ? 256 : b)); }
+static int ln_bwd_blocks(long rows) { long b = (rows + 127) / 128; return (int)(b < 1 ? 1 : (b > 512 ? 512 : b)); }
 
 extern "C" size_t clc_layernorm_bwd_workspace_bytes(long rows, int C) { return (size_t)ln_bwd_blocks(rows) * 2 * C * sizeof(float); }
 
@@ -312,10 +381,14 @@ extern "C" int clc_layernorm_bwd(const float* dy, int lddy, const float* x, int 
   CLC_CHECK(C <= 64 * LN_MAX_PER_LANE, "clc_layernorm_bwd: C=%d too large", C);
   CLC_CHECK(ws && ws_bytes >= clc_layernorm_bwd_workspace_bytes(rows, C), "clc_layernorm_bwd: workspace too small");
   const int nb = ln_bwd_blocks(rows);
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), (size_t)8 * C * sizeof(float), ST, dy, lddy, x, ldx, gamma, mean, rstd, dx,
+  const bool vec = (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) && aligned16(ws);
+  if (vec && C == 64) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<16>, dim3(nb), dim3(256), 0, ST, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, (float*)ws, rows);
+  else if (vec && C == 128) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<32>, dim3(nb), dim3(256), 0, ST, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, (float*)ws, rows);
+  else if (vec && C == 256) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<64>, dim3(nb), dim3(256), 0, ST, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, (float*)ws, rows);
+  else hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), (size_t)8 * C * sizeof(float), ST, dy, lddy, x, ldx, gamma, mean, rstd, dx,
                      lddx, (float*)ws, rows, C);
   CLC_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ST, (const float*)ws, nb, C, dgamma, dbeta, accumulate);
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, ST, (const float*)ws, nb, C, dgamma, dbeta, accumulate);
   CLC_LAUNCH_CHECK();
   return 0;
 }

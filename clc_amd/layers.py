@@ -301,6 +301,13 @@ class SWAtten(AttentionBlock):
     def forward(self, x):
         if self.in_conv is not None:
             x = self.in_conv(x)
-        z = self.non_local_block(x)
-        out = ops.gate(self.conv_a(x), self.conv_b(z), x)
+        if ops.BRANCH_STREAMS and ops.PROFILE is None:
+            with ops.fork("swatten_a", [x]) as f:       # conv_a(x) is independent of the Swin -> conv_b branch
+                a = self.conv_a(x)
+            b = self.conv_b(self.non_local_block(x))
+            f.join(a)
+        else:
+            a = self.conv_a(x)
+            b = self.conv_b(self.non_local_block(x))
+        out = ops.gate(a, b, x)
         return self.out_conv(out) if self.out_conv is not None else out

@@ -153,14 +153,26 @@ class _SliceCodec(CompressionModel):
 
     def _slice_params(self, i, latent_means, latent_scales, y_hat_slices, ref_features, y_shape):
         support = y_hat_slices if self.max_support_slices < 0 else y_hat_slices[: self.max_support_slices]
+
+        def scale_branch():
+            ss = self.atten_scale[i](torch.cat([latent_scales] + support, dim=1))
+            if ref_features is not None:
+                return self.ref_cc_scale_transforms[i](torch.cat([ss, ref_features], dim=1))
+            return self.cc_scale_transforms[i](ss)
+
+        branch = ops.BRANCH_STREAMS and ops.PROFILE is None
+        if branch:   # the scale-parameter net is independent of the mean-parameter net: run it on a forked stream
+            with ops.fork("scale", [latent_scales, ref_features] + list(support)) as f:
+                scale = scale_branch()
         mean_support = self.atten_mean[i](torch.cat([latent_means] + support, dim=1))
-        scale_support = self.atten_scale[i](torch.cat([latent_scales] + support, dim=1))
         if ref_features is not None:
             mu = self.ref_cc_mean_transforms[i](torch.cat([mean_support, ref_features], dim=1))
-            scale = self.ref_cc_scale_transforms[i](torch.cat([scale_support, ref_features], dim=1))
         else:
             mu = self.cc_mean_transforms[i](mean_support)
-            scale = self.cc_scale_transforms[i](scale_support)
+        if branch:
+            f.join(scale)
+        else:
+            scale = scale_branch()
         if mu.shape[2] != y_shape[0] or mu.shape[3] != y_shape[1]:
             mu, scale = mu[:, :, : y_shape[0], : y_shape[1]], scale[:, :, : y_shape[0], : y_shape[1]]
         return mean_support, mu, scale

@@ -42,6 +42,49 @@ def join_side_streams():
     _KEEPALIVE.clear()
 
 
+# Branch streams: independent sub-graphs of the latency-bound 16x16 slice loop (mean vs scale parameter nets, the
+# conv_a vs Swin->conv_b branches of SWAtten) run on forked HIP streams and join again, so the ~10 us kernels of different
+# branches overlap on the 256 CUs; under hipGraph capture the fork/join becomes parallel graph branches. Autograd runs
+# each op's backward on the stream of its forward, so the backward overlaps the same way.
+BRANCH_STREAMS = False
+_BRANCH_POOL = {}
+
+
+def enable_branch_streams(enable=True):
+    global BRANCH_STREAMS
+    BRANCH_STREAMS = bool(enable)
+
+
+class fork:
+    """with ops.fork(slot, inputs) as f: out = branch(...);  f.join(out) afterwards on the parent stream."""
+
+    def __init__(self, slot, inputs):
+        self.parent = torch.cuda.current_stream()
+        key = (self.parent.cuda_stream, slot)
+        if key not in _BRANCH_POOL:
+            _BRANCH_POOL[key] = torch.cuda.Stream()
+        self.stream = _BRANCH_POOL[key]
+        self.inputs = [t for t in inputs if t is not None]
+
+    def __enter__(self):
+        self.stream.wait_stream(self.parent)
+        for t in self.inputs:
+            t.record_stream(self.stream)      # produced on the parent, read on the branch
+        self.ctx = torch.cuda.stream(self.stream)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self.ctx.__exit__(*exc)
+        return False
+
+    def join(self, *outputs):
+        self.parent.wait_stream(self.stream)
+        for t in outputs:
+            if t is not None:
+                t.record_stream(self.parent)  # produced on the branch, read on the parent
+
+
 # when set to a list, every conv / wgrad launch is bracketed by HIP events on the launch stream and recorded as
 # (kernel family, tile-variant id, algorithmic FLOPs, start event, end event) — used by bench.py's roofline leg
 PROFILE = None

@@ -289,6 +289,7 @@ class TrainEngine:
         aux = [p for n, p in self.model.named_parameters() if n.endswith(".quantiles")]
         if self.side_stream:
             ops.enable_wgrad_stream(True)
+            ops.enable_branch_streams(True)
         self.opt = FusedAdamW(live, lr=self.lr, max_norm=self.clip)
         self.aux_opt = FusedAdamW(aux, lr=self.aux_lr, max_norm=0.0)
         self.transposer = FilterTransposer(live)
