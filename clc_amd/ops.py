@@ -68,8 +68,10 @@ class fork:
 
     def __enter__(self):
         self.stream.wait_stream(self.parent)
-        for t in self.inputs:
-            t.record_stream(self.stream)      # produced on the parent, read on the branch
+        # tensors crossing streams are kept alive until the end of the step (ops.join_side_streams) instead of
+        # record_stream(): every later use of a branch stream starts with wait_stream(parent), which orders any reuse of
+        # their memory after the consumers — and record_stream's deferred events crash hipGraph capture_end (ROCm 7.2)
+        _KEEPALIVE.append(self.inputs)
         self.ctx = torch.cuda.stream(self.stream)
         self.ctx.__enter__()
         return self
@@ -80,9 +82,7 @@ class fork:
 
     def join(self, *outputs):
         self.parent.wait_stream(self.stream)
-        for t in outputs:
-            if t is not None:
-                t.record_stream(self.parent)  # produced on the branch, read on the parent
+        _KEEPALIVE.append(outputs)
 
 
 # when set to a list, every conv / wgrad launch is bracketed by HIP events on the launch stream and recorded as
