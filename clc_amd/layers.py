@@ -301,7 +301,7 @@ class SWAtten(AttentionBlock):
     def forward(self, x):
         if self.in_conv is not None:
             x = self.in_conv(x)
-        if ops.BRANCH_STREAMS and ops.PROFILE is None:
+        if ops.BRANCH_STREAMS and ops.PROFILE is None and "swatten_a" in ops.BRANCH_SLOTS:
             with ops.fork("swatten_a", [x]) as f:       # conv_a(x) is independent of the Swin -> conv_b branch
                 a = self.conv_a(x)
             b = self.conv_b(self.non_local_block(x))

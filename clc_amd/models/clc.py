@@ -160,7 +160,7 @@ class _SliceCodec(CompressionModel):
                 return self.ref_cc_scale_transforms[i](torch.cat([ss, ref_features], dim=1))
             return self.cc_scale_transforms[i](ss)
 
-        branch = ops.BRANCH_STREAMS and ops.PROFILE is None
+        branch = ops.BRANCH_STREAMS and ops.PROFILE is None and "scale" in ops.BRANCH_SLOTS
         if branch:   # the scale-parameter net is independent of the mean-parameter net: run it on a forked stream
             with ops.fork("scale", [latent_scales, ref_features] + list(support)) as f:
                 scale = scale_branch()

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -47,6 +48,7 @@ def join_side_streams():
 # branches overlap on the 256 CUs; under hipGraph capture the fork/join becomes parallel graph branches. Autograd runs
 # each op's backward on the stream of its forward, so the backward overlaps the same way.
 BRANCH_STREAMS = False
+BRANCH_SLOTS = set(os.environ.get("CLC_BRANCH", "scale,swatten_a").split(","))   # which forks are taken (debug knob)
 _BRANCH_POOL = {}
 
 
