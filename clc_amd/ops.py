@@ -48,7 +48,7 @@ def join_side_streams():
 # branches overlap on the 256 CUs; under hipGraph capture the fork/join becomes parallel graph branches. Autograd runs
 # each op's backward on the stream of its forward, so the backward overlaps the same way.
 BRANCH_STREAMS = False
-BRANCH_SLOTS = set(os.environ.get("CLC_BRANCH", "scale,swatten_a").split(","))   # which forks are taken (debug knob)
+BRANCH_SLOTS = set(os.environ.get("CLC_BRANCH", "scale").split(","))   # which forks are taken (debug knob)
 _BRANCH_POOL = {}
 
 
