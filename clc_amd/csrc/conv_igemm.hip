@@ -23,11 +23,11 @@
 // Two families:
 //   conv_igemm_kernel<BM,BN,WM,WN>   block-cooperative tiles, double-buffered LDS, register
 //                                    prefetch of K-tile k+1 under the MFMAs of tile k, 2 WG/CU.
-//   conv_igemm_splitk_kernel<BN>     small maps (<= 16x16 per image): 4 waves per 32xBN tile,
-//                                    each wave streams every 4th K-tile through its OWN LDS
-//                                    ring (no workgroup barrier in the loop, 4x the loads in
-//                                    flight, 4x shorter dependent chain), fixed-order
-//                                    ((w0+w1)+(w2+w3)) combine through LDS.
+//   conv_igemm_splitk_kernel<BN>     small maps (<= 16x16 per image): 8 waves per 32xBN tile,
+//                                    each wave takes every 8th K-tile and loads its MFMA
+//                                    fragments straight from global memory (no LDS, no barrier
+//                                    in the loop, all its tiles in flight at once), fixed-order
+//                                    tree combine through LDS.
 #include "common.h"
 
 namespace {
@@ -255,18 +255,18 @@ void conv_igemm_kernel(const ConvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Small maps: one 32 x BN output tile per workgroup of 4 waves; wave w owns K-tiles w, w+4, ...
+// Small maps (<= 16x16 per image): latency, not MFMA rate, is what matters (a 64->64 3x3 at 8x16x16 is 0.15 GFLOP).
+// One 32 x BN output tile per workgroup of KW = 8 waves; wave w owns K-tiles w, w+8, ... and loads its MFMA fragments
+// STRAIGHT from global memory into registers in operand layout (lane (i,h) needs 4 consecutive k of its own row i:
+// one buffer_load_dwordx4) — no LDS staging, no barrier and no ds round trip in the loop, all of a wave's K-tiles in
+// flight at once.  Partial tiles are combined through LDS in the fixed order ((w0+w1)+(w2+w3))+((w4+w5)+(w6+w7)).
 template <int BN, bool TR>
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__(512, 1)
 void conv_igemm_splitk_kernel(const ConvParams p) {
-  constexpr int BM = 32, TN = BN / 32, KW = 4;
-  constexpr int A_P = BM * 8 / 64, B_P = BN * 8 / 64;     // float4 pieces per lane per K-tile
-  constexpr int WAVE_LDS = (BM + BN) * LD;               // floats: ONE private tile per wave (LDS ops of a wave are in order,
-                                                         // so the write of tile k+1 cannot overtake the reads of tile k)
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BM = 32, TN = BN / 32, KW = 8, PF = 3;   // PF = K-tiles prefetched per wave
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // combine buffer [KW][TN][16][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* As = smem + wave * WAVE_LDS;      // [BM][LD]
-  float* Bs = As + BM * LD;                // [BN][LD]
+  const int li = lane & 31, h = lane >> 5;
 
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int cls = blockIdx.z, ph = cls >> 1, pw = cls & 1;
@@ -277,41 +277,32 @@ void conv_igemm_splitk_kernel(const ConvParams p) {
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
 
-  RowState rows[A_P];
+  const RowState row = make_row<TR>(p, m0 + li, DH, DW, ph, pw);
+  unsigned b_row_off[TN];
+  bool b_ok[TN];
 #pragma unroll
-  for (int i = 0; i < A_P; ++i) rows[i] = make_row<TR>(p, m0 + ((lane + i * 64) >> 3), DH, DW, ph, pw);
-  unsigned b_row_off[B_P];
-  bool b_ok[B_P];
-#pragma unroll
-  for (int i = 0; i < B_P; ++i) {
-    const int co = n0 + ((lane + i * 64) >> 3);
-    b_ok[i] = co < p.Cout;
-    b_row_off[i] = (unsigned)co * (unsigned)p.ldw;
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + j * 32 + li;
+    b_ok[j] = co < p.Cout;
+    b_row_off[j] = (unsigned)co * (unsigned)p.ldw;
   }
-  const int c4 = (lane & 7) * 4;
   const bool sq = p.in_op == CLC_IN_SQUARE;
+  const int total = tg.nkh * tg.nkw * p.kc_tiles;
 
-  f32x4 a_reg[A_P], b_reg[B_P];
-  auto load_tile = [&](int it) {   // it = global K-tile index -> (tap, kc)
+  f32x4 af[PF][4], bf[PF][TN][4];
+  auto load_tile = [&](int slot, int it) {   // it = global K-tile index -> (tap, kc); fragment t8 covers k = 8*t8 + 4h .. +3
     const int t = it / p.kc_tiles, kc = it - t * p.kc_tiles;
     const int tj = t / tg.nkw, ti = t - tj * tg.nkw;
     const int kh = tg.kh0 + tg.step * tj, kw = tg.kw0 + tg.step * ti;
-    const int c = kc * BK + c4;
-    const bool c_ok = c < p.Cin;
+    const unsigned tap_off = (unsigned)((kh * p.ks + kw) * p.Cin);
 #pragma unroll
-    for (int i = 0; i < A_P; ++i) a_reg[i] = buf_load4(xr, a_offset<TR>(p, rows[i], kh, kw, c, c_ok));
-    const unsigned tap_off = (unsigned)((kh * p.ks + kw) * p.Cin + c);
+    for (int t8 = 0; t8 < 4; ++t8) {
+      const int c = kc * BK + t8 * 8 + 4 * h;
+      const bool c_ok = c < p.Cin;
+      af[slot][t8] = buf_load4(xr, a_offset<TR>(p, row, kh, kw, c, c_ok));
 #pragma unroll
-    for (int i = 0; i < B_P; ++i) b_reg[i] = buf_load4(wr, (b_ok[i] && c_ok) ? (b_row_off[i] + tap_off) * 4u : kOOB);
-  };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int i = 0; i < A_P; ++i) {
-      const f32x4 v = sq ? a_reg[i] * a_reg[i] : a_reg[i];
-      *reinterpret_cast<f32x4*>(As + ((lane + i * 64) >> 3) * LD + c4) = v;
+      for (int j = 0; j < TN; ++j) bf[slot][j][t8] = buf_load4(wr, (b_ok[j] && c_ok) ? (b_row_off[j] + tap_off + (unsigned)c) * 4u : kOOB);
     }
-#pragma unroll
-    for (int i = 0; i < B_P; ++i) *reinterpret_cast<f32x4*>(Bs + ((lane + i * 64) >> 3) * LD + c4) = b_reg[i];
   };
 
   f32x16 acc[TN];
@@ -320,47 +311,45 @@ void conv_igemm_splitk_kernel(const ConvParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  const int total = tg.nkh * tg.nkw * p.kc_tiles;
-  const int frag_col = 4 * (lane >> 5);
+  // all of this wave's first PF tiles go in flight at once; later ones (rare: K > 8*PF tiles) are loaded as slots free up
+#pragma unroll
+  for (int s = 0; s < PF; ++s)
+    if (wave + s * KW < total) load_tile(s, wave + s * KW);
   int it = wave;
-  if (it < total) { load_tile(it); store_tile(); }
-  // the tile is wave-private: LDS writes and reads of one wave are ordered by its own lgkmcnt waits -> no s_barrier here
-  const float* Ab = As + (lane & 31) * LD + frag_col;
-  const float* Bb = Bs + (lane & 31) * LD + frag_col;
-  for (; it < total; it += KW) {
-    const bool more = it + KW < total;
-    if (more) load_tile(it + KW);          // wave-uniform branch; lands while the MFMAs below run
-    f32x4 af[4], bf[4][TN];
+  for (int base = 0; it < total; base += PF) {
 #pragma unroll
-    for (int t8 = 0; t8 < 4; ++t8) {
-      af[t8] = *reinterpret_cast<const f32x4*>(Ab + t8 * 8);
+    for (int s = 0; s < PF; ++s) {
+      if (it < total) {      // wave-uniform
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[t8][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LD + t8 * 8);
+        for (int t8 = 0; t8 < 4; ++t8) {
+          const f32x4 a = sq ? af[s][t8] * af[s][t8] : af[s][t8];
+#pragma unroll
+          for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ss], bf[s][j][t8][ss], acc[j], 0, 0, 0);
+        }
+        if (it + PF * KW < total) load_tile(s, it + PF * KW);
+      }
+      it += KW;
     }
-#pragma unroll
-    for (int t8 = 0; t8 < 4; ++t8)
-#pragma unroll
-      for (int ss = 0; ss < 4; ++ss)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t8][ss], bf[t8][j][ss], acc[j], 0, 0, 0);
-    if (more) store_tile();                // all fragment reads of this tile were issued above (in-order LDS)
   }
 
-  // fixed-order combine ((w0 + w1) + (w2 + w3)) through LDS, then every wave finishes a quarter of the rows
-  __syncthreads();
-  float* red = smem;   // [KW][TN][16][64] floats  (<= 32 KB, inside the tiles' footprint)
+  // fixed-order combine through LDS, then a compact coalesced epilogue over the 32 x BN tile
+  float* red = smem;
 #pragma unroll
   for (int j = 0; j < TN; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[((wave * TN + j) * 16 + r) * 64 + lane] = acc[j][r];
   __syncthreads();
-  for (int e = tid; e < BM * BN; e += 256) {
-    const int row = e / BN, cc = e - row * BN;          // row = (r&3) + 8*(r>>2) + 4*h ; cc = j*32 + (lane&31)
-    const int j = cc >> 5, r = (row & 3) + 4 * (row >> 3), ln = (cc & 31) + 32 * ((row >> 2) & 1);
-    const float s01 = red[((0 * TN + j) * 16 + r) * 64 + ln] + red[((1 * TN + j) * 16 + r) * 64 + ln];
-    const float s23 = red[((2 * TN + j) * 16 + r) * 64 + ln] + red[((3 * TN + j) * 16 + r) * 64 + ln];
-    const int m = m0 + row, co = n0 + cc;
-    if (m < p.M && co < p.Cout) epilogue_store(p, s01 + s23, p.bias ? p.bias[co] : 0.f, m, co, DH, DW, ph, pw);
+  for (int e = tid; e < BM * BN; e += 512) {
+    const int rowi = e / BN, cc = e - rowi * BN;         // rowi = (r&3) + 8*(r>>2) + 4*h ; cc = j*32 + (lane&31)
+    const int j = cc >> 5, r = (rowi & 3) + 4 * (rowi >> 3), ln = (cc & 31) + 32 * ((rowi >> 2) & 1);
+    float q[KW];
+#pragma unroll
+    for (int w = 0; w < KW; ++w) q[w] = red[((w * TN + j) * 16 + r) * 64 + ln];
+    const float v = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+    const int m = m0 + rowi, co = n0 + cc;
+    if (m < p.M && co < p.Cout) epilogue_store(p, v, p.bias ? p.bias[co] : 0.f, m, co, DH, DW, ph, pw);
   }
 }
 
@@ -386,14 +375,13 @@ int launch(const ConvParams& p, int classes, hipStream_t st) {
 template <int BN, bool TR>
 int launch_splitk_t(const ConvParams& p, int classes, hipStream_t st) {
   dim3 grid((p.M + 31) / 32, (p.Cout + BN - 1) / BN, classes);
-  const size_t lds = (size_t)4 * (32 + BN) * LD * sizeof(float);
-  static_assert(4 * (BN / 32) * 16 * 64 <= 4 * (32 + BN) * LD, "combine buffer must fit");
+  const size_t lds = (size_t)8 * (BN / 32) * 16 * 64 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_splitk_kernel<BN, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_splitk_kernel<BN, TR>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((conv_igemm_splitk_kernel<BN, TR>), grid, dim3(512), lds, st, p);
   CLC_LAUNCH_CHECK();
   return 32 * 1000 + BN + 500;  // 32x<BN> split-K family
 }
