@@ -38,9 +38,14 @@ for name, N, Cin, H, W, Cout, ks, s in SHAPES:
     for fn in (fwd, dgrad, wgrad):
         for _ in range(3): fn()
         torch.cuda.synchronize()
+        # capture the launches in a hipGraph so the number is GPU time, not Python/ctypes launch overhead
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_):
+            for _ in range(reps): fn()
+        g_.replay(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(reps): fn()
+        g_.replay()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / reps * 1e3
         res.append(f"{fn.__name__} {us:8.1f} us {flops / us / 1e6:6.1f} TF")
