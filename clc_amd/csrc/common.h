@@ -41,6 +41,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case CLC_ACT_RELU: return v > 0.f ? v : 0.f;
     case CLC_ACT_GELU: return gelu_f(v);
     case CLC_ACT_HALFTANH: return 0.5f * tanhf(v);
+    case CLC_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
     default: return v;
   }
 }

@@ -397,7 +397,7 @@ extern "C" int clc_act_bwd(const float* dy, int lddy, const float* saved, int ld
                            int C, clc_stream_t stream) {
   CLC_CHECK(dy && saved && dz && rows > 0 && C > 0, "clc_act_bwd: bad args");
   CLC_CHECK(!(act == CLC_ACT_GELU && !use_pre), "clc_act_bwd: GELU needs the pre-activation");
-  CLC_CHECK(act >= CLC_ACT_NONE && act <= CLC_ACT_HALFTANH, "clc_act_bwd: unknown activation %d", act);
+  CLC_CHECK(act >= CLC_ACT_NONE && act <= CLC_ACT_HALFTANH, "clc_act_bwd: unsupported activation %d", act);
   hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(rows * C, 1024)), dim3(256), 0, ST, dy, lddy, saved, lds, use_pre, act, dz, lddz, rows, C);
   CLC_LAUNCH_CHECK();
   return 0;

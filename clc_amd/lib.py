@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclc_hip.so")
 
-ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU, ACT_HALFTANH = 0, 1, 2, 3, 4
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU, ACT_HALFTANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 IN_NONE, IN_SQUARE = 0, 1
 NORM_NONE, NORM_GDN, NORM_IGDN = 0, 1, 2
 
@@ -86,6 +86,11 @@ SIGNATURES = {
     "clc_scaled_diff": (_i, [fp, fp, _l, fp, _f, fp, fp]),
     "clc_sum_partials": (_i, [fp, _i, _f, fp, _i, fp]),
     "clc_sqdiff_partials": (_i, [fp, fp, _l, fp, _i, fp]),
+    "clc_clm_sim_colsum_workspace_bytes": (_sz, [_i, _i]),
+    "clc_clm_sim_colsum": (_i, [fp, _i, fp, _i, _i, _i, _i, _f, fp, fp, _sz, fp]),
+    "clc_clm_scale_rows": (_i, [fp, _i, fp, fp, _i, _l, _i, fp]),
+    "clc_clm_deform": (_i, [fp, _i, fp, _i, fp, _i, fp, _i, _i, _i, _i, _i, fp]),
+    "clc_clm_fuse": (_i, [_pp, _pp, _i, _i, _i, fp, _i, fp, _i, _l, _i, _i, fp]),
     "clc_optim_chunk_elems": (_i, []),
     "clc_grad_sqnorm_partials": (_i, [fp, fp, _i, fp, fp]),
     "clc_adamw_step": (_i, [fp, fp, _i, fp, _f, _f, _f, _f, _f, _f, fp, fp]),

@@ -38,7 +38,8 @@ const char* clc_last_error(void);
 int clc_version(void);
 
 /* ---- activation / epilogue codes ---------------------------------------------------- */
-enum { CLC_ACT_NONE = 0, CLC_ACT_LRELU = 1, CLC_ACT_RELU = 2, CLC_ACT_GELU = 3, CLC_ACT_HALFTANH = 4 /* 0.5*tanh(v), LRP head */ };
+enum { CLC_ACT_NONE = 0, CLC_ACT_LRELU = 1, CLC_ACT_RELU = 2, CLC_ACT_GELU = 3, CLC_ACT_HALFTANH = 4 /* 0.5*tanh(v), LRP head */,
+       CLC_ACT_SIGMOID = 5 /* forward only (CLM modulation) */ };
 /* input prologue applied to the gathered activations */
 enum { CLC_IN_NONE = 0, CLC_IN_SQUARE = 1 };
 /* norm modes of the epilogue: out = mul * rsqrt(v) (GDN) or mul * sqrt(v) (inverse GDN) */
@@ -200,6 +201,22 @@ int clc_scaled_diff(const float* a, const float* b, long n, const float* g_dev, 
 int clc_sum_partials(const float* partials, int n, float scale, float* out, int accumulate, clc_stream_t stream);
 /* sum((a-b)^2) partials */
 int clc_sqdiff_partials(const float* a, const float* b, long n, float* partials, int n_partials, clc_stream_t stream);
+
+/* ---- Conditional Latent Matching ops (standalone module /root/reference/models/CLM.py) ---- *
+ * All tensors NHWC fp32. Forward only (the reference module is an orphan that is never trained).
+ * clc_clm_sim_colsum: colsum[b][q] = sum_p softmax_q( yt[b,p,:].yrt[b,q,:] / temperature )   (CLM.py:107-109,14-20)
+ * clc_clm_scale_rows: out[r][c] = w[r] * x[r][c]                                             (CLM.py:16-22)
+ * clc_clm_deform:     9-tap modulated bilinear sampling, zero outside the map               (CLM.py:35-60)
+ * clc_clm_fuse:       out = sum_m softmax_m(att_m[r]) * feat_m[r][c] (* sigmoid(att_m[r]) if gate) + y[r][c]
+ *                                                                                            (CLM.py:118-125, SimpleCLM :166-179) */
+size_t clc_clm_sim_colsum_workspace_bytes(int B, int HW);
+int clc_clm_sim_colsum(const float* yt, int ldy, const float* yrt, int ldr, int B, int HW, int C, float temperature,
+                       float* colsum, void* ws, size_t ws_bytes, clc_stream_t stream);
+int clc_clm_scale_rows(const float* x, int ldx, const float* w, float* out, int ldo, long rows, int C, clc_stream_t stream);
+int clc_clm_deform(const float* x, int ldx, const float* offset, int ldo, const float* modulation, int ldm, float* out,
+                   int ldy, int B, int H, int W, int C, clc_stream_t stream);
+int clc_clm_fuse(const float* const* feats, const float* const* atts, int M, int ldf, int lda, const float* y, int ldy,
+                 float* out, int ldo, long rows, int C, int gate, clc_stream_t stream);
 
 /* ---- optimizer ------------------------------------------------------------------------ *
  * Multi-tensor AdamW + grad-norm clip + nan_to_num (train_CLC.py:164-179) over a flat

@@ -139,12 +139,39 @@ def rans_goldens():
     print("rans kat:", [c["name"] for c in kat["cases"]])
 
 
+def clm_goldens():
+    """Outputs of the genuine /root/reference/models/CLM.py (orphan module, loaded by file path) -> tests/golden/clm.npz."""
+    mod = ref_shim.import_reference_file("models/CLM.py", "ref_clm_file")
+    out = {}
+    g = torch.Generator().manual_seed(42)
+    for name, cls in (("clm", mod.CLM), ("simple", mod.SimpleCLM)):
+        m = cls(64, temperature=0.5).eval()
+        apply_weight_recipe(m, 11)
+        if name == "clm":  # offsets of a few pixels so the bilinear / border logic is exercised
+            with torch.no_grad():
+                m.alignment.offset_conv.weight.mul_(6.0)
+                m.alignment.offset_conv.bias.mul_(20.0)
+        y = torch.randn(2, 64, 16, 16, generator=g)
+        refs = [torch.randn(2, 64, 16, 16, generator=g) for _ in range(3)]
+        with torch.no_grad():
+            o = m(y, refs)
+        out[f"{name}_y"], out[f"{name}_refs"], out[f"{name}_out"] = y.numpy(), torch.stack(refs).numpy(), o.numpy()
+        if name == "clm":
+            with torch.no_grad():
+                yt, rt = m.feature_transform(y), m.feature_transform(refs[0])
+                sim = torch.softmax(torch.bmm(yt.view(2, 64, -1).transpose(1, 2), rt.view(2, 64, -1)) / 0.5, dim=-1)
+                out["clm_colsum0"] = sim.sum(1).numpy()
+    np.savez_compressed(os.path.join(OUT, "clm.npz"), **out)
+    print("clm:", {k: v.shape for k, v in out.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_shim.import_reference_models()
     graph_goldens(ref)
     block_goldens(ref)
     rans_goldens()
+    clm_goldens()
 
 
 if __name__ == "__main__":
