@@ -218,6 +218,22 @@ int clc_clm_deform(const float* x, int ldx, const float* offset, int ldo, const 
 int clc_clm_fuse(const float* const* feats, const float* const* atts, int M, int ldf, int lda, const float* y, int ldy,
                  float* out, int ldo, long rows, int C, int gate, clc_stream_t stream);
 
+/* ---- patch-matching side information (numeric core of /root/reference/models/Patch_Matching.py) ---- *
+ * Planar NCHW fp32 (3-channel images), forward only.
+ * clc_pm_prep:       rgb_transform(reduce_mean_and_std_normalize_images(x * in_scale))             (:913-934)
+ * clc_pm_gauss_mask: create_gaussian_masks(img_h, img_w, ph, pw) -> [P, H-ph+1, W-pw+1]            (:779-807)
+ * clc_pm_pearson:    L2_or_pearson_corr(q [P,C,ph,pw], y [C,H,W]) (* mask) -> [P, H-ph+1, W-pw+1]   (:854-910)
+ * clc_pm_topk:       top-k positions per patch (values, flat indices), ties -> lowest index       (:105, :225)
+ * clc_pm_gather:     SI_Wraper / SI_Finder patch gather + re-tiling; temperature < 0: plain argmax copy (k = 1) */
+int clc_pm_prep(const float* x, float* out, int n_img, int H, int W, float in_scale, clc_stream_t stream);
+int clc_pm_gauss_mask(float* out, int img_h, int img_w, int ph, int pw, clc_stream_t stream);
+size_t clc_pm_pearson_workspace_bytes(int P, int H, int W, int ph, int pw);
+int clc_pm_pearson(const float* q, int P, const float* y, int C, int H, int W, int ph, int pw, const float* mask,
+                   float* out, void* ws, size_t ws_bytes, clc_stream_t stream);
+int clc_pm_topk(const float* corr, int P, int npos, int k, float* val, int32_t* idx, clc_stream_t stream);
+int clc_pm_gather(const float* y, int C, int H, int W, int ph, int pw, const float* val, const int32_t* idx, int k,
+                  float temperature, float* out, clc_stream_t stream);
+
 /* ---- optimizer ------------------------------------------------------------------------ *
  * Multi-tensor AdamW + grad-norm clip + nan_to_num (train_CLC.py:164-179) over a flat
  * table of (param, grad, m, v, numel) entries resident on the device. */

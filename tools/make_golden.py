@@ -165,6 +165,34 @@ def clm_goldens():
     print("clm:", {k: v.shape for k, v in out.items()})
 
 
+def patch_matching_goldens():
+    """Outputs of the genuine numeric functions of models/Patch_Matching.py (AST-extracted: the file cannot be imported),
+    `.cuda()` patched to the identity -> tests/golden/patch_matching.npz."""
+    names = ["L2_or_pearson_corr", "create_gaussian_masks", "SI_Wraper", "SI_Finder_at_Image_Domain", "rgb_transform",
+             "reduce_mean_and_std_normalize_images"]
+    ns = ref_shim.extract_reference_functions("models/Patch_Matching.py", names)
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        ph = pw = 16
+        y_img = synthetic_image(2, 64, 96, 8, smooth=True)
+        y_dec = (y_img + 0.02 * torch.randn(y_img.shape, generator=torch.Generator().manual_seed(1))).clamp(0, 1)
+        x_dec = (torch.roll(y_img, shifts=(5, -7), dims=(2, 3)) + 0.03 * torch.randn(y_img.shape, generator=torch.Generator().manual_seed(2))).clamp(0, 1)
+        mask = ns["create_gaussian_masks"](64, 96, ph, pw)
+        out = {"x_dec": x_dec.numpy(), "y_img": y_img.numpy(), "y_dec": y_dec.numpy(), "mask": mask.numpy()}
+        xp = x_dec[0:1].reshape(1, 3, 4, 16, 6, 16).permute(0, 2, 4, 1, 3, 5).reshape(-1, 3, 16, 16)
+        q = ns["rgb_transform"](ns["reduce_mean_and_std_normalize_images"](xp * 255))
+        r = ns["rgb_transform"](ns["reduce_mean_and_std_normalize_images"](y_dec[0:1] * 255))
+        corr = ns["L2_or_pearson_corr"](q, r, ph, pw)
+        out["q"], out["r"], out["corr"] = q.numpy(), r.numpy(), corr.numpy()
+        out["finder"] = ns["SI_Finder_at_Image_Domain"](x_dec, y_img, ph, pw, y_dec, mask=mask).numpy()
+        out["wraper_k3"] = ns["SI_Wraper"](corr * mask, ph, pw, 24, y_img[0:1], k=3, temperature=15).numpy()
+    finally:
+        torch.Tensor.cuda = orig
+    np.savez_compressed(os.path.join(OUT, "patch_matching.npz"), **out)
+    print("patch matching:", {k: v.shape for k, v in out.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_shim.import_reference_models()
@@ -172,6 +200,7 @@ def main():
     block_goldens(ref)
     rans_goldens()
     clm_goldens()
+    patch_matching_goldens()
 
 
 if __name__ == "__main__":

@@ -76,3 +76,28 @@ def import_reference_file(relpath: str, name: str):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+def extract_reference_functions(relpath: str, names):
+    """AST-extract plain functions from a reference file that cannot be imported as a module
+    (models/Patch_Matching.py: `from turtle import shape`, cv2, compressai_local ...) and exec them with torch/np/F/nn/time
+    in scope.  `.cuda()` is patched to the identity by the caller (see tools/make_golden.py)."""
+    import ast
+    import time
+
+    import numpy as np
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    src = open(os.path.join(REFERENCE_ROOT, relpath)).read()
+    tree = ast.parse(src)
+    ns = {"torch": torch, "np": np, "nn": nn, "F": F, "time": time}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            code = compile(ast.Module(body=[node], type_ignores=[]), relpath, "exec")
+            exec(code, ns)
+    missing = [n for n in names if n not in ns]
+    if missing:
+        raise RuntimeError(f"functions not found in {relpath}: {missing}")
+    return ns
