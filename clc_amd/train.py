@@ -19,6 +19,7 @@ MI355X-first design of the step (not nn.DataParallel, not stock DDP):
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -331,7 +332,8 @@ class TrainEngine:
         refs = list(refs) if refs is not None else None
         if self.opt is None:
             self._discover(x, refs)
-        single = self.sync.world == 1
+        # CLC_FORCE_SPLIT_GRAPHS=1 exercises the multi-GPU structure (graph A | exchange | graph B) on one GPU
+        single = self.sync.world == 1 and os.environ.get("CLC_FORCE_SPLIT_GRAPHS", "0") != "1"
         if not self.use_graph:
             return self._eager_step(x, refs)
         if self.graph is None:
