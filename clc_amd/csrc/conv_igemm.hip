@@ -531,7 +531,9 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   const int img_pix = (d->transposed && d->stride == 2) ? (d->OH / 2) * (d->OW / 2) : d->OH * d->OW;
   const int C = d->Cout;
   if (img_pix <= 256) {
-    if (C > 32) return launch_splitk<64>(p, classes, st);
+    // 32x32 tiles: these layers are bound by how many CUs get MFMA work (f32 MFMA = 64 cycles each), not by operand
+    // re-use, so the smaller tile (2x the workgroups of 32x64) wins on every 16x16 shape measured
+    (void)&launch_splitk<64>;
     return launch_splitk<32>(p, classes, st);
   }
   if (img_pix <= 1024) {
