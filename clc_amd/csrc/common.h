@@ -46,6 +46,26 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
+// d act(v)/dv given the saved tensor s (= v when use_pre, else the activation output)
+__device__ __forceinline__ float act_deriv(float s, int act, int use_pre) {
+  switch (act) {
+    case CLC_ACT_LRELU: return s > 0.f ? 1.f : 0.01f;
+    case CLC_ACT_RELU: return s > 0.f ? 1.f : 0.f;
+    case CLC_ACT_GELU: {
+      const float cdf = 0.5f * (1.0f + erff(s * 0.70710678118654752440f));
+      return cdf + s * 0.39894228040143267794f * expf(-0.5f * s * s);
+    }
+    case CLC_ACT_HALFTANH: {
+      const float t = use_pre ? tanhf(s) : 2.f * s;
+      return 0.5f * (1.f - t * t);
+    }
+    default: return 1.f;
+  }
+}
+__device__ __forceinline__ f32x4 act_deriv4(f32x4 s, int act, int use_pre) {
+  return (f32x4){act_deriv(s[0], act, use_pre), act_deriv(s[1], act, use_pre), act_deriv(s[2], act, use_pre), act_deriv(s[3], act, use_pre)};
+}
+
 // wave64 sum
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -49,6 +49,7 @@ struct ConvParams {
   int M;                       // rows per class (transposed&stride2: per parity class)
   int kc_tiles;                // ceil(Cin/32)
   unsigned x_bytes, w_bytes;
+  const float* xs; int ldxs, xs_act, xs_pre; unsigned xs_bytes;   // fused activation backward on the gathered operand
 };
 
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
@@ -85,6 +86,25 @@ __device__ __forceinline__ RowState make_row(const ConvParams& p, int m, int DH,
   }
   r.base = n * p.H * p.W;
   return r;
+}
+// source pixel index of (row, tap kh/kw), or 0xFFFFFFFF when it falls outside the image / the row is past M
+template <bool TR>
+__device__ __forceinline__ unsigned a_pixel(const ConvParams& p, const RowState& r, int kh, int kw) {
+  int iy, ix;
+  bool ok = r.ok;
+  if (TR) {
+    const int sh = p.stride - 1;                 // parity already guaranteed by the tap grid
+    const int ty = r.y0 - kh, tx = r.x0 - kw;
+    iy = ty >> sh; ix = tx >> sh;
+    ok = ok && ty >= 0 && tx >= 0;
+  } else {
+    iy = r.y0 + kh; ix = r.x0 + kw;
+  }
+  ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+  return ok ? (unsigned)(r.base + iy * p.W + ix) : 0xFFFFFFFFu;
+}
+__device__ __forceinline__ unsigned pix_off(unsigned pix, int ld, int c, bool c_ok) {
+  return (pix != 0xFFFFFFFFu && c_ok) ? (pix * (unsigned)ld + (unsigned)c) * 4u : kOOB;
 }
 // byte offset of (row, tap kh/kw, channel c) in x, or kOOB
 template <bool TR>
@@ -168,12 +188,18 @@ void conv_igemm_kernel(const ConvParams p) {
   const int c4 = (tid & 7) * 4;
   const bool sq = p.in_op == CLC_IN_SQUARE;
 
-  f32x4 a_reg[A_P], b_reg[B_P];
+  const bool fuse_act = p.xs != nullptr;
+  const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fuse_act ? p.xs : p.x), 0, fuse_act ? p.xs_bytes : p.x_bytes, 0x00020000);
+  f32x4 a_reg[A_P], b_reg[B_P], s_reg[A_P];
   auto load_tile = [&](int kh, int kw, int kc) {
     const int c = kc * BK + c4;
     const bool c_ok = c < p.Cin;
 #pragma unroll
-    for (int i = 0; i < A_P; ++i) a_reg[i] = buf_load4(xr, a_offset<TR>(p, rows[i], kh, kw, c, c_ok));
+    for (int i = 0; i < A_P; ++i) {
+      const unsigned pix = a_pixel<TR>(p, rows[i], kh, kw);
+      a_reg[i] = buf_load4(xr, pix_off(pix, p.ldx, c, c_ok));
+      if (fuse_act) s_reg[i] = buf_load4(sr, pix_off(pix, p.ldxs, c, c_ok));    // block-uniform branch
+    }
     const unsigned tap_off = (unsigned)((kh * p.ks + kw) * p.Cin + c);
 #pragma unroll
     for (int i = 0; i < B_P; ++i) b_reg[i] = buf_load4(wr, (b_ok[i] && c_ok) ? (b_row_off[i] + tap_off) * 4u : kOOB);
@@ -181,7 +207,8 @@ void conv_igemm_kernel(const ConvParams p) {
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
-      const f32x4 v = sq ? a_reg[i] * a_reg[i] : a_reg[i];
+      f32x4 v = sq ? a_reg[i] * a_reg[i] : a_reg[i];
+      if (fuse_act) v = v * act_deriv4(s_reg[i], p.xs_act, p.xs_pre);
       *reinterpret_cast<f32x4*>(As + (buf * BM + ((tid + i * NT) >> 3)) * LD + c4) = v;
     }
 #pragma unroll
@@ -289,17 +316,21 @@ void conv_igemm_splitk_kernel(const ConvParams p) {
   const bool sq = p.in_op == CLC_IN_SQUARE;
   const int total = tg.nkh * tg.nkw * p.kc_tiles;
 
-  f32x4 af[PF][4], bf[PF][TN][4];
+  const bool fuse_act = p.xs != nullptr;
+  const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fuse_act ? p.xs : p.x), 0, fuse_act ? p.xs_bytes : p.x_bytes, 0x00020000);
+  f32x4 af[PF][4], sf[PF][4], bf[PF][TN][4];
   auto load_tile = [&](int slot, int it) {   // it = global K-tile index -> (tap, kc); fragment t8 covers k = 8*t8 + 4h .. +3
     const int t = it / p.kc_tiles, kc = it - t * p.kc_tiles;
     const int tj = t / tg.nkw, ti = t - tj * tg.nkw;
     const int kh = tg.kh0 + tg.step * tj, kw = tg.kw0 + tg.step * ti;
     const unsigned tap_off = (unsigned)((kh * p.ks + kw) * p.Cin);
+    const unsigned pix = a_pixel<TR>(p, row, kh, kw);
 #pragma unroll
     for (int t8 = 0; t8 < 4; ++t8) {
       const int c = kc * BK + t8 * 8 + 4 * h;
       const bool c_ok = c < p.Cin;
-      af[slot][t8] = buf_load4(xr, a_offset<TR>(p, row, kh, kw, c, c_ok));
+      af[slot][t8] = buf_load4(xr, pix_off(pix, p.ldx, c, c_ok));
+      if (fuse_act) sf[slot][t8] = buf_load4(sr, pix_off(pix, p.ldxs, c, c_ok));
 #pragma unroll
       for (int j = 0; j < TN; ++j) bf[slot][j][t8] = buf_load4(wr, (b_ok[j] && c_ok) ? (b_row_off[j] + tap_off + (unsigned)c) * 4u : kOOB);
     }
@@ -322,7 +353,8 @@ void conv_igemm_splitk_kernel(const ConvParams p) {
       if (it < total) {      // wave-uniform
 #pragma unroll
         for (int t8 = 0; t8 < 4; ++t8) {
-          const f32x4 a = sq ? af[s][t8] * af[s][t8] : af[s][t8];
+          f32x4 a = sq ? af[s][t8] * af[s][t8] : af[s][t8];
+          if (fuse_act) a = a * act_deriv4(sf[s][t8], p.xs_act, p.xs_pre);
 #pragma unroll
           for (int ss = 0; ss < 4; ++ss)
 #pragma unroll
@@ -513,13 +545,20 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   p.ldm = d->ldm; p.ldr = d->ldr; p.ldp = d->ldp; p.ldw = d->ks * d->ks * d->Cin; p.res_scale = d->res_scale;
   p.kc_tiles = (d->Cin + BK - 1) / BK;
   p.x_bytes = (unsigned)x_bytes; p.w_bytes = (unsigned)w_bytes;
+  p.xs = d->xs; p.ldxs = d->ldxs; p.xs_act = d->xs_act; p.xs_pre = d->xs_pre; p.xs_bytes = 0;
+  if (d->xs) {
+    CLC_CHECK(d->ldxs >= d->Cin && d->ldxs % 4 == 0 && aligned16(d->xs), "clc_conv2d: bad xs (fused activation backward operand)");
+    const size_t sb = ((size_t)d->N * d->H * d->W - 1) * d->ldxs * 4 + (size_t)d->Cin * 4;
+    CLC_CHECK(sb < (1ull << 31), "clc_conv2d: xs larger than 2 GiB");
+    p.xs_bytes = (unsigned)sb;
+  }
   int classes = 1;
   p.M = d->N * d->OH * d->OW;
   if (d->transposed && d->stride == 2) { classes = 4; p.M = d->N * (d->OH / 2) * (d->OW / 2); }
 
   const bool vec_ok = (d->Cin % 4 == 0) && (d->ldx % 4 == 0) && aligned16(d->x) && aligned16(d->w);
   if (!vec_ok) {
-    CLC_CHECK(!d->transposed, "clc_conv2d: unaligned/small-Cin path has no transposed mode (Cin=%d ldx=%d)", d->Cin, d->ldx);
+    CLC_CHECK(!d->transposed && !d->xs, "clc_conv2d: unaligned/small-Cin path has no transposed / fused-activation mode (Cin=%d ldx=%d)", d->Cin, d->ldx);
     const int cgroups = (d->Cout + 3) / 4;
     const long total = (long)p.M * cgroups;
     hipLaunchKernelGGL(conv_direct_small_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
@@ -533,7 +572,9 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   if (img_pix <= 256) {
     // 32x32 tiles: these layers are bound by how many CUs get MFMA work (f32 MFMA = 64 cycles each), not by operand
     // re-use, so the smaller tile (2x the workgroups of 32x64) wins on every 16x16 shape measured
-    (void)&launch_splitk<64>;
+    // ... except the slice-parameter nets with multi-MB filters (448..704 -> 224), where halving the number of N tiles
+    // halves the filter re-reads that dominate them
+    if ((size_t)d->Cout * d->ks * d->ks * d->Cin > 200000 && C > 32) return launch_splitk<64>(p, classes, st);
     return launch_splitk<32>(p, classes, st);
   }
   if (img_pix <= 1024) {

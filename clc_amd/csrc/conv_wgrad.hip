@@ -26,6 +26,7 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
 struct WgradParams {
   const float* x; const float* dy; float* partial; float* bias_partial;
   unsigned x_bytes, dy_bytes;
+  const float* dys; int lddys, dys_act, dys_pre; unsigned dys_bytes;   // fused activation backward on dy
   int rmw;          // single-split direct mode with accumulation: slab[i] += acc (one writer per element -> deterministic)
   int N, H, W, Cin, ldx;
   int OH, OW, Cout, lddy;
@@ -57,13 +58,15 @@ void conv_wgrad_kernel(const WgradParams p) {
   const int ntiles = (k_end - k_begin + BK - 1) / BK;
   const bool do_bias = (p.bias_partial != nullptr) && (blockIdx.x == 0);
 
-  f32x4 a_reg[A_P], b_reg[B_P], bias_acc[A_P];
+  f32x4 a_reg[A_P], b_reg[B_P], bias_acc[A_P], s_reg[A_P];
 #pragma unroll
   for (int i = 0; i < A_P; ++i) bias_acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
   const bool sq = p.in_op == CLC_IN_SQUARE;
+  const bool fuse_act = p.dys != nullptr;
+  const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fuse_act ? p.dys : p.dy), 0, fuse_act ? p.dys_bytes : p.dy_bytes, 0x00020000);
   auto load_tile = [&](int kt) {
     const int kbase = k_begin + kt * BK;
 #pragma unroll
@@ -72,6 +75,7 @@ void conv_wgrad_kernel(const WgradParams p) {
       const int pix = kbase + row, co = co0 + q * 4;
       const bool ok = row < BK && pix < k_end && co < p.Cout;
       a_reg[i] = buf_load4(dr, ok ? ((unsigned)pix * (unsigned)p.lddy + (unsigned)co) * 4u : kOOB);
+      if (fuse_act) s_reg[i] = buf_load4(sr, ok ? ((unsigned)pix * (unsigned)p.lddys + (unsigned)co) * 4u : kOOB);
     }
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
@@ -89,6 +93,7 @@ void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
       const int piece = tid + i * NT, row = piece / AQ, q = piece - row * AQ;
+      if (fuse_act) a_reg[i] = a_reg[i] * act_deriv4(s_reg[i], p.dys_act, p.dys_pre);
       if (row < BK) *reinterpret_cast<f32x4*>(As + (buf * BK + row) * BM + q * 4) = a_reg[i];
       if (do_bias) bias_acc[i] += a_reg[i];
     }
@@ -218,7 +223,9 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const WgradParams p, i
     __syncthreads();
     for (int e = tid; e < 32 * 128; e += 256) {
       const int k = e >> 7, c = e & 127, pix = kb + k;
-      dyS[k][c] = (pix < k_end && co0 + c < p.Cout) ? p.dy[(size_t)pix * p.lddy + co0 + c] : 0.f;
+      float gv = (pix < k_end && co0 + c < p.Cout) ? p.dy[(size_t)pix * p.lddy + co0 + c] : 0.f;
+      if (p.dys && pix < k_end && co0 + c < p.Cout) gv *= act_deriv(p.dys[(size_t)pix * p.lddys + co0 + c], p.dys_act, p.dys_pre);
+      dyS[k][c] = gv;
     }
     for (int e = tid; e < 32 * 32; e += 256) {
       const int k = e >> 5, j = e & 31, pix = kb + k;
@@ -345,6 +352,13 @@ extern "C" int clc_conv2d_wgrad(const clc_wgrad_desc* d, clc_stream_t stream) {
     const size_t db = ((size_t)d->N * d->OH * d->OW - 1) * d->lddy * 4 + (size_t)d->Cout * 4;
     CLC_CHECK(xb < (1ull << 31) && db < (1ull << 31), "clc_conv2d_wgrad: tensor larger than 2 GiB");
     p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)db;
+    p.dys = d->dys; p.lddys = d->lddys; p.dys_act = d->dys_act; p.dys_pre = d->dys_pre; p.dys_bytes = 0;
+    if (d->dys) {
+      CLC_CHECK(d->lddys >= d->Cout, "clc_conv2d_wgrad: bad dys");
+      const size_t sb = ((size_t)d->N * d->OH * d->OW - 1) * d->lddys * 4 + (size_t)d->Cout * 4;
+      CLC_CHECK(sb < (1ull << 31), "clc_conv2d_wgrad: dys larger than 2 GiB");
+      p.dys_bytes = (unsigned)sb;
+    }
   }
   if (pl.small) {
     CLC_CHECK(T * d->Cin <= 32, "clc_conv2d_wgrad: small/unaligned path needs ks*ks*Cin <= 32 (got %d)", T * d->Cin);

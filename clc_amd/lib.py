@@ -27,7 +27,8 @@ class ConvDesc(C.Structure):
                 ("norm", C.c_int), ("mul", fp), ("ldm", C.c_int),
                 ("res", fp), ("ldr", C.c_int), ("res_scale", C.c_float),
                 ("y_pre", fp), ("ldp", C.c_int),
-                ("shuffle", C.c_int), ("res_first", C.c_int)]
+                ("shuffle", C.c_int), ("res_first", C.c_int),
+                ("xs", fp), ("ldxs", C.c_int), ("xs_act", C.c_int), ("xs_pre", C.c_int)]
 
 
 class WgradDesc(C.Structure):
@@ -36,7 +37,8 @@ class WgradDesc(C.Structure):
                 ("dw", fp), ("dbias", fp),
                 ("ks", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
                 ("in_op", C.c_int), ("accumulate", C.c_int),
-                ("workspace", fp), ("workspace_bytes", C.c_size_t)]
+                ("workspace", fp), ("workspace_bytes", C.c_size_t),
+                ("dys", fp), ("lddys", C.c_int), ("dys_act", C.c_int), ("dys_pre", C.c_int)]
 
 
 class TransposeEntry(C.Structure):

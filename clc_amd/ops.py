@@ -152,7 +152,8 @@ def to_kernel_weight(w: torch.Tensor) -> torch.Tensor:
 
 
 def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_NONE, norm=NORM_NONE, mul=None,
-             res=None, res_scale=1.0, res_first=False, y_pre=None, shuffle=False, transposed=False, out=None, out_hw=None):
+             res=None, res_scale=1.0, res_first=False, y_pre=None, shuffle=False, transposed=False, out=None, out_hw=None,
+             xs=None, xs_act=ACT_NONE, xs_pre=False):
     """One clc_conv2d launch. ``w`` must already be in kernel layout [Cout][ks][ks][Cin]."""
     _require_gpu(x, "conv2d")
     x, xp, N, H, W, Cin, ldx = nhwc(x)
@@ -186,6 +187,10 @@ def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_
         q, qp, *_r, ldp = nhwc(y_pre)
         assert q is y_pre
         d.y_pre, d.ldp = qp, ldp
+    if xs is not None:   # fused activation backward: x <- x * act'(xs)
+        xs_t, xsp, *_r, ldxs = nhwc(xs)
+        d.xs, d.ldxs, d.xs_act, d.xs_pre = xsp, ldxs, xs_act, int(xs_pre)
+        keep.append(xs_t)
     if PROFILE is None:
         _lib.check(_L().clc_conv2d(C.byref(d), _stream()), "clc_conv2d")
     else:
@@ -204,7 +209,8 @@ def filter_transpose(w, Cout, T, Cin):
     return wt.view(Cin, T * Cout)
 
 
-def wgrad_raw(x, dy, *, ks, stride, pad, Cout, Cin, want_bias, in_op=IN_NONE, dw_out=None, db_out=None):
+def wgrad_raw(x, dy, *, ks, stride, pad, Cout, Cin, want_bias, in_op=IN_NONE, dw_out=None, db_out=None, dys=None, dys_act=ACT_NONE,
+              dys_pre=False):
     """Returns (dw [Cout, ks*ks*Cin] flat kernel layout, dbias or None).  With dw_out / db_out (persistent gradient
     buffers in kernel layout) the result is ACCUMULATED into them and (None, None) is returned."""
     x, xp, N, H, W, _, ldx = nhwc(x)
@@ -217,6 +223,9 @@ def wgrad_raw(x, dy, *, ks, stride, pad, Cout, Cin, want_bias, in_op=IN_NONE, dw
     d.dy, d.OH, d.OW, d.Cout, d.lddy = dp, OH, OW, Cout, lddy
     d.dw, d.dbias = dw.data_ptr(), (db.data_ptr() if db is not None else None)
     d.ks, d.stride, d.pad, d.in_op, d.accumulate = ks, stride, pad, in_op, int(direct)
+    if dys is not None:   # fused activation backward: dy <- dy * act'(dys)
+        dys_t, dysp, *_r, lddys = nhwc(dys)
+        d.dys, d.lddys, d.dys_act, d.dys_pre = dysp, lddys, dys_act, int(dys_pre)
     nbytes = _L().clc_conv2d_wgrad_workspace_bytes(C.byref(d))
     ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
     d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
@@ -287,7 +296,12 @@ class _ConvFn(Function):
         x, w, saved_act = ctx.saved_tensors
         Cout, Cin = w.shape[0], w.shape[1]
         need_x, need_w, need_b, need_res = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_b and ctx.needs_input_grad[2], has_res and ctx.needs_input_grad[3]
-        dz = act_bwd(dy, saved_act, ctx.use_pre, act) if act != ACT_NONE else dy
+        # the activation derivative is applied inside the data-/weight-gradient kernels' loaders (no dz tensor, no extra
+        # pass) unless the unshuffle copy or a pre-activation residual needs dz materialised
+        fuse = act != ACT_NONE and not shuffle and not (need_res and res_first)
+        dz = dy if (act == ACT_NONE or fuse) else act_bwd(dy, saved_act, ctx.use_pre, act)
+        fa = dict(xs=saved_act, xs_act=act, xs_pre=ctx.use_pre) if fuse else {}
+        fw = dict(dys=saved_act, dys_act=act, dys_pre=ctx.use_pre) if fuse else {}
         dres = None
         if need_res:
             dsrc = dz if res_first else dy  # residual added before / after the activation
@@ -303,19 +317,19 @@ class _ConvFn(Function):
                 if WGRAD_STREAM is not None and PROFILE is None:
                     cur = torch.cuda.current_stream()
                     WGRAD_STREAM.wait_stream(cur)
-                    _KEEPALIVE.append((x, dz))
+                    _KEEPALIVE.append((x, dz, saved_act))
                     with torch.cuda.stream(WGRAD_STREAM):
-                        wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb)
+                        wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb, **fw)
                 else:
-                    wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb)
+                    wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb, **fw)
             else:
-                dwf, db = wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=need_b)
+                dwf, db = wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=need_b, **fw)
                 dw = _dw_to_param_layout(dwf, w) if need_w else None
         if need_x:
             wt = getattr(w, "_clc_wt", None)   # refreshed once per step by the batched transpose (clc_amd.train)
             if wt is None:
                 wt = filter_transpose(to_kernel_weight(w), Cout, ks * ks, Cin)
-            dx = conv_raw(dz, wt.view(Cin, -1), None, ks=ks, stride=stride, pad=pad, transposed=True, out_hw=(x.shape[2], x.shape[3]))
+            dx = conv_raw(dz, wt.view(Cin, -1), None, ks=ks, stride=stride, pad=pad, transposed=True, out_hw=(x.shape[2], x.shape[3]), **fa)
         return dx, dw, db, dres, None, None, None, None, None, None
 
 

@@ -72,6 +72,9 @@ typedef struct {
   float* y_pre; int ldp;     /* optional pre-activation copy (training) */
   int shuffle;
   int res_first;
+  /* optional fused activation backward on the gathered operand: x <- x * act'(xs) with xs the saved
+   * pre-activation (xs_pre = 1) or activation output of the layer whose gradient x is (same geometry as x) */
+  const float* xs; int ldxs; int xs_act; int xs_pre;
 } clc_conv_desc;
 
 int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream);
@@ -87,6 +90,8 @@ typedef struct {
   int in_op;
   int accumulate;
   void* workspace; size_t workspace_bytes;
+  /* optional fused activation backward on dy: dy <- dy * act'(dys) (same geometry as dy) */
+  const float* dys; int lddys; int dys_act; int dys_pre;
 } clc_wgrad_desc;
 
 size_t clc_conv2d_wgrad_workspace_bytes(const clc_wgrad_desc* d);
