@@ -298,7 +298,8 @@ class _ConvFn(Function):
         need_x, need_w, need_b, need_res = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_b and ctx.needs_input_grad[2], has_res and ctx.needs_input_grad[3]
         # the activation derivative is applied inside the data-/weight-gradient kernels' loaders (no dz tensor, no extra
         # pass) unless the unshuffle copy or a pre-activation residual needs dz materialised
-        fuse = act != ACT_NONE and not shuffle and not (need_res and res_first)
+        # (only for the one-instruction derivatives: fusing GELU's erf/exp into the loaders measured slower)
+        fuse = act in (ACT_LRELU, ACT_RELU) and not shuffle and not (need_res and res_first)
         dz = dy if (act == ACT_NONE or fuse) else act_bwd(dy, saved_act, ctx.use_pre, act)
         fa = dict(xs=saved_act, xs_act=act, xs_pre=ctx.use_pre) if fuse else {}
         fw = dict(dys=saved_act, dys_act=act, dys_pre=ctx.use_pre) if fuse else {}
