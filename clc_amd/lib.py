@@ -99,6 +99,11 @@ SIGNATURES = {
     "clc_pm_pearson": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, fp, fp, fp, _sz, fp]),
     "clc_pm_topk": (_i, [fp, _i, _i, _i, fp, fp, fp]),
     "clc_pm_gather": (_i, [fp, _i, _i, _i, _i, _i, fp, fp, _i, _f, fp, fp]),
+    "clc_ssim_init": (_i, []),
+    "clc_ssim_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "clc_ssim_scale_fwd": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, _f, fp, fp, _sz, fp]),
+    "clc_ssim_scale_bwd": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, _sz, fp]),
+    "clc_avgpool2": (_i, [fp, _i, fp, _i, _i, _i, _i, fp]),
     "clc_optim_chunk_elems": (_i, []),
     "clc_grad_sqnorm_partials": (_i, [fp, fp, _i, fp, fp]),
     "clc_adamw_step": (_i, [fp, fp, _i, fp, _f, _f, _f, _f, _f, _f, fp, fp]),

@@ -694,3 +694,66 @@ class _SqDiffSumFn(Function):
 
 def sqdiff_sum(a, b):
     return _SqDiffSumFn.apply(a, b)
+
+
+# ------------------------------------------------------------------------------------- MS-SSIM
+
+
+class _MsSsimMeansFn(Function):
+    """Per-scale (mean cs, mean ssim) of x vs y over `levels` dyadic scales -> [levels, B*C, 2]; gradient flows to x."""
+
+    @staticmethod
+    def forward(ctx, x, y, levels, data_range):
+        x, y = dense(x), dense(y)
+        B, Cc, H, W = x.shape
+        L = _L()
+        _lib.check(L.clc_ssim_init(), "clc_ssim_init")
+        xs, ys = [x], [y]
+        means = torch.empty((levels, B * Cc, 2), device=x.device, dtype=torch.float32)
+        for s in range(levels):
+            xc, yc = xs[-1], ys[-1]
+            h, w = xc.shape[2], xc.shape[3]
+            nbytes = L.clc_ssim_workspace_bytes(B, h, w, Cc)
+            ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
+            _lib.check(L.clc_ssim_scale_fwd(xc.data_ptr(), Cc, yc.data_ptr(), Cc, B, h, w, Cc, float(data_range), means[s].data_ptr(),
+                                            ws.data_ptr(), nbytes, _stream()), "clc_ssim_scale_fwd")
+            if s + 1 < levels:
+                if h % 2 or w % 2:
+                    raise _lib.ClcError("ms_ssim: image sides must stay even across the scales (e.g. multiples of 16)")
+                xn, yn = new_act(B, Cc, h // 2, w // 2, x), new_act(B, Cc, h // 2, w // 2, x)
+                _lib.check(L.clc_avgpool2(xc.data_ptr(), Cc, xn.data_ptr(), B, h, w, Cc, _stream()), "clc_avgpool2")
+                _lib.check(L.clc_avgpool2(yc.data_ptr(), Cc, yn.data_ptr(), B, h, w, Cc, _stream()), "clc_avgpool2")
+                xs.append(xn)
+                ys.append(yn)
+        ctx.data_range = float(data_range)
+        ctx.save_for_backward(*xs, *ys)
+        return means
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        levels = len(saved) // 2
+        xs, ys = saved[:levels], saved[levels:]
+        g = g.contiguous()
+        L = _L()
+        dnext = None
+        for s in reversed(range(levels)):
+            xc, yc = xs[s], ys[s]
+            B, Cc, h, w = xc.shape
+            nbytes = L.clc_ssim_workspace_bytes(B, h, w, Cc)
+            ws = torch.empty((nbytes + 3) // 4, device=xc.device, dtype=torch.float32)
+            dx = new_act(B, Cc, h, w, xc)
+            _lib.check(L.clc_ssim_scale_bwd(xc.data_ptr(), Cc, yc.data_ptr(), Cc, B, h, w, Cc, ctx.data_range, g[s].data_ptr(),
+                                            dnext.data_ptr() if dnext is not None else None, dx.data_ptr(), Cc, ws.data_ptr(), nbytes, _stream()), "clc_ssim_scale_bwd")
+            dnext = dx
+        return dnext, None, None, None
+
+
+def ms_ssim(x, y, data_range=1.0, weights=(0.0448, 0.2856, 0.3001, 0.2363, 0.1333)):
+    """pytorch_msssim.ms_ssim(X, Y, data_range, size_average=True) — the windowed statistics run in HIP, the final
+    [5, B, C] product of powers is a handful of scalar-sized torch ops."""
+    B, Cc = x.shape[0], x.shape[1]
+    means = _MsSsimMeansFn.apply(x, y, len(weights), float(data_range)).view(len(weights), B, Cc, 2)
+    vals = torch.cat([torch.relu(means[:-1, :, :, 0]), torch.relu(means[-1:, :, :, 1])], dim=0)
+    w = torch.tensor(weights, device=x.device, dtype=torch.float32).view(-1, 1, 1)
+    return torch.prod(vals ** w, dim=0).mean()

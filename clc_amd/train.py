@@ -32,37 +32,9 @@ from . import ops
 # ------------------------------------------------------------------------------------------ loss
 
 
-def ms_ssim(X, Y, data_range=1.0, weights=(0.0448, 0.2856, 0.3001, 0.2363, 0.1333), K=(0.01, 0.03)):
-    """pytorch_msssim.ms_ssim semantics (train_CLC.py:33-34). Plain torch ops for now (depthwise 11-tap Gaussians);
-    only the MS-SSIM configs use it."""
-    import torch.nn.functional as F
-
-    size, sigma = 11, 1.5
-    coords = torch.arange(size, dtype=torch.float32, device=X.device) - size // 2
-    g = torch.exp(-(coords ** 2) / (2 * sigma ** 2))
-    g = g / g.sum()
-    C = X.shape[1]
-
-    def filt(t):
-        t = F.conv2d(t, g.view(1, 1, -1, 1).repeat(C, 1, 1, 1), groups=C)
-        return F.conv2d(t, g.view(1, 1, 1, -1).repeat(C, 1, 1, 1), groups=C)
-
-    C1, C2 = (K[0] * data_range) ** 2, (K[1] * data_range) ** 2
-    mcs = []
-    for i in range(len(weights)):
-        mu1, mu2 = filt(X), filt(Y)
-        s11, s22, s12 = filt(X * X) - mu1 * mu1, filt(Y * Y) - mu2 * mu2, filt(X * Y) - mu1 * mu2
-        cs_map = (2 * s12 + C2) / (s11 + s22 + C2)
-        ssim_map = ((2 * mu1 * mu2 + C1) / (mu1 ** 2 + mu2 ** 2 + C1)) * cs_map
-        if i < len(weights) - 1:
-            mcs.append(torch.relu(cs_map.flatten(2).mean(-1)))
-            pad = [s % 2 for s in X.shape[2:]]
-            X, Y = F.avg_pool2d(X, 2, padding=pad), F.avg_pool2d(Y, 2, padding=pad)
-        else:
-            last = torch.relu(ssim_map.flatten(2).mean(-1))
-    vals = torch.stack(mcs + [last], dim=0)
-    w = torch.tensor(weights, device=X.device, dtype=X.dtype).view(-1, 1, 1)
-    return torch.prod(vals ** w, dim=0).mean()
+def ms_ssim(X, Y, data_range=1.0):
+    """pytorch_msssim.ms_ssim semantics (train_CLC.py:33-34) on the HIP MS-SSIM kernels (clc_ssim_scale_fwd/bwd)."""
+    return ops.ms_ssim(X, Y.float().contiguous(memory_format=ops.CL), data_range=data_range)
 
 
 class RateDistortionLoss(nn.Module):

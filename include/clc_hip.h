@@ -239,6 +239,20 @@ int clc_pm_topk(const float* corr, int P, int npos, int k, float* val, int32_t* 
 int clc_pm_gather(const float* y, int C, int H, int W, int ph, int pw, const float* val, const int32_t* idx, int k,
                   float temperature, float* out, clc_stream_t stream);
 
+/* ---- MS-SSIM distortion (pytorch_msssim.ms_ssim semantics; train_CLC.py:33-34,55-57) ---- *
+ * NHWC fp32. One scale at a time: means[bc][0] = mean(cs map), means[bc][1] = mean(ssim map) over the valid 11x11
+ * Gaussian (sigma 1.5) windows; bwd: dx = d(sum_bc g_means[bc][0]*mean_cs + g_means[bc][1]*mean_ssim)/dx
+ * + 0.25 * dnext upsampled 2x (gradient arriving through the 2x2 average pool from the next coarser scale, or NULL).
+ * clc_ssim_init() uploads the window once (call outside graph capture). */
+int clc_ssim_init(void);
+size_t clc_ssim_workspace_bytes(int B, int H, int W, int C);
+int clc_ssim_scale_fwd(const float* x, int ldx, const float* y, int ldy, int B, int H, int W, int C, float data_range,
+                       float* means, void* ws, size_t ws_bytes, clc_stream_t stream);
+int clc_ssim_scale_bwd(const float* x, int ldx, const float* y, int ldy, int B, int H, int W, int C, float data_range,
+                       const float* g_means, const float* dnext, float* dx, int lddx, void* ws, size_t ws_bytes,
+                       clc_stream_t stream);
+int clc_avgpool2(const float* x, int ldx, float* out, int B, int H, int W, int C, clc_stream_t stream);
+
 /* ---- optimizer ------------------------------------------------------------------------ *
  * Multi-tensor AdamW + grad-norm clip + nan_to_num (train_CLC.py:164-179) over a flat
  * table of (param, grad, m, v, numel) entries resident on the device. */

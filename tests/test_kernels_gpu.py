@@ -339,3 +339,22 @@ def test_quantize_build_indexes_bit_exact(dev):
     assert torch.equal(sym.cpu(), sym_ref), "symbols differ"
     assert torch.equal(idx.cpu(), idx_ref), "indexes differ"
     assert torch.equal(y_hat.cpu(), sym_ref.float() + mu)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 256, 256), (1, 3, 256, 384)])
+def test_ms_ssim_fwd_bwd(dev, shape):
+    """HIP MS-SSIM (5 scales, 11-tap Gaussian) vs the oracle's plain-PyTorch restatement of pytorch_msssim.ms_ssim."""
+    from clc_amd import ops
+    from oracle.loss import ms_ssim as ms_ssim_ref
+    from oracle.recipe import synthetic_image
+
+    B, C, H, W = shape
+    y = synthetic_image(B, H, W, 5, smooth=True)
+    x = (y + 0.05 * _rand(shape, 6)).clamp(0, 1).requires_grad_()
+    ref = ms_ssim_ref(x, y, data_range=1.0)
+    ref.backward()
+    xd = _dev(x.detach(), dev, grad=True)
+    out = ops.ms_ssim(xd, _dev(y, dev), data_range=1.0)
+    assert abs(out.item() - ref.item()) < 2e-5, (out.item(), ref.item())
+    out.backward()
+    _close(xd.grad, x.grad, 2e-3, "ms-ssim dx")
