@@ -27,6 +27,7 @@ struct WgradParams {
   const float* x; const float* dy; float* partial; float* bias_partial;
   unsigned x_bytes, dy_bytes;
   const float* dys; int lddys, dys_act, dys_pre; unsigned dys_bytes;   // fused activation backward on dy
+  int ow_shift, img_shift;   // log2(OW), log2(OH*OW) when both are powers of two (else -1): pixel decode without integer division
   int rmw;          // single-split direct mode with accumulation: slab[i] += acc (one writer per element -> deterministic)
   int N, H, W, Cin, ldx;
   int OH, OW, Cout, lddy;
@@ -82,8 +83,16 @@ void conv_wgrad_kernel(const WgradParams p) {
       const int piece = tid + i * NT, row = piece / BQ, q = piece - row * BQ;
       const int pix = kbase + row, ci = ci0 + q * 4;
       const int pp = pix < k_end ? pix : k_begin;
-      const int n = pp / (p.OH * p.OW), r = pp - n * (p.OH * p.OW);
-      const int oy = r / p.OW, ox = r - oy * p.OW;
+      int n, oy, ox;
+      if (p.ow_shift >= 0) {   // block-uniform: every map of a 2^k-sized image is a power of two
+        n = pp >> p.img_shift;
+        const int r = pp & ((1 << p.img_shift) - 1);
+        oy = r >> p.ow_shift; ox = r & ((1 << p.ow_shift) - 1);
+      } else {
+        n = pp / (p.OH * p.OW);
+        const int r = pp - n * (p.OH * p.OW);
+        oy = r / p.OW; ox = r - oy * p.OW;
+      }
       const int iy = oy * p.stride - p.pad + kh, ix = ox * p.stride - p.pad + kw;
       const bool ok = row < BK && pix < k_end && ci < p.Cin && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       b_reg[i] = buf_load4(xr, ok ? ((unsigned)((n * p.H + iy) * p.W + ix) * (unsigned)p.ldx + (unsigned)ci) * 4u : kOOB);
@@ -352,6 +361,11 @@ extern "C" int clc_conv2d_wgrad(const clc_wgrad_desc* d, clc_stream_t stream) {
     const size_t db = ((size_t)d->N * d->OH * d->OW - 1) * d->lddy * 4 + (size_t)d->Cout * 4;
     CLC_CHECK(xb < (1ull << 31) && db < (1ull << 31), "clc_conv2d_wgrad: tensor larger than 2 GiB");
     p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)db;
+    {
+      auto lg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
+      const int a = lg(d->OW), b = lg(d->OH * d->OW);
+      p.ow_shift = (a >= 0 && b >= 0) ? a : -1; p.img_shift = (a >= 0 && b >= 0) ? b : -1;
+    }
     p.dys = d->dys; p.lddys = d->lddys; p.dys_act = d->dys_act; p.dys_pre = d->dys_pre; p.dys_bytes = 0;
     if (d->dys) {
       CLC_CHECK(d->lddys >= d->Cout, "clc_conv2d_wgrad: bad dys");
