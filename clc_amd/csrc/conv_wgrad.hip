@@ -307,12 +307,14 @@ Plan make_plan(const clc_wgrad_desc* d) {
       const long eff_pct = (bm == 128 && bn == 128) ? 100 : ((bm == 128 || bn == 128) ? 80 : 55);
       const long mfma_per_ktile = (long)(bm / 32) * (bn / 32) / 4 * 16 * 64 * 100 / eff_pct;
       const long max_sp = K / 64 > 0 ? K / 64 : 1;
-      for (long sp = 1; sp <= 256 && sp <= max_sp; sp *= 2) {
+      for (long sp = 1; sp <= 256 && sp <= max_sp; ++sp) {
         const long ktiles = (K / sp + BK - 1) / BK;
         const long chain = ktiles * mfma_per_ktile + 6000;
-        const long work = tiles * sp * ktiles * mfma_per_ktile / 256;
+        // a CU retires one workgroup's MFMA chain per chain-time (two co-resident workgroups share the matrix pipes), so
+        // the kernel takes ceil(workgroups / 256) chains: 288 workgroups cost as much as 512 — pick splits that fill whole rounds
+        const long rounds = (tiles * sp + 255) / 256;
         const long slab = sp > 1 ? 12000 + sp * wsz / 200 : 0;
-        const long cost = (chain > work ? chain : work) + slab;
+        const long cost = rounds * chain + slab;
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; pl.bm = bm; pl.bn = bn; splits = sp; }
       }
     }
