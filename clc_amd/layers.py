@@ -267,7 +267,7 @@ class ConvTransBlock(nn.Module):
 
     def forward(self, x):
         u = self.conv1_1(x)
-        c, t = u[:, : self.conv_dim], u[:, self.conv_dim:]   # channel-slice views, read in place by the kernels
+        c, t = ops.split_channels(u, (self.conv_dim, self.trans_dim))   # strided views, read in place by the kernels
         c = self.conv_block(c, extra_identity=1.0)
         t = self.trans_block(t)
         return self.conv1_2(torch.cat((c, t), dim=1), res=x)

@@ -199,7 +199,7 @@ class _SliceCodec(CompressionModel):
         latent_scales = self.h_scale_s(z_hat)
         latent_means = self.h_mean_s(z_hat)
         y_hat_slices, y_lik, mus, scales = [], [], [], []
-        for i, y_slice in enumerate(y.chunk(self.num_slices, 1)):
+        for i, y_slice in enumerate(ops.split_channels(y, [y.shape[1] // self.num_slices] * self.num_slices)):
             mean_support, mu, scale = self._slice_params(i, latent_means, latent_scales, y_hat_slices, ref_features, y_shape)
             mus.append(mu)
             scales.append(scale)

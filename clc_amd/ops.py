@@ -344,6 +344,47 @@ def linear(x, w, b=None, *, act=ACT_NONE, res=None):
     return _ConvFn.apply(x, w, b, res, 1, 1, act, 1.0, False, False)
 
 
+# ----------------------------------------------------------------------------------- split / chunk
+
+
+class _SplitFn(Function):
+    """torch.split along channels returning strided views, with a backward that writes the incoming slice gradients
+    straight into ONE buffer (one strided-copy kernel per slice) — autograd's own SliceBackward would zero-fill a full-size
+    tensor per slice and then add them all up (2n+1 full passes instead of n partial ones)."""
+
+    @staticmethod
+    def forward(ctx, x, *sizes):
+        ctx.sizes = sizes
+        ctx.shape = x.shape
+        outs, o = [], 0
+        for sz in sizes:
+            outs.append(x[:, o:o + sz])
+            o += sz
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        N, Cc, H, W = ctx.shape
+        ref = next(g for g in grads if g is not None)
+        dx = torch.empty((N, Cc, H, W), device=ref.device, dtype=torch.float32, memory_format=CL)
+        rows, o = N * H * W, 0
+        for sz, g in zip(ctx.sizes, grads):
+            dst = dx.data_ptr() + 4 * o
+            if g is None:
+                dx[:, o:o + sz].zero_()
+            else:
+                g, gp, *_r, ldg = nhwc(g)
+                _lib.check(_L().clc_copy2d(gp, ldg, dst, Cc, rows, sz, _stream()), "clc_copy2d")
+            o += sz
+        return (dx,) + (None,) * len(ctx.sizes)
+
+
+def split_channels(x, sizes):
+    """Channel split as zero-copy views (kernels read them through their leading dimension)."""
+    x, *_ = nhwc(x)
+    return _SplitFn.apply(x, *[int(s) for s in sizes])
+
+
 # ------------------------------------------------------------------------------------------- GDN
 
 
