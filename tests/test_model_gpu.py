@@ -59,6 +59,32 @@ def test_forward_parity(dev, kind, R):
     assert frac_bad < 0.02, frac_bad
 
 
+def test_forward_parity_other_shapes(dev):
+    """Shape-generic kernels: the wide model (N=128, train_CLC.py's default width) and a non-square 256x384 input."""
+    from clc_amd import models as pm
+    from oracle import graph as og
+    from oracle.loss import compute_bpp
+    from oracle.recipe import apply_weight_recipe, synthetic_image
+
+    for N, (h, w) in ((128, (256, 256)), (64, (256, 384))):
+        o = og.CLC(N=N, num_ref_frames=1).eval()
+        apply_weight_recipe(o, 2)
+        p = pm.CLC(N=N, num_ref_frames=1)
+        p.load_state_dict(o.state_dict())
+        p = p.to(dev).eval()
+        x, r = synthetic_image(1, h, w, 50, smooth=True), [synthetic_image(1, h, w, 51, smooth=True)]
+        with torch.no_grad():
+            a = o(x, r)
+            b = p(x.to(dev), [r[0].to(dev)])
+        assert b["x_hat"].shape == (1, 3, h, w)
+        y_err = (b["para"]["y"].cpu() - a["para"]["y"]).abs().max().item() / a["para"]["y"].abs().max().item()
+        assert y_err < 5e-5, (N, h, w, y_err)
+        bo = compute_bpp(a)
+        bp = compute_bpp({"x_hat": b["x_hat"].cpu(), "likelihoods": {k: v.cpu() for k, v in b["likelihoods"].items()}})
+        assert abs(bo - bp) <= 1e-4, (N, h, w, bo, bp)
+        assert abs(_psnr(a["x_hat"], x) - _psnr(b["x_hat"].cpu(), x)) <= 0.01
+
+
 def test_backward_parity_clc(dev):
     """Eval-mode (deterministic rounding) forward with autograd on: loss and gradients vs the oracle."""
     from clc_amd.train import RateDistortionLoss as PRD
