@@ -22,7 +22,8 @@ struct AttnParams {
   int ldq, ldo, lddo, lddq;
   int B, H, W, C, heads, ws, shift;
   int nwin_y, nwin_x;      // windows per image
-  int groups_total;        // total window groups (= B*nwin/G)
+  int groups_total;        // total window groups (= ceil(B*nwin/G))
+  int windows_total;       // B*nwin; the last group may be partial (its surplus slots recompute window 0 and store nothing)
   int groups_per_block;
 };
 
@@ -57,7 +58,8 @@ __global__ __launch_bounds__(64) void winattn_fwd_kernel(const AttnParams p) {
   for (int gi = 0; gi < p.groups_per_block; ++gi) {
     const int grp = blockIdx.x * p.groups_per_block + gi;
     if (grp >= p.groups_total) break;
-    const int widx = grp * G + g;            // global window index (b, wy, wx)
+    const bool wvalid = grp * G + g < p.windows_total;
+    const int widx = wvalid ? grp * G + g : 0;            // global window index (b, wy, wx)
     const int b = widx / nwin, wr = widx - b * nwin, wy = wr / p.nwin_x, wx = wr - wy * p.nwin_x;
     const int pix = token_pixel(p, b, wy, wx, ty, tx);
     const size_t row = (size_t)pix * p.ldq;
@@ -94,10 +96,12 @@ __global__ __launch_bounds__(64) void winattn_fwd_kernel(const AttnParams p) {
       for (int c = 0; c < HD; ++c) o[c] = fmaf(e, Vs[g][j][c], o[c]);
     }
     const float inv = 1.f / l;
-    float* op = p.out + (size_t)pix * p.ldo + head * HD;
+    if (wvalid) {
+      float* op = p.out + (size_t)pix * p.ldo + head * HD;
 #pragma unroll
-    for (int c = 0; c < HD; c += 4) *reinterpret_cast<f32x4*>(op + c) = (f32x4){o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv};
-    if (p.lse) p.lse[(size_t)pix * p.heads + head] = mx + logf(l);
+      for (int c = 0; c < HD; c += 4) *reinterpret_cast<f32x4*>(op + c) = (f32x4){o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv};
+      if (p.lse) p.lse[(size_t)pix * p.heads + head] = mx + logf(l);
+    }
   }
 }
 
@@ -117,7 +121,8 @@ __global__ __launch_bounds__(64) void winattn_bwd_kernel(const AttnParams p) {
   for (int gi = 0; gi < p.groups_per_block; ++gi) {
     const int grp = blockIdx.x * p.groups_per_block + gi;
     if (grp >= p.groups_total) break;
-    const int widx = grp * G + g;
+    const bool wvalid = grp * G + g < p.windows_total;
+    const int widx = wvalid ? grp * G + g : 0;
     const int b = widx / nwin, wr = widx - b * nwin, wy = wr / p.nwin_x, wx = wr - wy * p.nwin_x;
     const int pix = token_pixel(p, b, wy, wx, ty, tx);
     const size_t row = (size_t)pix * p.ldq;
@@ -154,14 +159,16 @@ __global__ __launch_bounds__(64) void winattn_bwd_kernel(const AttnParams p) {
       a += Bias[(ty - ky + WS - 1) * (2 * WS - 1) + (tx - kx + WS - 1)];
       const float pj = masked(p, wy, wx, ty, tx, ky, kx) ? 0.f : expf(a - lse);
       const float ds = pj * (dp - dsum);
-      AccS[g][t][j] += ds;
+      AccS[g][t][j] += wvalid ? ds : 0.f;
 #pragma unroll
       for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, Ks[g][j][c], dq[c]);
     }
-    float* dqp = p.dqkv + (size_t)pix * p.lddq + head * HD;
+    if (wvalid) {
+      float* dqp = p.dqkv + (size_t)pix * p.lddq + head * HD;
 #pragma unroll
-    for (int c = 0; c < HD; c += 4)
-      *reinterpret_cast<f32x4*>(dqp + c) = (f32x4){dq[c] * scale, dq[c + 1] * scale, dq[c + 2] * scale, dq[c + 3] * scale};
+      for (int c = 0; c < HD; c += 4)
+        *reinterpret_cast<f32x4*>(dqp + c) = (f32x4){dq[c] * scale, dq[c + 1] * scale, dq[c + 2] * scale, dq[c + 3] * scale};
+    }
     // ---- pass 2: lane = key column. dV = sum_i P[i][t] dO[i]; dK = sum_i dS[i][t] q_i ----
     float kk[HD], vv2[HD], dk[HD], dvv[HD];
 #pragma unroll
@@ -180,6 +187,7 @@ __global__ __launch_bounds__(64) void winattn_bwd_kernel(const AttnParams p) {
     }
     float* dkp = p.dqkv + (size_t)pix * p.lddq + p.C + head * HD;
     float* dvp = p.dqkv + (size_t)pix * p.lddq + 2 * p.C + head * HD;
+    if (wvalid)
 #pragma unroll
     for (int c = 0; c < HD; c += 4) {
       // Qs already carries the hd^-1/2 factor, so dk is complete as is
@@ -222,8 +230,6 @@ int check_geom(const char* who, int B, int H, int W, int C, int heads, int ws, i
   CLC_CHECK(hd == 8 || hd == 16 || hd == 32, "%s: head_dim must be 8/16/32 (got %d)", who, hd);
   CLC_CHECK(ld3 >= 3 * C && ld1 >= C && ld3 % 4 == 0 && ld1 % 4 == 0, "%s: bad leading dims", who);
   CLC_CHECK((long)B * H * W < (1l << 31), "%s: too many tokens", who);
-  const int T = ws * ws, G = 64 / T;
-  CLC_CHECK(((long)B * (H / ws) * (W / ws)) % G == 0, "%s: window count not a multiple of %d", who, G);
   return 0;
 }
 
@@ -231,7 +237,8 @@ void fill(AttnParams& p, int B, int H, int W, int C, int heads, int ws, int shif
   p.B = B; p.H = H; p.W = W; p.C = C; p.heads = heads; p.ws = ws; p.shift = shift;
   p.nwin_y = H / ws; p.nwin_x = W / ws;
   const int T = ws * ws, G = 64 / T;
-  p.groups_total = B * p.nwin_y * p.nwin_x / G;
+  p.windows_total = B * p.nwin_y * p.nwin_x;
+  p.groups_total = (p.windows_total + G - 1) / G;
   int per = (p.groups_total * heads + target_blocks - 1) / target_blocks;
   if (per < 1) per = 1;
   p.groups_per_block = per;
