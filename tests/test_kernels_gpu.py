@@ -208,7 +208,7 @@ def _ref_wmsa_core(qkv_nchw, relbias, heads, ws, shift):
     return out.permute(0, 3, 1, 2)
 
 
-@pytest.mark.parametrize("cfg", [(64, 8, 8, 32, 32), (64, 4, 8, 16, 24), (64, 2, 8, 16, 16), (128, 8, 8, 16, 16), (64, 2, 4, 8, 8), (64, 2, 4, 8, 16)])
+@pytest.mark.parametrize("cfg", [(64, 8, 8, 32, 32), (64, 4, 8, 16, 24), (64, 2, 8, 16, 16), (128, 8, 8, 16, 16), (64, 2, 4, 8, 8), (64, 2, 4, 8, 16), (64, 2, 4, 8, 12)])
 @pytest.mark.parametrize("shift", [False, True])
 def test_window_attention(dev, cfg, shift):
     from clc_amd import ops
