@@ -38,8 +38,7 @@ struct WgradParams {
 };
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, 2)
-void conv_wgrad_kernel(const WgradParams p) {
+__device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, const int by, const int bz) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_P = (BK * BM / 4 + NT - 1) / NT, B_P = (BK * BN / 4 + NT - 1) / NT;
@@ -50,14 +49,14 @@ void conv_wgrad_kernel(const WgradParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int tap = blockIdx.x / p.nci, ci0 = (blockIdx.x % p.nci) * BN;
+  const int tap = bx / p.nci, ci0 = (bx % p.nci) * BN;
   const int kh = tap / p.ks, kw = tap - kh * p.ks;
-  const int co0 = blockIdx.y * BM;
-  const int split = blockIdx.z;
+  const int co0 = by * BM;
+  const int split = bz;
   const int k_begin = split * p.k_per_split;
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int ntiles = (k_end - k_begin + BK - 1) / BK;
-  const bool do_bias = (p.bias_partial != nullptr) && (blockIdx.x == 0);
+  const bool do_bias = (p.bias_partial != nullptr) && (bx == 0);
 
   f32x4 a_reg[A_P], b_reg[B_P], bias_acc[A_P], s_reg[A_P];
 #pragma unroll
@@ -190,12 +189,57 @@ void conv_wgrad_kernel(const WgradParams p) {
   }
 }
 
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2)
+void conv_wgrad_kernel(const WgradParams p) {
+  wgrad_body<BM, BN, WM, WN>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Grouped launch: up to kMaxGroup independent filter-gradient problems of one tile shape in ONE grid (descriptors in the
+// kernel-argument segment, workgroup -> problem by a scalar search of the prefix table).  The small-map layers of the
+// slice loop are 5-20 us kernels of 60-250 workgroups each; grouped they fill the chip and pay one launch.
+constexpr int kMaxGroup = 16;
+struct WgradGroup {
+  int count;
+  int wg_end[kMaxGroup];   // exclusive prefix of workgroups
+  int gx[kMaxGroup], gy[kMaxGroup];
+  WgradParams p[kMaxGroup];
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2)
+void conv_wgrad_grouped_kernel(const WgradGroup g) {
+  const int b = blockIdx.x;
+  int idx = 0;
+  while (idx + 1 < g.count && b >= g.wg_end[idx]) ++idx;
+  const int l = b - (idx ? g.wg_end[idx - 1] : 0);
+  const int gx = g.gx[idx], gy = g.gy[idx];
+  const int bx = l % gx, t = l / gx;
+  wgrad_body<BM, BN, WM, WN>(g.p[idx], bx, t % gy, t / gy);
+}
+
 // out[i] (+)= sum_k partial[k][i], fixed order: 4 interleaved groups (k mod 4) summed ascending, then ((g0+g1)+(g2+g3)).
 // Block = 64 column-threads (float4 each) x 4 groups, so a 128-way split is a chain of 32 loads per thread, 4 in flight.
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, long n, int splits, int accumulate) {
+// One launch serves up to kMaxSlabs slab sets (the dW and dbias slabs of every problem of a grouped launch).
+constexpr int kMaxSlabs = 2 * kMaxGroup;
+struct SlabSet { const float* partial; float* out; long n; int splits, accumulate; };
+struct SlabGroup {
+  int count;
+  int blk_end[kMaxSlabs];
+  SlabSet e[kMaxSlabs];
+};
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabGroup sg) {
   __shared__ f32x4 sm[4][64];
   const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const long i = ((long)blockIdx.x * 64 + tx) * 4;
+  int idx = 0;
+  while (idx + 1 < sg.count && (int)blockIdx.x >= sg.blk_end[idx]) ++idx;
+  const long bx = (int)blockIdx.x - (idx ? sg.blk_end[idx - 1] : 0);
+  const float* __restrict__ partial = sg.e[idx].partial;
+  float* __restrict__ out = sg.e[idx].out;
+  const long n = sg.e[idx].n;
+  const int splits = sg.e[idx].splits, accumulate = sg.e[idx].accumulate;
+  const long i = (bx * 64 + tx) * 4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (i < n) {
     const bool vec = (i + 3 < n) && ((n & 3) == 0);
@@ -335,8 +379,10 @@ extern "C" size_t clc_conv2d_wgrad_workspace_bytes(const clc_wgrad_desc* d) {
   return ((size_t)pl.splits * (wsz + d->Cout) + 64) * sizeof(float);
 }
 
-extern "C" int clc_conv2d_wgrad(const clc_wgrad_desc* d, clc_stream_t stream) {
-  hipStream_t st = (hipStream_t)stream;
+namespace {
+
+// validates one descriptor and fills the kernel parameters for its plan
+int prepare(const clc_wgrad_desc* d, Plan& pl, WgradParams& p) {
   CLC_CHECK(d && d->x && d->dy && d->dw, "clc_conv2d_wgrad: null pointer");
   CLC_CHECK(d->ks == 1 || d->ks == 3, "clc_conv2d_wgrad: ks must be 1 or 3");
   CLC_CHECK(d->stride == 1 || d->stride == 2, "clc_conv2d_wgrad: stride must be 1 or 2");
@@ -345,10 +391,9 @@ extern "C" int clc_conv2d_wgrad(const clc_wgrad_desc* d, clc_stream_t stream) {
   CLC_CHECK(d->ldx >= d->Cin && d->lddy >= d->Cout, "clc_conv2d_wgrad: ld too small");
   CLC_CHECK((long)d->N * d->H * d->W < (1l << 31) && (long)d->N * d->OH * d->OW < (1l << 31), "clc_conv2d_wgrad: too many pixels");
   CLC_CHECK(d->workspace && d->workspace_bytes >= clc_conv2d_wgrad_workspace_bytes(d), "clc_conv2d_wgrad: workspace too small");
-  Plan pl = make_plan(d);
+  pl = make_plan(d);
   const int T = d->ks * d->ks;
   const size_t wsz = (size_t)d->Cout * T * d->Cin;
-  WgradParams p;
   p.x = d->x; p.dy = d->dy;
   const bool direct = (pl.splits == 1);   // one slab: write / accumulate the result in place, no reduce launch
   p.rmw = direct && d->accumulate;
@@ -358,44 +403,118 @@ extern "C" int clc_conv2d_wgrad(const clc_wgrad_desc* d, clc_stream_t stream) {
   p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout; p.lddy = d->lddy;
   p.ks = d->ks; p.stride = d->stride; p.pad = d->pad; p.in_op = d->in_op;
   p.K = d->N * d->OH * d->OW; p.k_per_split = pl.k_per_split; p.nci = pl.nci;
-  {
-    const size_t xb = ((size_t)d->N * d->H * d->W - 1) * d->ldx * 4 + (size_t)d->Cin * 4;
-    const size_t db = ((size_t)d->N * d->OH * d->OW - 1) * d->lddy * 4 + (size_t)d->Cout * 4;
-    CLC_CHECK(xb < (1ull << 31) && db < (1ull << 31), "clc_conv2d_wgrad: tensor larger than 2 GiB");
-    p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)db;
-    {
-      auto lg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
-      const int a = lg(d->OW), b = lg(d->OH * d->OW);
-      p.ow_shift = (a >= 0 && b >= 0) ? a : -1; p.img_shift = (a >= 0 && b >= 0) ? b : -1;
-    }
-    p.dys = d->dys; p.lddys = d->lddys; p.dys_act = d->dys_act; p.dys_pre = d->dys_pre; p.dys_bytes = 0;
-    if (d->dys) {
-      CLC_CHECK(d->lddys >= d->Cout, "clc_conv2d_wgrad: bad dys");
-      const size_t sb = ((size_t)d->N * d->OH * d->OW - 1) * d->lddys * 4 + (size_t)d->Cout * 4;
-      CLC_CHECK(sb < (1ull << 31), "clc_conv2d_wgrad: dys larger than 2 GiB");
-      p.dys_bytes = (unsigned)sb;
-    }
+  const size_t xb = ((size_t)d->N * d->H * d->W - 1) * d->ldx * 4 + (size_t)d->Cin * 4;
+  const size_t db = ((size_t)d->N * d->OH * d->OW - 1) * d->lddy * 4 + (size_t)d->Cout * 4;
+  CLC_CHECK(xb < (1ull << 31) && db < (1ull << 31), "clc_conv2d_wgrad: tensor larger than 2 GiB");
+  p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)db;
+  auto lg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
+  const int la = lg(d->OW), lb = lg(d->OH * d->OW);
+  p.ow_shift = (la >= 0 && lb >= 0) ? la : -1; p.img_shift = (la >= 0 && lb >= 0) ? lb : -1;
+  p.dys = d->dys; p.lddys = d->lddys; p.dys_act = d->dys_act; p.dys_pre = d->dys_pre; p.dys_bytes = 0;
+  if (d->dys) {
+    CLC_CHECK(d->lddys >= d->Cout, "clc_conv2d_wgrad: bad dys");
+    const size_t sb = ((size_t)d->N * d->OH * d->OW - 1) * d->lddys * 4 + (size_t)d->Cout * 4;
+    CLC_CHECK(sb < (1ull << 31), "clc_conv2d_wgrad: dys larger than 2 GiB");
+    p.dys_bytes = (unsigned)sb;
   }
-  if (pl.small) {
-    CLC_CHECK(T * d->Cin <= 32, "clc_conv2d_wgrad: small/unaligned path needs ks*ks*Cin <= 32 (got %d)", T * d->Cin);
-    hipLaunchKernelGGL(wgrad_small_kernel, dim3(pl.splits, (d->Cout + 127) / 128), dim3(256), 0, st, p, pl.splits);
-    CLC_LAUNCH_CHECK();
+  if (pl.small) CLC_CHECK(T * d->Cin <= 32, "clc_conv2d_wgrad: small/unaligned path needs ks*ks*Cin <= 32 (got %d)", T * d->Cin);
+  else CLC_CHECK(aligned16(d->x) && aligned16(d->dy), "clc_conv2d_wgrad: unaligned pointers");
+  return 0;
+}
+
+struct Pending { const clc_wgrad_desc* d; Plan pl; WgradParams p; };
+
+template <int BM, int BN>
+int launch_variant(const Pending* pend, int n, hipStream_t st) {
+  WgradGroup g;
+  g.count = 0;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    const Pending& e = pend[i];
+    if (e.pl.small || e.pl.bm != BM || e.pl.bn != BN) continue;
+    const int T = e.d->ks * e.d->ks;
+    const int gx = e.pl.nci * T, gy = (e.d->Cout + BM - 1) / BM;
+    total += gx * gy * e.pl.splits;
+    g.gx[g.count] = gx; g.gy[g.count] = gy; g.wg_end[g.count] = total; g.p[g.count] = e.p;
+    ++g.count;
+  }
+  if (g.count == 0) return 0;
+  const size_t lds = (size_t)2 * BK * (BM + BN) * sizeof(float);
+  if (g.count == 1) {
+    const int last = g.wg_end[0] / (g.gx[0] * g.gy[0]);
+    hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, 2, 2>), dim3(g.gx[0], g.gy[0], last), dim3(256), lds, st, g.p[0]);
   } else {
-    CLC_CHECK(aligned16(d->x) && aligned16(d->dy), "clc_conv2d_wgrad: unaligned pointers");
-    dim3 grid(pl.nci * T, (d->Cout + pl.bm - 1) / pl.bm, pl.splits);
-    const size_t lds = (size_t)2 * BK * (pl.bm + pl.bn) * sizeof(float);
-    if (pl.bm == 128 && pl.bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), lds, st, p);
-    else if (pl.bm == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 2>), grid, dim3(256), lds, st, p);
-    else if (pl.bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 2, 2>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2>), grid, dim3(256), lds, st, p);
-    CLC_LAUNCH_CHECK();
+    hipLaunchKernelGGL((conv_wgrad_grouped_kernel<BM, BN, 2, 2>), dim3(total), dim3(256), lds, st, g);
   }
-  if (direct) return pl.small ? 1 : pl.bm * 1000 + pl.bn;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((wsz + 255) / 256)), dim3(256), 0, st, p.partial, d->dw, (long)wsz, pl.splits, d->accumulate);
   CLC_LAUNCH_CHECK();
-  if (d->dbias) {
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((d->Cout + 255) / 256), dim3(256), 0, st, p.bias_partial, d->dbias, (long)d->Cout, pl.splits, d->accumulate);
+  return 0;
+}
+
+// launches everything pending: one grid per tile shape, then one fixed-order reduce over every slab set
+int flush(Pending* pend, int& n, hipStream_t st) {
+  if (n == 0) return 0;
+  for (int i = 0; i < n; ++i)
+    if (pend[i].pl.small) {
+      hipLaunchKernelGGL(wgrad_small_kernel, dim3(pend[i].pl.splits, (pend[i].d->Cout + 127) / 128), dim3(256), 0, st, pend[i].p, pend[i].pl.splits);
+      CLC_LAUNCH_CHECK();
+    }
+  int rc;
+  if ((rc = launch_variant<128, 128>(pend, n, st)) < 0) return rc;
+  if ((rc = launch_variant<128, 64>(pend, n, st)) < 0) return rc;
+  if ((rc = launch_variant<64, 128>(pend, n, st)) < 0) return rc;
+  if ((rc = launch_variant<64, 64>(pend, n, st)) < 0) return rc;
+  SlabGroup sg;
+  sg.count = 0;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const Pending& e = pend[i];
+    if (e.pl.splits == 1) continue;
+    const long wsz = (long)e.d->Cout * e.d->ks * e.d->ks * e.d->Cin;
+    blocks += (int)((wsz + 255) / 256);
+    sg.e[sg.count] = SlabSet{e.p.partial, e.d->dw, wsz, e.pl.splits, e.d->accumulate};
+    sg.blk_end[sg.count++] = blocks;
+    if (e.d->dbias) {
+      blocks += (e.d->Cout + 255) / 256;
+      sg.e[sg.count] = SlabSet{e.p.bias_partial, e.d->dbias, (long)e.d->Cout, e.pl.splits, e.d->accumulate};
+      sg.blk_end[sg.count++] = blocks;
+    }
+  }
+  if (sg.count) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, sg);
     CLC_LAUNCH_CHECK();
   }
-  return pl.small ? 1 : pl.bm * 1000 + pl.bn;  // kernel-variant id
+  n = 0;
+  return 0;
+}
+
+int variant_id(const Plan& pl) { return pl.small ? 1 : pl.bm * 1000 + pl.bn; }
+
+}  // namespace
+
+extern "C" int clc_conv2d_wgrad(const clc_wgrad_desc* d, clc_stream_t stream) {
+  Pending e;
+  e.d = d;
+  int rc = prepare(d, e.pl, e.p);
+  if (rc < 0) return rc;
+  int n = 1;
+  if ((rc = flush(&e, n, (hipStream_t)stream)) < 0) return rc;
+  return variant_id(e.pl);  // kernel-variant id
+}
+
+extern "C" int clc_conv2d_wgrad_batched(const clc_wgrad_desc* descs, int count, clc_stream_t stream) {
+  CLC_CHECK(descs && count >= 0, "clc_conv2d_wgrad_batched: bad arguments");
+  Pending pend[kMaxGroup];
+  int n = 0, rc;
+  for (int i = 0; i < count; ++i) {
+    const clc_wgrad_desc* d = descs + i;
+    // two problems that write the same gradient buffer (a filter applied twice) must not share a launch
+    bool clash = n == kMaxGroup;
+    for (int j = 0; j < n && !clash; ++j)
+      clash = pend[j].d->dw == d->dw || (d->dbias && pend[j].d->dbias == d->dbias) || pend[j].d->workspace == d->workspace;
+    if (clash && (rc = flush(pend, n, (hipStream_t)stream)) < 0) return rc;
+    pend[n].d = d;
+    if ((rc = prepare(d, pend[n].pl, pend[n].p)) < 0) return rc;
+    ++n;
+  }
+  return flush(pend, n, (hipStream_t)stream);
 }

@@ -59,6 +59,7 @@ SIGNATURES = {
     "clc_conv2d": (_i, [C.POINTER(ConvDesc), fp]),
     "clc_conv2d_wgrad_workspace_bytes": (_sz, [C.POINTER(WgradDesc)]),
     "clc_conv2d_wgrad": (_i, [C.POINTER(WgradDesc), fp]),
+    "clc_conv2d_wgrad_batched": (_i, [C.POINTER(WgradDesc), _i, fp]),
     "clc_filter_transpose": (_i, [fp, fp, _i, _i, _i, fp]),
     "clc_filter_transpose_batched": (_i, [fp, _i, _i, fp]),
     "clc_act_bwd": (_i, [fp, _i, fp, _i, _i, _i, fp, _i, _l, _i, fp]),

@@ -37,8 +37,26 @@ def enable_wgrad_stream(enable=True):
     WGRAD_STREAM = torch.cuda.Stream() if enable else None
 
 
+# Deferred filter gradients: the side stream's problems are independent of each other, so they are queued and launched
+# WGRAD_GROUP at a time through clc_conv2d_wgrad_batched (one grid per tile shape + one slab reduce for the whole group)
+# instead of 2-3 launch-bound kernels per layer.
+WGRAD_GROUP = int(os.environ.get("CLC_WGRAD_GROUP", "16"))
+_PENDING = []
+
+
+def flush_wgrads():
+    if not _PENDING:
+        return
+    arr = (_lib.WgradDesc * len(_PENDING))(*[d for d, _ in _PENDING])
+    with torch.cuda.stream(WGRAD_STREAM):
+        _lib.check(_L().clc_conv2d_wgrad_batched(arr, len(_PENDING), _stream()), "clc_conv2d_wgrad_batched")
+    _KEEPALIVE.append([k for _, k in _PENDING])
+    _PENDING.clear()
+
+
 def join_side_streams():
     if WGRAD_STREAM is not None:
+        flush_wgrads()
         torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
     _KEEPALIVE.clear()
 
@@ -209,10 +227,22 @@ def filter_transpose(w, Cout, T, Cin):
     return wt.view(Cin, T * Cout)
 
 
+def wgrad_batched(problems):
+    """problems: list of dicts of wgrad_raw keyword arguments (with x, dy, dw_out[, db_out]); one clc_conv2d_wgrad_batched
+    call on the current stream, accumulating into the given buffers."""
+    queued = []
+    for kw in problems:
+        queued.append(wgrad_raw(**kw, _collect=True))
+    arr = (_lib.WgradDesc * len(queued))(*[d for d, _ in queued])
+    _lib.check(_L().clc_conv2d_wgrad_batched(arr, len(queued), _stream()), "clc_conv2d_wgrad_batched")
+    return [k for _, k in queued]   # operands / workspaces: keep until the stream has run the launches
+
+
 def wgrad_raw(x, dy, *, ks, stride, pad, Cout, Cin, want_bias, in_op=IN_NONE, dw_out=None, db_out=None, dys=None, dys_act=ACT_NONE,
-              dys_pre=False):
+              dys_pre=False, defer=False, _collect=False):
     """Returns (dw [Cout, ks*ks*Cin] flat kernel layout, dbias or None).  With dw_out / db_out (persistent gradient
-    buffers in kernel layout) the result is ACCUMULATED into them and (None, None) is returned."""
+    buffers in kernel layout) the result is ACCUMULATED into them and (None, None) is returned.  defer=True (direct mode
+    on the side stream only) queues the problem for the next grouped launch (flush_wgrads)."""
     x, xp, N, H, W, _, ldx = nhwc(x)
     dy, dp, _, OH, OW, _, lddy = nhwc(dy)
     direct = dw_out is not None
@@ -223,12 +253,21 @@ def wgrad_raw(x, dy, *, ks, stride, pad, Cout, Cin, want_bias, in_op=IN_NONE, dw
     d.dy, d.OH, d.OW, d.Cout, d.lddy = dp, OH, OW, Cout, lddy
     d.dw, d.dbias = dw.data_ptr(), (db.data_ptr() if db is not None else None)
     d.ks, d.stride, d.pad, d.in_op, d.accumulate = ks, stride, pad, in_op, int(direct)
+    dys_t = None
     if dys is not None:   # fused activation backward: dy <- dy * act'(dys)
         dys_t, dysp, *_r, lddys = nhwc(dys)
         d.dys, d.lddys, d.dys_act, d.dys_pre = dysp, lddys, dys_act, int(dys_pre)
     nbytes = _L().clc_conv2d_wgrad_workspace_bytes(C.byref(d))
     ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
     d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+    if _collect:
+        return d, (x, dy, dys_t, dw, db, ws)
+    if defer:
+        WGRAD_STREAM.wait_stream(torch.cuda.current_stream())   # the operands are produced on the current stream
+        _PENDING.append((d, (x, dy, dys_t, dw, db, ws)))
+        if len(_PENDING) >= WGRAD_GROUP:
+            flush_wgrads()
+        return None, None
     if PROFILE is None:
         _lib.check(_L().clc_conv2d_wgrad(C.byref(d), _stream()), "clc_conv2d_wgrad")
     else:
@@ -316,11 +355,14 @@ class _ConvFn(Function):
             if gw is not None and (gb is not None or not has_b) and to_kernel_weight(w) is w:
                 # write straight into the persistent gradient arena (accumulate) — no temporary, no autograd add kernel
                 if WGRAD_STREAM is not None and PROFILE is None:
-                    cur = torch.cuda.current_stream()
-                    WGRAD_STREAM.wait_stream(cur)
-                    _KEEPALIVE.append((x, dz, saved_act))
-                    with torch.cuda.stream(WGRAD_STREAM):
-                        wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb, **fw)
+                    if WGRAD_GROUP > 1:
+                        wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb, defer=True, **fw)
+                    else:
+                        cur = torch.cuda.current_stream()
+                        WGRAD_STREAM.wait_stream(cur)
+                        _KEEPALIVE.append((x, dz, saved_act))
+                        with torch.cuda.stream(WGRAD_STREAM):
+                            wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb, **fw)
                 else:
                     wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb, **fw)
             else:

@@ -96,6 +96,12 @@ typedef struct {
 
 size_t clc_conv2d_wgrad_workspace_bytes(const clc_wgrad_desc* d);
 int clc_conv2d_wgrad(const clc_wgrad_desc* d, clc_stream_t stream);
+/* `count` independent filter-gradient problems (each with its own workspace): same results, bit for bit, as `count`
+ * calls of clc_conv2d_wgrad in order, but problems of one tile shape share a grid and all slab sets share one
+ * fixed-order reduce launch (the 16x16-map layers of the slice loop are launch-bound one by one).  Problems that write
+ * the same dw / dbias (a filter applied twice, e.g. the reference encoder over several reference frames) are kept in
+ * separate launches, in order. */
+int clc_conv2d_wgrad_batched(const clc_wgrad_desc* descs, int count, clc_stream_t stream);
 
 /* [Cout][T][Cin] -> [Cin][T][Cout]  (T = ks*ks) */
 int clc_filter_transpose(const float* w, float* wt, int Cout, int T, int Cin, clc_stream_t stream);

@@ -50,6 +50,55 @@ CONV_CASES = [
 ]
 
 
+def test_wgrad_batched_matches_single_launches(dev):
+    """clc_conv2d_wgrad_batched == the same problems launched one by one, bit for bit: mixed tile shapes, the RGB
+    small path, K-splits, fused activation derivative, more problems than one group holds, and a filter that is
+    written twice (accumulation order preserved)."""
+    from clc_amd import ops
+
+    shapes = [(8, 64, 16, 16, 64, 3, 1), (8, 224, 16, 16, 128, 3, 1), (8, 128, 16, 16, 32, 3, 1), (8, 64, 16, 16, 128, 1, 1),
+              (2, 128, 64, 64, 128, 3, 1), (2, 128, 32, 32, 256, 3, 2), (1, 3, 64, 64, 128, 3, 2), (3, 128, 24, 40, 96, 3, 1),
+              (8, 448, 16, 16, 224, 3, 1), (1, 192, 4, 4, 512, 3, 1)] * 2 + [(8, 64, 16, 16, 64, 3, 1)] * 3
+    probs = []
+    for i, (N, Cin, H, W, Cout, ks, stride) in enumerate(shapes):
+        pad = ks // 2
+        OH, OW = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+        x = _dev(_rand((N, Cin, H, W), 100 + i), dev).contiguous(memory_format=torch.channels_last)
+        dy = _dev(_rand((N, Cout, OH, OW), 200 + i), dev).contiguous(memory_format=torch.channels_last)
+        pre = _dev(_rand((N, Cout, OH, OW), 300 + i), dev).contiguous(memory_format=torch.channels_last)
+        kw = dict(x=x, dy=dy, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=True)
+        if i % 3 == 1:
+            kw.update(dys=pre, dys_act=1, dys_pre=True)
+        probs.append(kw)
+
+    def buffers():
+        out = []
+        for i, kw in enumerate(probs):
+            if i >= len(probs) - 2:   # the last two problems accumulate into the buffers of the third-last one
+                out.append(out[len(probs) - 3])
+            else:
+                n = kw["Cout"] * kw["ks"] ** 2 * kw["Cin"]
+                out.append((torch.full((n,), 0.25, device=dev), torch.full((kw["Cout"],), -0.5, device=dev)))
+        return out
+
+    single = buffers()
+    for kw, (dw, db) in zip(probs, single):
+        ops.wgrad_raw(**kw, dw_out=dw, db_out=db)
+    batched = buffers()
+    keep = ops.wgrad_batched([dict(kw, dw_out=dw, db_out=db) for kw, (dw, db) in zip(probs, batched)])
+    torch.cuda.synchronize()
+    del keep
+    for i, ((dw1, db1), (dw2, db2)) in enumerate(zip(single, batched)):
+        assert torch.equal(dw1, dw2), f"problem {i}: dW differs"
+        assert torch.equal(db1, db2), f"problem {i}: dbias differs"
+    # and against the fp32 reference for one grouped problem
+    kw = probs[0]
+    wref = torch.zeros(64, 64, 3, 3, requires_grad=True)
+    F.conv2d(kw["x"].cpu(), wref, None, padding=1).backward(kw["dy"].cpu())
+    got = (batched[0][0] - 0.25).view(64, 3, 3, 64).permute(0, 3, 1, 2).cpu()
+    _close(got, wref.grad, 1e-4, "grouped wgrad vs torch")
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("act", [0, 1, 3])
 def test_conv_fwd_bwd(dev, case, act):
