@@ -198,7 +198,7 @@ void conv_wgrad_kernel(const WgradParams p) {
 // Grouped launch: up to kMaxGroup independent filter-gradient problems of one tile shape in ONE grid (descriptors in the
 // kernel-argument segment, workgroup -> problem by a scalar search of the prefix table).  The small-map layers of the
 // slice loop are 5-20 us kernels of 60-250 workgroups each; grouped they fill the chip and pay one launch.
-constexpr int kMaxGroup = 16;
+constexpr int kMaxGroup = 64;
 struct WgradGroup {
   int count;
   int wg_end[kMaxGroup];   // exclusive prefix of workgroups

@@ -40,8 +40,10 @@ def enable_wgrad_stream(enable=True):
 # Deferred filter gradients: the side stream's problems are independent of each other, so they are queued and launched
 # WGRAD_GROUP at a time through clc_conv2d_wgrad_batched (one grid per tile shape + one slab reduce for the whole group)
 # instead of 2-3 launch-bound kernels per layer.
-WGRAD_GROUP = int(os.environ.get("CLC_WGRAD_GROUP", "16"))
-_PENDING = []
+WGRAD_GROUP = int(os.environ.get("CLC_WGRAD_GROUP", "64"))             # problems per grouped launch (library cap: 64)
+WGRAD_FLUSH_GFLOP = float(os.environ.get("CLC_WGRAD_FLUSH_GFLOP", "100"))  # ... or as soon as this much work is queued:
+_PENDING = []                                                            # large layers fill the chip alone and go at once
+_PENDING_FLOP = [0.0]
 
 
 def flush_wgrads():
@@ -52,6 +54,7 @@ def flush_wgrads():
         _lib.check(_L().clc_conv2d_wgrad_batched(arr, len(_PENDING), _stream()), "clc_conv2d_wgrad_batched")
     _KEEPALIVE.append([k for _, k in _PENDING])
     _PENDING.clear()
+    _PENDING_FLOP[0] = 0.0
 
 
 def join_side_streams():
@@ -265,7 +268,8 @@ def wgrad_raw(x, dy, *, ks, stride, pad, Cout, Cin, want_bias, in_op=IN_NONE, dw
     if defer:
         WGRAD_STREAM.wait_stream(torch.cuda.current_stream())   # the operands are produced on the current stream
         _PENDING.append((d, (x, dy, dys_t, dw, db, ws)))
-        if len(_PENDING) >= WGRAD_GROUP:
+        _PENDING_FLOP[0] += 2.0 * N * OH * OW * ks * ks * Cin * Cout
+        if len(_PENDING) >= WGRAD_GROUP or _PENDING_FLOP[0] >= WGRAD_FLUSH_GFLOP * 1e9:
             flush_wgrads()
         return None, None
     if PROFILE is None:
