@@ -88,7 +88,7 @@ def roofline_leg(engine, x, refs):
     finally:
         ops.PROFILE = None
     agg = {}
-    for fam, variant, flops, e0, e1 in rec:
+    for fam, variant, flops, e0, e1, *_shape in rec:
         key = f"{fam}<{variant // 1000},{variant % 1000}>" if variant >= 1000 else fam
         a = agg.setdefault(key, [0.0, 0.0, 0])
         a[0] += flops

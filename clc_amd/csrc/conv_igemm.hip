@@ -50,6 +50,7 @@ struct ConvParams {
   int kc_tiles;                // ceil(Cin/32)
   unsigned x_bytes, w_bytes;
   const float* xs; int ldxs, xs_act, xs_pre; unsigned xs_bytes;   // fused activation backward on the gathered operand
+  int vec_epi;                 // every epilogue operand is 16-B addressable per 4 channels -> float4 epilogue
 };
 
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
@@ -149,6 +150,35 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, float acc, f
   v = apply_act(v, p.act);
   if (p.res && !p.res_first) v += p.res_scale * p.res[pix * p.ldr + ch];
   p.y[pix * p.ldy + ch] = v;
+}
+
+// Same arithmetic, element for element, on 4 consecutive channels of one pixel (p.vec_epi: no shuffle, Cout % 4 == 0,
+// every row stride a multiple of 4 floats and every base 16-B aligned): b128 loads / stores instead of dword ones.
+__device__ __forceinline__ void epilogue_store4(const ConvParams& p, f32x4 acc, int m, int co, int DH, int DW, int ph, int pw) {
+  size_t pix;
+  if (p.transposed && p.stride == 2) {
+    const int n = m / (DH * DW), rr = m - n * (DH * DW);
+    const int oy = rr / DW, ox = rr - oy * DW;
+    pix = (size_t)(n * p.OH + 2 * oy + ph) * p.OW + 2 * ox + pw;
+  } else {
+    pix = (size_t)m;
+  }
+  f32x4 v = acc;
+  if (p.bias) { v[0] += p.bias[co]; v[1] += p.bias[co + 1]; v[2] += p.bias[co + 2]; v[3] += p.bias[co + 3]; }
+  else { v[0] += 0.f; v[1] += 0.f; v[2] += 0.f; v[3] += 0.f; }
+  f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+  if (p.res) rv = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + co);
+  if (p.res && p.res_first) v = v + p.res_scale * rv;
+  if (p.y_pre) *reinterpret_cast<f32x4*>(p.y_pre + pix * p.ldp + co) = v;
+  if (p.norm != CLC_NORM_NONE) {
+    const f32x4 mv = *reinterpret_cast<const f32x4*>(p.mul + pix * p.ldm + co);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (p.norm == CLC_NORM_GDN) ? mv[q] * rsqrtf(v[q]) : mv[q] * sqrtf(v[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], p.act);
+  if (p.res && !p.res_first) v = v + p.res_scale * rv;
+  *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + co) = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -274,6 +304,14 @@ void conv_igemm_kernel(const ConvParams p) {
           Cs[(wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf) * LDC + wn * (BN / WN) + j * 32 + col] = acc[i][j][r];
   }
   __syncthreads();
+  if (p.vec_epi) {   // block-uniform
+    for (int e = tid; e < BM * BN / 4; e += NT) {
+      const int row = e / (BN / 4), cc = (e - row * (BN / 4)) * 4;
+      const int m = m0 + row, co = n0 + cc;
+      if (m < p.M && co < p.Cout) epilogue_store4(p, *reinterpret_cast<const f32x4*>(Cs + row * LDC + cc), m, co, DH, DW, ph, pw);
+    }
+    return;
+  }
   for (int e = tid; e < BM * BN; e += NT) {
     const int row = e / BN, cc = e - row * BN;
     const int m = m0 + row, co = n0 + cc;
@@ -373,6 +411,19 @@ void conv_igemm_splitk_kernel(const ConvParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[((wave * TN + j) * 16 + r) * 64 + lane] = acc[j][r];
   __syncthreads();
+  if (p.vec_epi) {   // block-uniform: 4 consecutive channels = 4 consecutive lanes of one (wave, j, r) row of the buffer
+    for (int e = tid; e < BM * BN / 4; e += 512) {
+      const int rowi = e / (BN / 4), cc = (e - rowi * (BN / 4)) * 4;
+      const int j = cc >> 5, r = (rowi & 3) + 4 * (rowi >> 3), ln = (cc & 31) + 32 * ((rowi >> 2) & 1);
+      f32x4 q[KW];
+#pragma unroll
+      for (int w = 0; w < KW; ++w) q[w] = *reinterpret_cast<const f32x4*>(red + ((w * TN + j) * 16 + r) * 64 + ln);
+      const f32x4 v = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+      const int m = m0 + rowi, co = n0 + cc;
+      if (m < p.M && co < p.Cout) epilogue_store4(p, v, m, co, DH, DW, ph, pw);
+    }
+    return;
+  }
   for (int e = tid; e < BM * BN; e += 512) {
     const int rowi = e / BN, cc = e - rowi * BN;         // rowi = (r&3) + 8*(r>>2) + 4*h ; cc = j*32 + (lane&31)
     const int j = cc >> 5, r = (rowi & 3) + 4 * (rowi >> 3), ln = (cc & 31) + 32 * ((rowi >> 2) & 1);
@@ -551,6 +602,10 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
     const size_t sb = ((size_t)d->N * d->H * d->W - 1) * d->ldxs * 4 + (size_t)d->Cin * 4;
     CLC_CHECK(sb < (1ull << 31), "clc_conv2d: xs larger than 2 GiB");
     p.xs_bytes = (unsigned)sb;
+  }
+  {
+    auto ok4 = [](const void* ptr, int ld) { return ptr == nullptr || (aligned16(ptr) && ld % 4 == 0); };
+    p.vec_epi = !d->shuffle && d->Cout % 4 == 0 && ok4(d->y, d->ldy) && ok4(d->res, d->ldr) && ok4(d->mul, d->ldm) && ok4(d->y_pre, d->ldp);
   }
   int classes = 1;
   p.M = d->N * d->OH * d->OW;

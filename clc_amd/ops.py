@@ -51,7 +51,14 @@ def flush_wgrads():
         return
     arr = (_lib.WgradDesc * len(_PENDING))(*[d for d, _ in _PENDING])
     with torch.cuda.stream(WGRAD_STREAM):
-        _lib.check(_L().clc_conv2d_wgrad_batched(arr, len(_PENDING), _stream()), "clc_conv2d_wgrad_batched")
+        if PROFILE is None:
+            _lib.check(_L().clc_conv2d_wgrad_batched(arr, len(_PENDING), _stream()), "clc_conv2d_wgrad_batched")
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(_L().clc_conv2d_wgrad_batched(arr, len(_PENDING), _stream()), "clc_conv2d_wgrad_batched")
+            e1.record()
+            PROFILE.append(("conv_wgrad_grouped", 0, _PENDING_FLOP[0], e0, e1, f"{len(_PENDING)} problems"))
     _KEEPALIVE.append([k for _, k in _PENDING])
     _PENDING.clear()
     _PENDING_FLOP[0] = 0.0
@@ -220,7 +227,8 @@ def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_
         variant = _lib.check(_L().clc_conv2d(C.byref(d), _stream()), "clc_conv2d")
         e1.record()
         pix = N * H * W if transposed else N * OH * OW
-        PROFILE.append(("conv_igemm" if variant != 1 else "conv_direct_small", variant, 2.0 * pix * ks * ks * Cin * Cout, e0, e1))
+        PROFILE.append(("conv_igemm" if variant != 1 else "conv_direct_small", variant, 2.0 * pix * ks * ks * Cin * Cout, e0, e1,
+                        f"{'dgrad' if transposed else 'fwd'} {Cin}->{Cout} k{ks} s{stride} {N}x{H}x{W}" + (" +actbwd" if xs is not None else "")))
     return out
 
 
@@ -279,7 +287,8 @@ def wgrad_raw(x, dy, *, ks, stride, pad, Cout, Cin, want_bias, in_op=IN_NONE, dw
         e0.record()
         variant = _lib.check(_L().clc_conv2d_wgrad(C.byref(d), _stream()), "clc_conv2d_wgrad")
         e1.record()
-        PROFILE.append(("conv_wgrad" if variant != 1 else "wgrad_small", variant, 2.0 * N * OH * OW * ks * ks * Cin * Cout, e0, e1))
+        PROFILE.append(("conv_wgrad" if variant != 1 else "wgrad_small", variant, 2.0 * N * OH * OW * ks * ks * Cin * Cout, e0, e1,
+                        f"wgrad {Cin}->{Cout} k{ks} s{stride} {N}x{H}x{W}"))
     return (None, None) if direct else (dw, db)
 
 
@@ -358,7 +367,7 @@ class _ConvFn(Function):
             gw, gb = _direct_grad(w), (_direct_grad(ctx.bias_ref) if has_b else None)
             if gw is not None and (gb is not None or not has_b) and to_kernel_weight(w) is w:
                 # write straight into the persistent gradient arena (accumulate) — no temporary, no autograd add kernel
-                if WGRAD_STREAM is not None and PROFILE is None:
+                if WGRAD_STREAM is not None and (PROFILE is None or WGRAD_GROUP > 1):
                     if WGRAD_GROUP > 1:
                         wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb, defer=True, **fw)
                     else:
