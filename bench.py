@@ -89,7 +89,10 @@ def roofline_leg(engine, x, refs):
         ops.PROFILE = None
     agg = {}
     for fam, variant, flops, e0, e1, *_shape in rec:
-        key = f"{fam}<{variant // 1000},{variant % 1000}>" if variant >= 1000 else fam
+        if variant >= 1000 and variant % 1000 >= 500:
+            key = f"{fam}_splitk<32,{variant % 1000 - 500}>"
+        else:
+            key = f"{fam}<{variant // 1000},{variant % 1000}>" if variant >= 1000 else fam
         a = agg.setdefault(key, [0.0, 0.0, 0])
         a[0] += flops
         a[1] += e0.elapsed_time(e1) * 1e-3

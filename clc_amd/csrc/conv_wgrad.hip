@@ -189,6 +189,148 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 on power-of-two maps: ALL NINE TAPS in one workgroup.
+// The tap-per-workgroup kernel above re-reads dY and X nine times (PMC: 12.6 GB fetched per step by the 64-channel
+// layers alone, HBM-bound at 58 TF).  Here a K-tile is a TH x TW block of output pixels (TH*TW = 32); its dY rows and
+// the (TH+2) x (TW+2) input window are staged in LDS ONCE and the nine taps are nine shifted views of that window:
+// 64 co x (9 taps x 64 ci) outputs per workgroup, wave (wm, wn) = 32 co x 32 ci x 9 taps = 9 MFMA blocks (144 acc
+// registers), 10 ds_read_b32 per 9 MFMAs.  Same slab layout / fixed-order reduce as above.
+template <int TW>
+__device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int bx, const int by, const int bz) {
+  constexpr int TH = 32 / TW, XW = TW + 2, XH = TH + 2, XP = XH * XW;
+  constexpr int LTW = TW == 32 ? 5 : (TW == 16 ? 4 : 3);
+  constexpr int X_P = (XP * 16 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                  // [2][32][64]   dY tile, [k][co]
+  float* Xs = smem + 2 * 32 * 64;    // [2][XP][64]   input window, [pixel][ci]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ci0 = bx * 64, co0 = by * 64, split = bz;
+  const int t_begin = split * (p.k_per_split >> 5);
+  const int t_end = min(p.K >> 5, t_begin + (p.k_per_split >> 5));
+  const int ntiles = t_end - t_begin;
+  const bool do_bias = (p.bias_partial != nullptr) && (bx == 0);
+  const int lcols = p.ow_shift - LTW;                       // log2(tile columns per image row)
+  const int lrows = (p.img_shift - p.ow_shift) - (5 - LTW); // log2(tile rows per image)
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
+  const bool fuse_act = p.dys != nullptr;
+  const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fuse_act ? p.dys : p.dy), 0, fuse_act ? p.dys_bytes : p.dy_bytes, 0x00020000);
+
+  f32x4 a_reg[2], s_reg[2], x_reg[X_P], bias_acc[2];
+  bias_acc[0] = bias_acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto load_tile = [&](int t) {
+    const int bc = t & ((1 << lcols) - 1), t2 = t >> lcols;
+    const int br = t2 & ((1 << lrows) - 1), n = t2 >> lrows;
+    const int oy0 = br * TH, ox0 = bc * TW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = tid + i * 256, row = piece >> 4, q = piece & 15;
+      const int pix = (n * p.OH + oy0 + (row >> LTW)) * p.OW + ox0 + (row & (TW - 1));
+      const int co = co0 + q * 4;
+      const bool ok = co < p.Cout;
+      a_reg[i] = buf_load4(dr, ok ? ((unsigned)pix * (unsigned)p.lddy + (unsigned)co) * 4u : kOOB);
+      if (fuse_act) s_reg[i] = buf_load4(sr, ok ? ((unsigned)pix * (unsigned)p.lddys + (unsigned)co) * 4u : kOOB);
+    }
+#pragma unroll
+    for (int i = 0; i < X_P; ++i) {
+      const int piece = tid + i * 256, xp = piece >> 4, q = piece & 15;
+      const int wy = xp / XW, wx = xp - wy * XW;
+      const int iy = oy0 + wy - 1, ix = ox0 + wx - 1, ci = ci0 + q * 4;
+      const bool ok = xp < XP && ci < p.Cin && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      x_reg[i] = buf_load4(xr, ok ? ((unsigned)((n * p.H + iy) * p.W + ix) * (unsigned)p.ldx + (unsigned)ci) * 4u : kOOB);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = tid + i * 256;
+      if (fuse_act) a_reg[i] = a_reg[i] * act_deriv4(s_reg[i], p.dys_act, p.dys_pre);
+      *reinterpret_cast<f32x4*>(As + buf * 32 * 64 + piece * 4) = a_reg[i];
+      if (do_bias) bias_acc[i] += a_reg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < X_P; ++i) {
+      const int piece = tid + i * 256;
+      if (piece < XP * 16) *reinterpret_cast<f32x4*>(Xs + buf * XP * 64 + piece * 4) = x_reg[i];
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  if (ntiles > 0) {
+    load_tile(t_begin);
+    store_tile(0);
+    __syncthreads();
+  }
+  const int khalf = lane >> 5, li = lane & 31;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < ntiles;
+    if (more) load_tile(t_begin + kt + 1);
+    const float* Ab = As + buf * 32 * 64 + wm * 32 + li;
+    const float* Xb = Xs + buf * XP * 64 + wn * 32 + li;
+#pragma unroll
+    for (int ss = 0; ss < 16; ++ss) {
+      const int k = 2 * ss + khalf;
+      const float a = Ab[k * 64];
+      const float* xk = Xb + ((k >> LTW) * XW + (k & (TW - 1))) * 64;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+          acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xk[(kh * XW + kw) * 64], acc[kh * 3 + kw], 0, 0, 0);
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // partial slab [split][Cout][9][Cin]
+  float* slab = p.partial + (size_t)split * p.Cout * 9 * p.Cin;
+  const int ci = ci0 + wn * 32 + li;
+  if (ci < p.Cin) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (co < p.Cout) {
+          float* dst = slab + ((size_t)co * 9 + t) * p.Cin + ci;
+          *dst = p.rmw ? *dst + acc[t][r] : acc[t][r];
+        }
+      }
+  }
+
+  if (do_bias) {  // column sums of the dY tiles: per-thread partial sums over this thread's rows, reduced through LDS
+    __syncthreads();
+    float* red = smem;  // [32][64]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(red + (tid + i * 256) * 4) = bias_acc[i];
+    __syncthreads();
+    if (tid < 64) {
+      float sum = 0.f;
+      for (int r = 0; r < 32; ++r) sum += red[r * 64 + tid];
+      if (co0 + tid < p.Cout) {
+        float* dst = p.bias_partial + (size_t)split * p.Cout + co0 + tid;
+        *dst = p.rmw ? *dst + sum : sum;
+      }
+    }
+  }
+}
+
+template <int TW>
+__global__ __launch_bounds__(256, 2)
+void conv_wgrad_taps_kernel(const WgradParams p) {
+  wgrad_taps_body<TW>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN, 2)
 void conv_wgrad_kernel(const WgradParams p) {
@@ -216,6 +358,18 @@ void conv_wgrad_grouped_kernel(const WgradGroup g) {
   const int gx = g.gx[idx], gy = g.gy[idx];
   const int bx = l % gx, t = l / gx;
   wgrad_body<BM, BN, WM, WN>(g.p[idx], bx, t % gy, t / gy);
+}
+
+template <int TW>
+__global__ __launch_bounds__(256, 2)
+void conv_wgrad_taps_grouped_kernel(const WgradGroup g) {
+  const int b = blockIdx.x;
+  int idx = 0;
+  while (idx + 1 < g.count && b >= g.wg_end[idx]) ++idx;
+  const int l = b - (idx ? g.wg_end[idx - 1] : 0);
+  const int gx = g.gx[idx], gy = g.gy[idx];
+  const int bx = l % gx, t = l / gx;
+  wgrad_taps_body<TW>(g.p[idx], bx, t % gy, t / gy);
 }
 
 // out[i] (+)= sum_k partial[k][i], fixed order: 4 interleaved groups (k mod 4) summed ascending, then ((g0+g1)+(g2+g3)).
@@ -318,10 +472,17 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const WgradParams p, i
   }
 }
 
-struct Plan { int bm, bn, splits, k_per_split, nci; bool small; };
+struct Plan { int bm, bn, splits, k_per_split, nci; bool small; int taps; };   // taps = TW of the all-taps kernel, or 0
+
+int taps_mode() {   // CLC_WGRAD_TAPS: 0 = never, 1 = where the tap-per-workgroup plan is not 128x128, 2 = wherever eligible (default)
+  static int mode = -1;
+  if (mode < 0) { const char* e = getenv("CLC_WGRAD_TAPS"); mode = e ? atoi(e) : 2; }
+  return mode;
+}
 
 Plan make_plan(const clc_wgrad_desc* d) {
   Plan pl;
+  pl.taps = 0;
   const long K = (long)d->N * d->OH * d->OW;
   const int T = d->ks * d->ks;
   pl.small = !((d->Cin % 4 == 0) && (d->ldx % 4 == 0) && (d->Cout % 4 == 0) && (d->lddy % 4 == 0));
@@ -362,6 +523,26 @@ Plan make_plan(const clc_wgrad_desc* d) {
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; pl.bm = bm; pl.bn = bn; splits = sp; }
       }
     }
+  {
+    auto lg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
+    const int la = lg(d->OW), lb = lg(d->OH * d->OW), tw = d->OW < 32 ? d->OW : 32;
+    const bool eligible = d->ks == 3 && d->stride == 1 && d->pad == 1 && la >= 3 && lb >= 0 && d->OH >= 32 / tw;
+    const int mode = taps_mode();
+    if (eligible && (mode == 2 || (mode == 1 && !(pl.bm == 128 && pl.bn == 128)))) {
+      pl.taps = tw; pl.bm = 64; pl.bn = 64; pl.nci = (d->Cin + 63) / 64;
+      const long ktiles = K / 32, tiles = (long)((d->Cout + 63) / 64) * pl.nci;
+      long sp = (ktiles + 15) / 16;                    // <= ~16 K-tiles (a ~60 us MFMA chain) per workgroup,
+      const long fill = (256 + tiles - 1) / tiles;     // enough workgroups for one per CU while K-tiles last (>= 2 each),
+      if (sp < fill) sp = fill;
+      if (sp > ktiles / 2) sp = ktiles / 2 > 0 ? ktiles / 2 : 1;
+      const long cap = 512 / tiles > 0 ? 512 / tiles : 1;
+      if (sp > cap) sp = cap;                          // and no more slabs than two workgroups per CU need
+      const long kt = (ktiles + sp - 1) / sp;
+      pl.k_per_split = (int)(kt * 32);
+      pl.splits = (int)((ktiles + kt - 1) / kt);
+      return pl;
+    }
+  }
   pl.nci = (d->Cin + pl.bn - 1) / pl.bn;
   long kps = (K + splits - 1) / splits;
   kps = (kps + BK - 1) / BK * BK;
@@ -431,7 +612,7 @@ int launch_variant(const Pending* pend, int n, hipStream_t st) {
   int total = 0;
   for (int i = 0; i < n; ++i) {
     const Pending& e = pend[i];
-    if (e.pl.small || e.pl.bm != BM || e.pl.bn != BN) continue;
+    if (e.pl.small || e.pl.taps || e.pl.bm != BM || e.pl.bn != BN) continue;
     const int T = e.d->ks * e.d->ks;
     const int gx = e.pl.nci * T, gy = (e.d->Cout + BM - 1) / BM;
     total += gx * gy * e.pl.splits;
@@ -450,6 +631,38 @@ int launch_variant(const Pending* pend, int n, hipStream_t st) {
   return 0;
 }
 
+template <int TW>
+int launch_taps(const Pending* pend, int n, hipStream_t st) {
+  WgradGroup g;
+  g.count = 0;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    const Pending& e = pend[i];
+    if (e.pl.small || e.pl.taps != TW) continue;
+    const int gx = e.pl.nci, gy = (e.d->Cout + 63) / 64;
+    total += gx * gy * e.pl.splits;
+    g.gx[g.count] = gx; g.gy[g.count] = gy; g.wg_end[g.count] = total; g.p[g.count] = e.p;
+    ++g.count;
+  }
+  if (g.count == 0) return 0;
+  constexpr int XP = (32 / TW + 2) * (TW + 2);
+  const size_t lds = (size_t)2 * (32 * 64 + XP * 64) * sizeof(float);
+  static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in (first call happens before any graph capture)
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_taps_kernel<TW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_taps_grouped_kernel<TW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  if (g.count == 1) {
+    const int last = g.wg_end[0] / (g.gx[0] * g.gy[0]);
+    hipLaunchKernelGGL((conv_wgrad_taps_kernel<TW>), dim3(g.gx[0], g.gy[0], last), dim3(256), lds, st, g.p[0]);
+  } else {
+    hipLaunchKernelGGL((conv_wgrad_taps_grouped_kernel<TW>), dim3(total), dim3(256), lds, st, g);
+  }
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+
 // launches everything pending: one grid per tile shape, then one fixed-order reduce over every slab set
 int flush(Pending* pend, int& n, hipStream_t st) {
   if (n == 0) return 0;
@@ -463,6 +676,9 @@ int flush(Pending* pend, int& n, hipStream_t st) {
   if ((rc = launch_variant<128, 64>(pend, n, st)) < 0) return rc;
   if ((rc = launch_variant<64, 128>(pend, n, st)) < 0) return rc;
   if ((rc = launch_variant<64, 64>(pend, n, st)) < 0) return rc;
+  if ((rc = launch_taps<32>(pend, n, st)) < 0) return rc;
+  if ((rc = launch_taps<16>(pend, n, st)) < 0) return rc;
+  if ((rc = launch_taps<8>(pend, n, st)) < 0) return rc;
   SlabGroup sg;
   sg.count = 0;
   int blocks = 0;
@@ -487,7 +703,7 @@ int flush(Pending* pend, int& n, hipStream_t st) {
   return 0;
 }
 
-int variant_id(const Plan& pl) { return pl.small ? 1 : pl.bm * 1000 + pl.bn; }
+int variant_id(const Plan& pl) { return pl.small ? 1 : (pl.taps ? 64900 + pl.taps : pl.bm * 1000 + pl.bn); }
 
 }  // namespace
 

@@ -47,6 +47,9 @@ CONV_CASES = [
     (8, 320, 16, 16, 128, 3, 2),
     (1, 192, 4, 4, 512, 3, 1),
     (3, 128, 24, 40, 96, 3, 1),  # ragged: non power-of-two map, Cout not a tile multiple
+    (2, 64, 8, 8, 96, 3, 1),     # all-taps filter gradient, 4x8 pixel tiles
+    (1, 64, 64, 128, 64, 3, 1),  # all-taps filter gradient, 1x32 pixel tiles, non-square map
+    (2, 96, 32, 16, 160, 3, 1),  # all-taps filter gradient, 2x16 tiles, channel counts that are not tile multiples
 ]
 
 
@@ -109,13 +112,18 @@ def test_conv_fwd_bwd(dev, case, act):
     w = _rand((Cout, Cin, ks, ks), 2, (1.0 / (Cin * ks * ks)) ** 0.5)
     b = _rand((Cout,), 3, 0.1)
     xr, wr, br = x.clone().requires_grad_(Cin != 3), w.clone().requires_grad_(), b.clone().requires_grad_()
-    ref = F.conv2d(xr, wr, br, stride=stride, padding=ks // 2)
-    ref = {0: ref, 1: F.leaky_relu(ref, 0.01), 3: F.gelu(ref)}[act]
-    gy = _rand(ref.shape, 4)
-    ref.backward(gy)
-
     xd, wd, bd = _dev(x, dev, grad=Cin != 3), _dev(w, dev, grad=True), _dev(b, dev, grad=True)
     y = ops.conv2d(xd, wd, bd, stride=stride, act=act)
+    ref = F.conv2d(xr, wr, br, stride=stride, padding=ks // 2)
+    if act == 1:
+        # LeakyReLU's derivative jumps at 0: a pre-activation of ~1e-8 can round to either side in two fp32 summation
+        # orders, which moves dW by |dy*x| ~ 1e-2 of its scale.  Take the branch from the kernel's own output so the
+        # comparison tests arithmetic, not the coin flip (the forward check still pins y to 2e-5).
+        ref = torch.where(y.detach().cpu() > 0, ref, 0.01 * ref)
+    else:
+        ref = {0: ref, 3: F.gelu(ref)}[act]
+    gy = _rand(ref.shape, 4)
+    ref.backward(gy)
     assert y.shape == ref.shape
     _close(y, ref, 2e-5, "conv fwd")
     y.backward(_dev(gy, dev))
