@@ -51,6 +51,7 @@ struct ConvParams {
   unsigned x_bytes, w_bytes;
   const float* xs; int ldxs, xs_act, xs_pre; unsigned xs_bytes;   // fused activation backward on the gathered operand
   int vec_epi;                 // every epilogue operand is 16-B addressable per 4 channels -> float4 epilogue
+  const float* w2; const float* bias2; int group_rows;   // rows >= group_rows (second half of the batch) use w2 / bias2
 };
 
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
@@ -154,7 +155,7 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, float acc, f
 
 // Same arithmetic, element for element, on 4 consecutive channels of one pixel (p.vec_epi: no shuffle, Cout % 4 == 0,
 // every row stride a multiple of 4 floats and every base 16-B aligned): b128 loads / stores instead of dword ones.
-__device__ __forceinline__ void epilogue_store4(const ConvParams& p, f32x4 acc, int m, int co, int DH, int DW, int ph, int pw) {
+__device__ __forceinline__ void epilogue_store4(const ConvParams& p, const float* bias, f32x4 acc, int m, int co, int DH, int DW, int ph, int pw) {
   size_t pix;
   if (p.transposed && p.stride == 2) {
     const int n = m / (DH * DW), rr = m - n * (DH * DW);
@@ -164,7 +165,7 @@ __device__ __forceinline__ void epilogue_store4(const ConvParams& p, f32x4 acc, 
     pix = (size_t)m;
   }
   f32x4 v = acc;
-  if (p.bias) { v[0] += p.bias[co]; v[1] += p.bias[co + 1]; v[2] += p.bias[co + 2]; v[3] += p.bias[co + 3]; }
+  if (bias) { v[0] += bias[co]; v[1] += bias[co + 1]; v[2] += bias[co + 2]; v[3] += bias[co + 3]; }
   else { v[0] += 0.f; v[1] += 0.f; v[2] += 0.f; v[3] += 0.f; }
   f32x4 rv = {0.f, 0.f, 0.f, 0.f};
   if (p.res) rv = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + co);
@@ -201,8 +202,11 @@ void conv_igemm_kernel(const ConvParams p) {
   const int DH = half ? p.OH / 2 : p.OH, DW = half ? p.OW / 2 : p.OW;
   const TapGrid tg = make_taps(p, ph, pw);
 
+  const bool second = p.w2 != nullptr && m0 >= p.group_rows;   // block-uniform: tiles never straddle the two batch halves
+  const float* wsel = second ? p.w2 : p.w;
+  const float* bsel = second ? p.bias2 : p.bias;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wsel), 0, p.w_bytes, 0x00020000);
 
   RowState rows[A_P];
 #pragma unroll
@@ -308,14 +312,14 @@ void conv_igemm_kernel(const ConvParams p) {
     for (int e = tid; e < BM * BN / 4; e += NT) {
       const int row = e / (BN / 4), cc = (e - row * (BN / 4)) * 4;
       const int m = m0 + row, co = n0 + cc;
-      if (m < p.M && co < p.Cout) epilogue_store4(p, *reinterpret_cast<const f32x4*>(Cs + row * LDC + cc), m, co, DH, DW, ph, pw);
+      if (m < p.M && co < p.Cout) epilogue_store4(p, bsel, *reinterpret_cast<const f32x4*>(Cs + row * LDC + cc), m, co, DH, DW, ph, pw);
     }
     return;
   }
   for (int e = tid; e < BM * BN; e += NT) {
     const int row = e / BN, cc = e - row * BN;
     const int m = m0 + row, co = n0 + cc;
-    if (m < p.M && co < p.Cout) epilogue_store(p, Cs[row * LDC + cc], p.bias ? p.bias[co] : 0.f, m, co, DH, DW, ph, pw);
+    if (m < p.M && co < p.Cout) epilogue_store(p, Cs[row * LDC + cc], bsel ? bsel[co] : 0.f, m, co, DH, DW, ph, pw);
   }
 }
 
@@ -339,8 +343,11 @@ void conv_igemm_splitk_kernel(const ConvParams p) {
   const int DH = half ? p.OH / 2 : p.OH, DW = half ? p.OW / 2 : p.OW;
   const TapGrid tg = make_taps(p, ph, pw);
 
+  const bool second = p.w2 != nullptr && m0 >= p.group_rows;   // block-uniform
+  const float* wsel = second ? p.w2 : p.w;
+  const float* bsel = second ? p.bias2 : p.bias;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wsel), 0, p.w_bytes, 0x00020000);
 
   const RowState row = make_row<TR>(p, m0 + li, DH, DW, ph, pw);
   unsigned b_row_off[TN];
@@ -420,7 +427,7 @@ void conv_igemm_splitk_kernel(const ConvParams p) {
       for (int w = 0; w < KW; ++w) q[w] = *reinterpret_cast<const f32x4*>(red + ((w * TN + j) * 16 + r) * 64 + ln);
       const f32x4 v = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
       const int m = m0 + rowi, co = n0 + cc;
-      if (m < p.M && co < p.Cout) epilogue_store4(p, v, m, co, DH, DW, ph, pw);
+      if (m < p.M && co < p.Cout) epilogue_store4(p, bsel, v, m, co, DH, DW, ph, pw);
     }
     return;
   }
@@ -432,7 +439,7 @@ void conv_igemm_splitk_kernel(const ConvParams p) {
     for (int w = 0; w < KW; ++w) q[w] = red[((w * TN + j) * 16 + r) * 64 + ln];
     const float v = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
     const int m = m0 + rowi, co = n0 + cc;
-    if (m < p.M && co < p.Cout) epilogue_store(p, v, p.bias ? p.bias[co] : 0.f, m, co, DH, DW, ph, pw);
+    if (m < p.M && co < p.Cout) epilogue_store(p, v, bsel ? bsel[co] : 0.f, m, co, DH, DW, ph, pw);
   }
 }
 
@@ -610,6 +617,14 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   int classes = 1;
   p.M = d->N * d->OH * d->OW;
   if (d->transposed && d->stride == 2) { classes = 4; p.M = d->N * (d->OH / 2) * (d->OW / 2); }
+  p.w2 = d->w2; p.bias2 = d->bias2; p.group_rows = 0;
+  if (d->w2) {   // second half of the batch on a second filter set; rows are image-major, so the halves split at M/2
+    CLC_CHECK(d->N % 2 == 0, "clc_conv2d: w2 needs an even batch (got N=%d)", d->N);
+    CLC_CHECK((d->bias == nullptr) == (d->bias2 == nullptr), "clc_conv2d: bias / bias2 must both be given or both NULL");
+    CLC_CHECK(aligned16(d->w2) && (d->Cin % 4 == 0) && (d->ldx % 4 == 0), "clc_conv2d: w2 needs the aligned (Cin %% 4 == 0) path");
+    p.group_rows = p.M / 2;
+    CLC_CHECK(p.group_rows % 128 == 0, "clc_conv2d: w2 needs (N/2)*rows-per-image to be a multiple of the largest tile (128), got %d", p.group_rows);
+  }
 
   const bool vec_ok = (d->Cin % 4 == 0) && (d->ldx % 4 == 0) && aligned16(d->x) && aligned16(d->w);
   if (!vec_ok) {

@@ -72,9 +72,11 @@ class Conv2d(nn.Conv2d):
         self.weight.data = self.weight.data.contiguous(memory_format=CL)
         self.weight._clc_is_filter = True
 
-    def forward(self, x, act=ACT_NONE, res=None, res_scale=1.0, res_first=False, shuffle=False):
+    def forward(self, x, act=ACT_NONE, res=None, res_scale=1.0, res_first=False, shuffle=False, pair=None):
+        """pair: a second Conv2d of the same shape applied to the second half of the batch in the same launch."""
         return ops.conv2d(x, self.weight, self.bias, stride=self.stride[0], act=act, res=res, res_scale=res_scale,
-                          res_first=res_first, shuffle=shuffle)
+                          res_first=res_first, shuffle=shuffle, w2=pair.weight if pair is not None else None,
+                          b2=pair.bias if pair is not None else None)
 
 
 class Linear(nn.Linear):
@@ -84,13 +86,21 @@ class Linear(nn.Linear):
         super().__init__(*a, **kw)
         self.weight._clc_is_filter = True
 
-    def forward(self, x, act=ACT_NONE, res=None):
-        return ops.linear(x, self.weight, self.bias, act=act, res=res)
+    def forward(self, x, act=ACT_NONE, res=None, pair=None):
+        return ops.linear(x, self.weight, self.bias, act=act, res=res, w2=pair.weight if pair is not None else None,
+                          b2=pair.bias if pair is not None else None)
+
+
+def _halves(x):
+    return ops.split_batch(x)   # views; the backward is one concatenation
 
 
 class LayerNorm(nn.LayerNorm):
-    def forward(self, x):
-        return ops.layernorm(x, self.weight, self.bias)
+    def forward(self, x, pair=None):
+        if pair is None:
+            return ops.layernorm(x, self.weight, self.bias)
+        a, b = _halves(x)   # per-module affine parameters: one launch per half
+        return torch.cat((ops.layernorm(a, self.weight, self.bias), ops.layernorm(b, pair.weight, pair.bias)), dim=0)
 
 
 class GELU(nn.Module):
@@ -198,10 +208,11 @@ class ResidualUnit(nn.Module):
                                   conv1x1(N // 2, N))
         self.relu = nn.ReLU(inplace=True)
 
-    def forward(self, x):
-        t = self.conv[0](x, act=ACT_RELU)
-        t = self.conv[2](t, act=ACT_RELU)
-        return self.conv[4](t, act=ACT_RELU, res=x, res_first=True)
+    def forward(self, x, pair=None):
+        q = pair.conv if pair is not None else (None,) * 5
+        t = self.conv[0](x, act=ACT_RELU, pair=q[0])
+        t = self.conv[2](t, act=ACT_RELU, pair=q[2])
+        return self.conv[4](t, act=ACT_RELU, res=x, res_first=True, pair=q[4])
 
 
 class AttentionBlock(nn.Module):
@@ -231,10 +242,16 @@ class WMSA(nn.Module):
             torch.nn.init.trunc_normal_(torch.zeros(self.n_heads, 2 * window_size - 1, 2 * window_size - 1), std=0.02))
         self.linear = Linear(input_dim, output_dim)
 
-    def forward(self, x, res=None):
-        qkv = self.embedding_layer(x)
-        a = ops.window_attention(qkv, self.relative_position_params, self.n_heads, self.window_size, self.type != "W")
-        return self.linear(a, res=res)
+    def forward(self, x, res=None, pair=None):
+        if pair is None:
+            qkv = self.embedding_layer(x)
+            a = ops.window_attention(qkv, self.relative_position_params, self.n_heads, self.window_size, self.type != "W")
+            return self.linear(a, res=res)
+        qkv = self.embedding_layer(x, pair=pair.embedding_layer)
+        q1, q2 = _halves(qkv)   # per-module relative-position tables: one attention launch per half
+        a = torch.cat((ops.window_attention(q1, self.relative_position_params, self.n_heads, self.window_size, self.type != "W"),
+                       ops.window_attention(q2, pair.relative_position_params, self.n_heads, self.window_size, self.type != "W")), dim=0)
+        return self.linear(a, res=res, pair=pair.linear)
 
 
 class Block(nn.Module):
@@ -250,10 +267,14 @@ class Block(nn.Module):
         self.ln2 = LayerNorm(input_dim)
         self.mlp = nn.Sequential(Linear(input_dim, 4 * input_dim), GELU(), Linear(4 * input_dim, output_dim))
 
-    def forward(self, x):
-        x = self.msa(self.ln1(x), res=x)
-        h = self.mlp[0](self.ln2(x), act=ACT_GELU)
-        return self.mlp[2](h, res=x)
+    def forward(self, x, pair=None):
+        if pair is None:
+            x = self.msa(self.ln1(x), res=x)
+            h = self.mlp[0](self.ln2(x), act=ACT_GELU)
+            return self.mlp[2](h, res=x)
+        x = self.msa(self.ln1(x, pair=pair.ln1), res=x, pair=pair.msa)
+        h = self.mlp[0](self.ln2(x, pair=pair.ln2), act=ACT_GELU, pair=pair.mlp[0])
+        return self.mlp[2](h, res=x, pair=pair.mlp[2])
 
 
 class ConvTransBlock(nn.Module):
@@ -280,9 +301,11 @@ class SwinBlock(nn.Module):
         self.block_2 = Block(input_dim, output_dim, head_dim, window_size, drop_path, type="SW")
         self.window_size = window_size
 
-    def forward(self, x):
+    def forward(self, x, pair=None):
         if x.size(-1) <= self.window_size or x.size(-2) <= self.window_size:
             raise ValueError("SwinBlock: feature map must be larger than the window (input must be >= 256x256)")
+        if pair is not None:
+            return self.block_2(self.block_1(x, pair=pair.block_1), pair=pair.block_2)
         return self.block_2(self.block_1(x))
 
 
@@ -298,10 +321,35 @@ class SWAtten(AttentionBlock):
             self.non_local_block = SwinBlock(input_dim, input_dim, head_dim, window_size, drop_path)
             self.in_conv = self.out_conv = None
 
-    def forward(self, x):
+    def forward(self, x, pair=None):
+        """pair: a second SWAtten of the same shape; x then holds both inputs stacked along the batch ([2B, C, H, W]) and
+        every convolution / linear of the two modules runs as ONE launch over both halves."""
+        if pair is not None:
+            if self.in_conv is not None:
+                x = self.in_conv(x, pair=pair.in_conv)
+            def branch_a():
+                a = x
+                for m, q in zip(self.conv_a, pair.conv_a):
+                    a = m(a, pair=q)
+                return a
+
+            fork_a = ops.BRANCH_STREAMS and ops.PROFILE is None and "swatten_a" in ops.BRANCH_SLOTS
+            if fork_a:   # conv_a(x) is independent of the Swin -> conv_b branch: run it on a forked stream
+                with ops.fork("swatten_a", [x]) as f:
+                    a = branch_a()
+            b = self.non_local_block(x, pair=pair.non_local_block)
+            for m, q in zip(self.conv_b, pair.conv_b):
+                b = m(b, pair=q)
+            if fork_a:
+                f.join(a)
+            else:
+                a = branch_a()
+            out = ops.gate(a, b, x)
+            return self.out_conv(out, pair=pair.out_conv) if self.out_conv is not None else out
         if self.in_conv is not None:
             x = self.in_conv(x)
-        if ops.BRANCH_STREAMS and ops.PROFILE is None and "swatten_a" in ops.BRANCH_SLOTS:
+        if ops.BRANCH_STREAMS and ops.PROFILE is None and "swatten_a" in ops.BRANCH_SLOTS and "scale" not in ops.BRANCH_SLOTS:
+            # (not inside the forked scale branch: nested forks crash hipGraph capture_end on ROCm 7.2)
             with ops.fork("swatten_a", [x]) as f:       # conv_a(x) is independent of the Swin -> conv_b branch
                 a = self.conv_a(x)
             b = self.conv_b(self.non_local_block(x))

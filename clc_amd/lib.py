@@ -28,7 +28,8 @@ class ConvDesc(C.Structure):
                 ("res", fp), ("ldr", C.c_int), ("res_scale", C.c_float),
                 ("y_pre", fp), ("ldp", C.c_int),
                 ("shuffle", C.c_int), ("res_first", C.c_int),
-                ("xs", fp), ("ldxs", C.c_int), ("xs_act", C.c_int), ("xs_pre", C.c_int)]
+                ("xs", fp), ("ldxs", C.c_int), ("xs_act", C.c_int), ("xs_pre", C.c_int),
+                ("w2", fp), ("bias2", fp)]
 
 
 class WgradDesc(C.Structure):

@@ -42,10 +42,12 @@ class SliceTransform(nn.Sequential):
     def __init__(self, cin, cout):
         super().__init__(Conv2d(cin, 224, 3), GELU(), Conv2d(224, 128, 3), GELU(), Conv2d(128, cout, 3))
 
-    def forward(self, x, final_act=ACT_NONE, res=None):
-        t = self[0](x, act=ACT_GELU)
-        t = self[2](t, act=ACT_GELU)
-        return self[4](t, act=final_act, res=res)
+    def forward(self, x, final_act=ACT_NONE, res=None, pair=None):
+        """pair: a second SliceTransform of the same shape for the second half of the batch (one launch per layer)."""
+        q = pair if pair is not None else (None,) * 5
+        t = self[0](x, act=ACT_GELU, pair=q[0])
+        t = self[2](t, act=ACT_GELU, pair=q[2])
+        return self[4](t, act=final_act, res=res, pair=q[4])
 
 
 class PointwiseMLP(nn.Sequential):
@@ -151,8 +153,26 @@ class _SliceCodec(CompressionModel):
     def _ref(self, ref_frames):
         return None
 
-    def _slice_params(self, i, latent_means, latent_scales, y_hat_slices, ref_features, y_shape):
+    def _slice_params(self, i, latent_means, latent_scales, y_hat_slices, ref_features, y_shape, ref_pair=None):
         support = y_hat_slices if self.max_support_slices < 0 else y_hat_slices[: self.max_support_slices]
+        rows = latent_means.shape[0] * latent_means.shape[2] * latent_means.shape[3]
+        if ops.PAIR_SLICES and rows % 128 == 0:   # (the paired launch needs the batch halves to fall on tile boundaries)
+            # The mean- and the scale-parameter nets are the same architecture on different inputs: stack the inputs along
+            # the batch and run every layer of the two nets as ONE launch (second half of the batch on the second net's
+            # filters).  These 16x16-map layers are latency-bound: twice the rows cost about the same time.
+            both = torch.cat((torch.cat([latent_means] + support, dim=1), torch.cat([latent_scales] + support, dim=1)), dim=0)
+            both = self.atten_mean[i][0](both, pair=self.atten_scale[i][0])
+            mean_support, _ = ops.split_batch(both)
+            if ref_features is not None:
+                if ref_pair is None:
+                    ref_pair = torch.cat((ref_features, ref_features), dim=0)
+                ps = self.ref_cc_mean_transforms[i](torch.cat((both, ref_pair), dim=1), pair=self.ref_cc_scale_transforms[i])
+            else:
+                ps = self.cc_mean_transforms[i](both, pair=self.cc_scale_transforms[i])
+            mu, scale = ops.split_batch(ps)
+            if mu.shape[2] != y_shape[0] or mu.shape[3] != y_shape[1]:
+                mu, scale = mu[:, :, : y_shape[0], : y_shape[1]], scale[:, :, : y_shape[0], : y_shape[1]]
+            return mean_support, mu, scale
 
         def scale_branch():
             ss = self.atten_scale[i](torch.cat([latent_scales] + support, dim=1))
@@ -199,8 +219,9 @@ class _SliceCodec(CompressionModel):
         latent_scales = self.h_scale_s(z_hat)
         latent_means = self.h_mean_s(z_hat)
         y_hat_slices, y_lik, mus, scales = [], [], [], []
+        ref_pair = torch.cat((ref_features, ref_features), dim=0) if (ref_features is not None and ops.PAIR_SLICES) else None
         for i, y_slice in enumerate(ops.split_channels(y, [y.shape[1] // self.num_slices] * self.num_slices)):
-            mean_support, mu, scale = self._slice_params(i, latent_means, latent_scales, y_hat_slices, ref_features, y_shape)
+            mean_support, mu, scale = self._slice_params(i, latent_means, latent_scales, y_hat_slices, ref_features, y_shape, ref_pair)
             mus.append(mu)
             scales.append(scale)
             lik, y_hat_slice = self.gaussian_conditional.likelihood_and_ste(y_slice, scale, mu)

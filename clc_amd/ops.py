@@ -50,7 +50,12 @@ def flush_wgrads():
     if not _PENDING:
         return
     arr = (_lib.WgradDesc * len(_PENDING))(*[d for d, _ in _PENDING])
-    with torch.cuda.stream(WGRAD_STREAM):
+    if os.environ.get("CLC_WGRAD_SERIAL", "0") == "1":   # analysis knob: run the groups in line with the data-gradient chain
+        torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
+        stream_ctx = torch.cuda.stream(torch.cuda.current_stream())
+    else:
+        stream_ctx = torch.cuda.stream(WGRAD_STREAM)
+    with stream_ctx:
         if PROFILE is None:
             _lib.check(_L().clc_conv2d_wgrad_batched(arr, len(_PENDING), _stream()), "clc_conv2d_wgrad_batched")
         else:
@@ -76,6 +81,9 @@ def join_side_streams():
 # branches overlap on the 256 CUs; under hipGraph capture the fork/join becomes parallel graph branches. Autograd runs
 # each op's backward on the stream of its forward, so the backward overlaps the same way.
 BRANCH_STREAMS = False
+# Paired layers: the mean- and scale-parameter nets of a slice run as one launch per layer over a stacked batch (CLC_PAIR=0:
+# two launches, optionally on forked streams).
+PAIR_SLICES = int(os.environ.get("CLC_PAIR", "0"))   # measured neutral against the forked-stream default (163 vs 165 img/s)
 BRANCH_SLOTS = set(os.environ.get("CLC_BRANCH", "scale").split(","))   # which forks are taken (debug knob)
 _BRANCH_POOL = {}
 
@@ -181,7 +189,7 @@ def to_kernel_weight(w: torch.Tensor) -> torch.Tensor:
 
 def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_NONE, norm=NORM_NONE, mul=None,
              res=None, res_scale=1.0, res_first=False, y_pre=None, shuffle=False, transposed=False, out=None, out_hw=None,
-             xs=None, xs_act=ACT_NONE, xs_pre=False):
+             xs=None, xs_act=ACT_NONE, xs_pre=False, w2=None, bias2=None):
     """One clc_conv2d launch. ``w`` must already be in kernel layout [Cout][ks][ks][Cin]."""
     _require_gpu(x, "conv2d")
     x, xp, N, H, W, Cin, ldx = nhwc(x)
@@ -203,6 +211,9 @@ def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_
     d.ks, d.stride, d.pad = ks, stride, pad
     d.transposed, d.in_op, d.act, d.norm, d.shuffle = int(transposed), in_op, act, norm, int(shuffle)
     keep = [x, w, bias, out]
+    if w2 is not None:   # second half of the batch on a second filter set (paired layers)
+        d.w2 = w2.data_ptr()
+        d.bias2 = bias2.data_ptr() if bias2 is not None else None
     if mul is not None:
         m, mp, *_r, ldm = nhwc(mul)
         d.mul, d.ldm = mp, ldm
@@ -319,11 +330,13 @@ def act_bwd(dy, saved, use_pre, act):
 
 
 class _ConvFn(Function):
-    """y = act(conv(x, w) + b) + res_scale * res, optionally PixelShuffle(2)-stored."""
+    """y = act(conv(x, w) + b) + res_scale * res, optionally PixelShuffle(2)-stored.  With (w2, b2) the second half of
+    the batch is convolved with the second filter set in the same launch (paired layers)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, res, ks, stride, act, res_scale, shuffle, res_first):
+    def forward(ctx, x, w, b, res, ks, stride, act, res_scale, shuffle, res_first, w2=None, b2=None):
         wk = to_kernel_weight(w)
+        wk2 = to_kernel_weight(w2) if w2 is not None else None
         need_grad = any(ctx.needs_input_grad)
         # the activation derivative needs the pre-activation whenever the output does not determine it
         save_pre = need_grad and (act == ACT_GELU or (act in (ACT_LRELU, ACT_RELU, ACT_HALFTANH) and res is not None and not res_first))
@@ -334,18 +347,43 @@ class _ConvFn(Function):
         y_pre = None
         if save_pre:
             y_pre = new_act(N, Cout // 4, 2 * OH, 2 * OW, x) if shuffle else new_act(N, Cout, OH, OW, x)
-        y = conv_raw(x, wk, b, ks=ks, stride=stride, act=act, res=res, res_scale=res_scale, res_first=res_first, y_pre=y_pre, shuffle=shuffle)
+        y = conv_raw(x, wk, b, ks=ks, stride=stride, act=act, res=res, res_scale=res_scale, res_first=res_first, y_pre=y_pre, shuffle=shuffle,
+                     w2=wk2, bias2=b2)
         ctx.cfg = (ks, stride, act, res_scale, shuffle, b is not None, res is not None, res_first)
         saved_act = y_pre if save_pre else (y if act in (ACT_LRELU, ACT_RELU, ACT_HALFTANH) else None)
         ctx.use_pre = save_pre
         ctx.bias_ref = b
+        ctx.pair = (w2, b2)
         ctx.save_for_backward(x, w, saved_act)
         return y
+
+    @staticmethod
+    def _wgrad(x, dz, w, bias_ref, has_b, need_w, need_b, ks, stride, pad, fw):
+        """filter / bias gradient of one filter set: straight into the gradient arena when possible (returns None, None)."""
+        Cout, Cin = w.shape[0], w.shape[1]
+        gw, gb = _direct_grad(w), (_direct_grad(bias_ref) if has_b else None)
+        if gw is not None and (gb is not None or not has_b) and to_kernel_weight(w) is w:
+            # write straight into the persistent gradient arena (accumulate) — no temporary, no autograd add kernel
+            if WGRAD_STREAM is not None and (PROFILE is None or WGRAD_GROUP > 1):
+                if WGRAD_GROUP > 1:
+                    wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb, defer=True, **fw)
+                else:
+                    cur = torch.cuda.current_stream()
+                    WGRAD_STREAM.wait_stream(cur)
+                    _KEEPALIVE.append((x, dz, fw.get("dys")))
+                    with torch.cuda.stream(WGRAD_STREAM):
+                        wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb, **fw)
+            else:
+                wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb, **fw)
+            return None, None
+        dwf, db = wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=need_b, **fw)
+        return (_dw_to_param_layout(dwf, w) if need_w else None), db
 
     @staticmethod
     def backward(ctx, dy):
         ks, stride, act, res_scale, shuffle, has_b, has_res, res_first = ctx.cfg
         x, w, saved_act = ctx.saved_tensors
+        w2, b2 = ctx.pair
         Cout, Cin = w.shape[0], w.shape[1]
         need_x, need_w, need_b, need_res = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_b and ctx.needs_input_grad[2], has_res and ctx.needs_input_grad[3]
         # the activation derivative is applied inside the data-/weight-gradient kernels' loaders (no dz tensor, no extra
@@ -354,52 +392,72 @@ class _ConvFn(Function):
         fuse = act in (ACT_LRELU, ACT_RELU) and not shuffle and not (need_res and res_first)
         dz = dy if (act == ACT_NONE or fuse) else act_bwd(dy, saved_act, ctx.use_pre, act)
         fa = dict(xs=saved_act, xs_act=act, xs_pre=ctx.use_pre) if fuse else {}
-        fw = dict(dys=saved_act, dys_act=act, dys_pre=ctx.use_pre) if fuse else {}
         dres = None
         if need_res:
             dsrc = dz if res_first else dy  # residual added before / after the activation
             dres = dsrc if res_scale == 1.0 else dsrc * res_scale
         if shuffle:  # undo PixelShuffle(2): [N, C/4, 2H, 2W] -> [N, C, H, W] (strided copy; TODO fuse into the gathers)
             dz = torch.nn.functional.pixel_unshuffle(dz, 2).contiguous(memory_format=CL)
-        dx = dw = db = None
+        dx = dw = db = dw2 = db2 = None
         pad = ks // 2
         if need_w or need_b:
-            gw, gb = _direct_grad(w), (_direct_grad(ctx.bias_ref) if has_b else None)
-            if gw is not None and (gb is not None or not has_b) and to_kernel_weight(w) is w:
-                # write straight into the persistent gradient arena (accumulate) — no temporary, no autograd add kernel
-                if WGRAD_STREAM is not None and (PROFILE is None or WGRAD_GROUP > 1):
-                    if WGRAD_GROUP > 1:
-                        wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb, defer=True, **fw)
-                    else:
-                        cur = torch.cuda.current_stream()
-                        WGRAD_STREAM.wait_stream(cur)
-                        _KEEPALIVE.append((x, dz, saved_act))
-                        with torch.cuda.stream(WGRAD_STREAM):
-                            wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb, **fw)
-                else:
-                    wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb, **fw)
-            else:
-                dwf, db = wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=need_b, **fw)
-                dw = _dw_to_param_layout(dwf, w) if need_w else None
+            if w2 is None:
+                fw = dict(dys=saved_act, dys_act=act, dys_pre=ctx.use_pre) if fuse else {}
+                dw, db = _ConvFn._wgrad(x, dz, w, ctx.bias_ref, has_b, need_w, need_b, ks, stride, pad, fw)
+            else:   # one problem per filter set, on its half of the batch
+                h = x.shape[0] // 2
+                fw1 = dict(dys=saved_act[:h], dys_act=act, dys_pre=ctx.use_pre) if fuse else {}
+                fw2 = dict(dys=saved_act[h:], dys_act=act, dys_pre=ctx.use_pre) if fuse else {}
+                dw, db = _ConvFn._wgrad(x[:h], dz[:h], w, ctx.bias_ref, has_b, need_w, need_b, ks, stride, pad, fw1)
+                dw2, db2 = _ConvFn._wgrad(x[h:], dz[h:], w2, b2, has_b, need_w, need_b, ks, stride, pad, fw2)
         if need_x:
-            wt = getattr(w, "_clc_wt", None)   # refreshed once per step by the batched transpose (clc_amd.train)
-            if wt is None:
-                wt = filter_transpose(to_kernel_weight(w), Cout, ks * ks, Cin)
-            dx = conv_raw(dz, wt.view(Cin, -1), None, ks=ks, stride=stride, pad=pad, transposed=True, out_hw=(x.shape[2], x.shape[3]), **fa)
-        return dx, dw, db, dres, None, None, None, None, None, None
+            def wt_of(wp):
+                wt = getattr(wp, "_clc_wt", None)   # refreshed once per step by the batched transpose (clc_amd.train)
+                if wt is None:
+                    wt = filter_transpose(to_kernel_weight(wp), Cout, ks * ks, Cin)
+                return wt.view(Cin, -1)
+            dx = conv_raw(dz, wt_of(w), None, ks=ks, stride=stride, pad=pad, transposed=True, out_hw=(x.shape[2], x.shape[3]),
+                          w2=(wt_of(w2) if w2 is not None else None), **fa)
+        return dx, dw, db, dres, None, None, None, None, None, None, dw2, db2
 
 
-def conv2d(x, w, b=None, *, stride=1, act=ACT_NONE, res=None, res_scale=1.0, shuffle=False, res_first=False):
+def conv2d(x, w, b=None, *, stride=1, act=ACT_NONE, res=None, res_scale=1.0, shuffle=False, res_first=False, w2=None, b2=None):
     ks = w.shape[2] if w.dim() == 4 else 1
-    return _ConvFn.apply(x, w, b, res, ks, stride, act, float(res_scale), bool(shuffle), bool(res_first))
+    return _ConvFn.apply(x, w, b, res, ks, stride, act, float(res_scale), bool(shuffle), bool(res_first), w2, b2)
 
 
-def linear(x, w, b=None, *, act=ACT_NONE, res=None):
+def linear(x, w, b=None, *, act=ACT_NONE, res=None, w2=None, b2=None):
     """nn.Linear on channels (tokens are pixels): x [N,Cin,H,W] pixel-major, w [Cout,Cin]."""
-    return _ConvFn.apply(x, w, b, res, 1, 1, act, 1.0, False, False)
+    return _ConvFn.apply(x, w, b, res, 1, 1, act, 1.0, False, False, w2, b2)
 
 
 # ----------------------------------------------------------------------------------- split / chunk
+
+
+class _SplitBatchFn(Function):
+    """x [2B, ...] -> (x[:B], x[B:]) as views; the backward is ONE concatenation (autograd's own slice backward would
+    zero-fill two full-size tensors and add them)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        h = x.shape[0] // 2
+        ctx.meta = (x.shape, x.dtype, x.device)
+        return x[:h], x[h:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        shape, dtype, device = ctx.meta
+        h = shape[0] // 2
+        if ga is None:
+            ga = torch.zeros((h,) + tuple(shape[1:]), dtype=dtype, device=device).contiguous(memory_format=CL)
+        if gb is None:
+            gb = torch.zeros((shape[0] - h,) + tuple(shape[1:]), dtype=dtype, device=device).contiguous(memory_format=CL)
+        return torch.cat((ga, gb), dim=0)
+
+
+def split_batch(x):
+    return _SplitBatchFn.apply(x)
+
 
 
 class _SplitFn(Function):

@@ -75,6 +75,11 @@ typedef struct {
   /* optional fused activation backward on the gathered operand: x <- x * act'(xs) with xs the saved
    * pre-activation (xs_pre = 1) or activation output of the layer whose gradient x is (same geometry as x) */
   const float* xs; int ldxs; int xs_act; int xs_pre;
+  /* optional second filter set: images [N/2, N) of the batch are convolved with w2 / bias2 (same geometry as w / bias),
+   * images [0, N/2) with w / bias.  Two same-shaped layers that run side by side on different data (the mean- and the
+   * scale-parameter nets of a slice, CLC_run.py:560-566) become ONE launch with twice the rows — the 16x16-map layers
+   * are latency-bound, so the second one is nearly free.  NULL = ordinary convolution; N must be even. */
+  const float* w2; const float* bias2;
 } clc_conv_desc;
 
 int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream);

@@ -133,6 +133,32 @@ def test_conv_fwd_bwd(dev, case, act):
         _close(xd.grad, xr.grad, 1e-4, "conv dgrad")
 
 
+@pytest.mark.parametrize("case", [(8, 64, 16, 16, 64, 3), (8, 128, 16, 16, 64, 1), (2, 448, 16, 16, 224, 3), (2, 64, 64, 64, 128, 3), (4, 64, 32, 32, 64, 1)])
+def test_conv_paired_filters(dev, case):
+    """w2/bias2: the second half of the batch on a second filter set in the same launch == two separate launches, bit
+    for bit (forward, data gradient, both filter gradients), for both kernel families."""
+    from clc_amd import ops
+
+    N, Cin, H, W, Cout, ks = case
+    h = N // 2
+    x = _rand((N, Cin, H, W), 1)
+    w1, w2 = _rand((Cout, Cin, ks, ks), 2, 0.05), _rand((Cout, Cin, ks, ks), 3, 0.05)
+    b1, b2 = _rand((Cout,), 4, 0.1), _rand((Cout,), 5, 0.1)
+    gy = _rand((N, Cout, H, W), 6)
+    for act in (0, 1, 3):
+        xs, ws = _dev(x, dev, grad=True), [_dev(t, dev, grad=True) for t in (w1, b1, w2, b2)]
+        ya = ops.conv2d(xs[:h], ws[0], ws[1], act=act)
+        yb = ops.conv2d(xs[h:], ws[2], ws[3], act=act)
+        torch.cat((ya, yb), 0).backward(_dev(gy, dev))
+        xp, wp = _dev(x, dev, grad=True), [_dev(t, dev, grad=True) for t in (w1, b1, w2, b2)]
+        yp = ops.conv2d(xp, wp[0], wp[1], act=act, w2=wp[2], b2=wp[3])
+        yp.backward(_dev(gy, dev))
+        assert torch.equal(yp[:h], ya) and torch.equal(yp[h:], yb), f"act {act}: paired forward differs"
+        assert torch.equal(xp.grad, xs.grad), f"act {act}: paired data gradient differs"
+        for a, b, name in zip(wp, ws, ("w", "b", "w2", "b2")):
+            assert torch.equal(a.grad, b.grad), f"act {act}: paired {name} gradient differs"
+
+
 def test_conv_residual_slice_shuffle(dev):
     from clc_amd import ops
 

@@ -19,6 +19,11 @@ SHAPES = [  # name, N, Cin, H, W, Cout, ks, stride
     ("c64_64_3x3_16", 8, 64, 16, 16, 64, 3, 1),
     ("c128_64_1x1_16", 8, 128, 16, 16, 64, 1, 1),
     ("c128_128_3x3_32", 8, 128, 32, 32, 128, 3, 1),
+    ("n16_c64_64_3x3_16", 16, 64, 16, 16, 64, 3, 1),
+    ("n16_c128_64_1x1_16", 16, 128, 16, 16, 64, 1, 1),
+    ("n16_c448_224_3x3_16", 16, 448, 16, 16, 224, 3, 1),
+    ("n16_c224_128_3x3_16", 16, 224, 16, 16, 128, 3, 1),
+    ("c224_128_3x3_16", 8, 224, 16, 16, 128, 3, 1),
 ]
 g = torch.Generator().manual_seed(0)
 for name, N, Cin, H, W, Cout, ks, s in SHAPES:
