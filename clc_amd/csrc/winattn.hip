@@ -48,13 +48,19 @@ __device__ __forceinline__ bool masked(const AttnParams& p, int wy, int wx, int 
 // array per lane: keeps the kernel in registers (no scratch) at the price of computing q.k twice.
 template <int T, int HD>
 __global__ __launch_bounds__(64) void winattn_fwd_kernel(const AttnParams p) {
-  constexpr int G = 64 / T, WS = (T == 64) ? 8 : 4, LDK = HD + 1;
-  __shared__ float Ks[G][T][LDK], Vs[G][T][LDK], Bias[(2 * WS - 1) * (2 * WS - 1)];
+  // K / V rows are read as BROADCASTS (every lane of a window reads the same key row), so rows are packed (LDK = HD,
+  // 16-B aligned): one ds_read_b128 feeds 4 FMAs — the b32-per-FMA version was LDS-issue-bound (220 us at 128x128).
+  constexpr int G = 64 / T, WS = (T == 64) ? 8 : 4, LDK = HD, NBW = 2 * WS - 1;
+  __shared__ __attribute__((aligned(16))) float Ks[G][T][LDK], Vs[G][T][LDK];
+  __shared__ float Bias[NBW * NBW];
   const int lane = threadIdx.x, g = lane / T, t = lane % T, ty = t / WS, tx = t % WS;
   const int head = blockIdx.y;
   const float scale = rsqrtf((float)HD);
-  for (int i = lane; i < (2 * WS - 1) * (2 * WS - 1); i += 64) Bias[i] = p.relbias[head * (2 * WS - 1) * (2 * WS - 1) + i];
+  for (int i = lane; i < NBW * NBW; i += 64) Bias[i] = p.relbias[head * NBW * NBW + i];
   const int nwin = p.nwin_y * p.nwin_x;
+  const float* bias_t = Bias + (ty + WS - 1) * NBW + (tx + WS - 1);   // Bias[(ty-ky+WS-1)*NBW + tx-kx+WS-1] = bias_t[-(ky*NBW+kx)]
+  const int sgap = WS - WS / 2;
+  const bool q_lo_y = ty < sgap, q_lo_x = tx < sgap;
   for (int gi = 0; gi < p.groups_per_block; ++gi) {
     const int grp = blockIdx.x * p.groups_per_block + gi;
     if (grp >= p.groups_total) break;
@@ -63,43 +69,59 @@ __global__ __launch_bounds__(64) void winattn_fwd_kernel(const AttnParams p) {
     const int b = widx / nwin, wr = widx - b * nwin, wy = wr / p.nwin_x, wx = wr - wy * p.nwin_x;
     const int pix = token_pixel(p, b, wy, wx, ty, tx);
     const size_t row = (size_t)pix * p.ldq;
-    float q[HD];
+    const bool edge_y = p.shift && wy == p.nwin_y - 1, edge_x = p.shift && wx == p.nwin_x - 1;
+    f32x4 q[HD / 4];
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < HD; c += 4) {
-      const f32x4 qv = *reinterpret_cast<const f32x4*>(p.qkv + row + head * HD + c);
-      const f32x4 kv = *reinterpret_cast<const f32x4*>(p.qkv + row + p.C + head * HD + c);
-      const f32x4 vv = *reinterpret_cast<const f32x4*>(p.qkv + row + 2 * p.C + head * HD + c);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { q[c + e] = qv[e] * scale; Ks[g][t][c + e] = kv[e]; Vs[g][t][c + e] = vv[e]; }
+      q[c / 4] = *reinterpret_cast<const f32x4*>(p.qkv + row + head * HD + c) * scale;
+      *reinterpret_cast<f32x4*>(&Ks[g][t][c]) = *reinterpret_cast<const f32x4*>(p.qkv + row + p.C + head * HD + c);
+      *reinterpret_cast<f32x4*>(&Vs[g][t][c]) = *reinterpret_cast<const f32x4*>(p.qkv + row + 2 * p.C + head * HD + c);
     }
     __syncthreads();
-    auto score = [&](int j) -> float {
+    // keys as (ky, kx): kx is unrolled (compile-time), ky is a scalar loop counter -> the bias offset and the mask's key
+    // side are scalar / immediate, and the register footprint stays that of one key row (full unrolling of all T keys
+    // lets the scheduler hoist every LDS read: 250 VGPRs)
+    auto score = [&](int ky, int kx) -> float {
+      const int j = ky * WS + kx;
       float a = 0.f;
 #pragma unroll
-      for (int c = 0; c < HD; ++c) a = fmaf(q[c], Ks[g][j][c], a);
-      const int ky = j / WS, kx = j % WS;
-      a += Bias[(ty - ky + WS - 1) * (2 * WS - 1) + (tx - kx + WS - 1)];
-      return masked(p, wy, wx, ty, tx, ky, kx) ? -INFINITY : a;
+      for (int c = 0; c < HD; c += 4) {
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(&Ks[g][j][c]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a = fmaf(q[c / 4][e], kv[e], a);
+      }
+      a += bias_t[-(ky * NBW + kx)];
+      const bool m = (edge_y && (q_lo_y != (ky < sgap))) || (edge_x && (q_lo_x != (kx < sgap)));
+      return m ? -INFINITY : a;
     };
     float mx = -INFINITY;
-#pragma unroll 4
-    for (int j = 0; j < T; ++j) mx = fmaxf(mx, score(j));
-    float l = 0.f, o[HD];
+#pragma unroll 1
+    for (int ky = 0; ky < WS; ++ky)
 #pragma unroll
-    for (int c = 0; c < HD; ++c) o[c] = 0.f;
-#pragma unroll 4
-    for (int j = 0; j < T; ++j) {
-      const float e = expf(score(j) - mx);
-      l += e;
+      for (int kx = 0; kx < WS; ++kx) mx = fmaxf(mx, score(ky, kx));
+    float l = 0.f;
+    f32x4 o[HD / 4];
 #pragma unroll
-      for (int c = 0; c < HD; ++c) o[c] = fmaf(e, Vs[g][j][c], o[c]);
-    }
+    for (int c = 0; c < HD / 4; ++c) o[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ky = 0; ky < WS; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < WS; ++kx) {
+        const float e = expf(score(ky, kx) - mx);
+        l += e;
+#pragma unroll
+        for (int c = 0; c < HD; c += 4) {
+          const f32x4 vv = *reinterpret_cast<const f32x4*>(&Vs[g][ky * WS + kx][c]);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[c / 4][k] = fmaf(e, vv[k], o[c / 4][k]);
+        }
+      }
     const float inv = 1.f / l;
     if (wvalid) {
       float* op = p.out + (size_t)pix * p.ldo + head * HD;
 #pragma unroll
-      for (int c = 0; c < HD; c += 4) *reinterpret_cast<f32x4*>(op + c) = (f32x4){o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv};
+      for (int c = 0; c < HD; c += 4) *reinterpret_cast<f32x4*>(op + c) = o[c / 4] * inv;
       if (p.lse) p.lse[(size_t)pix * p.heads + head] = mx + logf(l);
     }
   }
@@ -108,16 +130,27 @@ __global__ __launch_bounds__(64) void winattn_fwd_kernel(const AttnParams p) {
 // Backward. Inputs: qkv, the forward output `out` (for D = dO.O), lse = log-sum-exp per (token, head).
 template <int T, int HD>
 __global__ __launch_bounds__(64) void winattn_bwd_kernel(const AttnParams p) {
-  constexpr int G = 64 / T, WS = (T == 64) ? 8 : 4, LDK = HD + 1, NB = (2 * WS - 1) * (2 * WS - 1);
-  __shared__ float Qs[G][T][LDK], Ks[G][T][LDK], Vs[G][T][LDK], Ds[G][T][LDK];
+  constexpr int G = 64 / T, WS = (T == 64) ? 8 : 4, LDK = HD, NBW = 2 * WS - 1, NB = NBW * NBW;   // packed rows: b128 broadcasts
+  constexpr int UNR = HD == 8 ? 4 : (HD == 16 ? 2 : 1);   // keys per unrolled group (register pressure: each key holds 2*HD operand floats)
+  __shared__ __attribute__((aligned(16))) float Qs[G][T][LDK], Ks[G][T][LDK], Vs[G][T][LDK], Ds[G][T][LDK];
   __shared__ float Lse[G][T], Dd[G][T], Bias[NB];
-  __shared__ float AccS[G][T][T + 1];   // sum over this workgroup's windows of dS (rows owned by one lane each)
+  // relative-bias gradient bins of this workgroup: for a fixed key the 64 query lanes hit 64 DISTINCT bins (bin = q - k), so a
+  // plain LDS read-modify-write per key is race-free and its order (windows, then keys) is fixed -> reproducible without a
+  // [T][T] dS buffer (16.6 KB per wave, which capped the kernel at 6 waves per CU)
+  __shared__ float BinAcc[G][NB];
   const int lane = threadIdx.x, g = lane / T, t = lane % T, ty = t / WS, tx = t % WS;
   const int head = blockIdx.y;
   const float scale = rsqrtf((float)HD);
   for (int i = lane; i < NB; i += 64) Bias[i] = p.relbias[head * NB + i];
-  for (int j = 0; j < T; ++j) AccS[g][t][j] = 0.f;
+  for (int i = lane; i < G * NB; i += 64) (&BinAcc[0][0])[i] = 0.f;
   const int nwin = p.nwin_y * p.nwin_x;
+  const float* bias_q = Bias + (ty + WS - 1) * NBW + (tx + WS - 1);   // lane = query: Bias[q - k] = bias_q[-(ky*NBW+kx)]
+  const float* bias_k = Bias + (WS - 1 - ty) * NBW + (WS - 1 - tx);   // lane = key:   Bias[q - k] = bias_k[+(qy*NBW+qx)]
+  // volatile: the read-modify-writes of successive keys alias ACROSS lanes (lane A's bin for key j is lane B's bin for key
+  // j+1), which per-thread alias analysis cannot see — keep them in program order
+  volatile float* bin_q = &BinAcc[g][(ty + WS - 1) * NBW + (tx + WS - 1)];
+  const int sgap = WS - WS / 2;
+  const bool lo_y = ty < sgap, lo_x = tx < sgap;
   for (int gi = 0; gi < p.groups_per_block; ++gi) {
     const int grp = blockIdx.x * p.groups_per_block + gi;
     if (grp >= p.groups_total) break;
@@ -126,100 +159,126 @@ __global__ __launch_bounds__(64) void winattn_bwd_kernel(const AttnParams p) {
     const int b = widx / nwin, wr = widx - b * nwin, wy = wr / p.nwin_x, wx = wr - wy * p.nwin_x;
     const int pix = token_pixel(p, b, wy, wx, ty, tx);
     const size_t row = (size_t)pix * p.ldq;
-    float q[HD], d_o[HD];
+    const bool edge_y = p.shift && wy == p.nwin_y - 1, edge_x = p.shift && wx == p.nwin_x - 1;
+    f32x4 q[HD / 4], d_o[HD / 4];
     float dsum = 0.f;
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < HD; c += 4) {
-      const f32x4 qv = *reinterpret_cast<const f32x4*>(p.qkv + row + head * HD + c);
+      const f32x4 qv = *reinterpret_cast<const f32x4*>(p.qkv + row + head * HD + c) * scale;
       const f32x4 kv = *reinterpret_cast<const f32x4*>(p.qkv + row + p.C + head * HD + c);
       const f32x4 vv = *reinterpret_cast<const f32x4*>(p.qkv + row + 2 * p.C + head * HD + c);
       const f32x4 dv = *reinterpret_cast<const f32x4*>(p.dout + (size_t)pix * p.lddo + head * HD + c);
       const f32x4 ov = *reinterpret_cast<const f32x4*>(p.out + (size_t)pix * p.ldo + head * HD + c);
+      q[c / 4] = qv; d_o[c / 4] = dv;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        q[c + e] = qv[e] * scale; d_o[c + e] = dv[e];
-        dsum = fmaf(dv[e], ov[e], dsum);
-        Qs[g][t][c + e] = qv[e] * scale; Ks[g][t][c + e] = kv[e]; Vs[g][t][c + e] = vv[e]; Ds[g][t][c + e] = dv[e];
-      }
+      for (int e = 0; e < 4; ++e) dsum = fmaf(dv[e], ov[e], dsum);
+      *reinterpret_cast<f32x4*>(&Qs[g][t][c]) = qv; *reinterpret_cast<f32x4*>(&Ks[g][t][c]) = kv;
+      *reinterpret_cast<f32x4*>(&Vs[g][t][c]) = vv; *reinterpret_cast<f32x4*>(&Ds[g][t][c]) = dv;
     }
     const float lse = p.lse[(size_t)pix * p.heads + head];
     Lse[g][t] = lse; Dd[g][t] = dsum;
     __syncthreads();
     // ---- pass 1: lane = query row -> dQ and this row of dS (for the relative-bias gradient) ----
-    float dq[HD];
+    f32x4 dq[HD / 4];
 #pragma unroll
-    for (int c = 0; c < HD; ++c) dq[c] = 0.f;
-#pragma unroll 4
-    for (int j = 0; j < T; ++j) {
-      float a = 0.f, dp = 0.f;
+    for (int c = 0; c < HD / 4; ++c) dq[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ky = 0; ky < WS; ++ky)
+#pragma unroll 1
+      for (int kx0 = 0; kx0 < WS; kx0 += UNR)
 #pragma unroll
-      for (int c = 0; c < HD; ++c) { a = fmaf(q[c], Ks[g][j][c], a); dp = fmaf(d_o[c], Vs[g][j][c], dp); }
-      const int ky = j / WS, kx = j % WS;
-      a += Bias[(ty - ky + WS - 1) * (2 * WS - 1) + (tx - kx + WS - 1)];
-      const float pj = masked(p, wy, wx, ty, tx, ky, kx) ? 0.f : expf(a - lse);
-      const float ds = pj * (dp - dsum);
-      AccS[g][t][j] += wvalid ? ds : 0.f;
+      for (int u = 0; u < UNR; ++u) {
+        const int kx = kx0 + u, j = ky * WS + kx;
+        float a = 0.f, dp = 0.f;
+        f32x4 kr[HD / 4];
 #pragma unroll
-      for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, Ks[g][j][c], dq[c]);
-    }
+        for (int c = 0; c < HD; c += 4) {
+          kr[c / 4] = *reinterpret_cast<const f32x4*>(&Ks[g][j][c]);
+          const f32x4 vr = *reinterpret_cast<const f32x4*>(&Vs[g][j][c]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { a = fmaf(q[c / 4][e], kr[c / 4][e], a); dp = fmaf(d_o[c / 4][e], vr[e], dp); }
+        }
+        a += bias_q[-(ky * NBW + kx)];
+        const bool m = (edge_y && (lo_y != (ky < sgap))) || (edge_x && (lo_x != (kx < sgap)));
+        const float pj = m ? 0.f : expf(a - lse);
+        const float ds = pj * (dp - dsum);
+        bin_q[-(ky * NBW + kx)] = bin_q[-(ky * NBW + kx)] + (wvalid ? ds : 0.f);
+#pragma unroll
+        for (int c = 0; c < HD / 4; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dq[c][e] = fmaf(ds, kr[c][e], dq[c][e]);
+      }
     if (wvalid) {
       float* dqp = p.dqkv + (size_t)pix * p.lddq + head * HD;
 #pragma unroll
-      for (int c = 0; c < HD; c += 4)
-        *reinterpret_cast<f32x4*>(dqp + c) = (f32x4){dq[c] * scale, dq[c + 1] * scale, dq[c + 2] * scale, dq[c + 3] * scale};
+      for (int c = 0; c < HD; c += 4) *reinterpret_cast<f32x4*>(dqp + c) = dq[c / 4] * scale;
     }
     // ---- pass 2: lane = key column. dV = sum_i P[i][t] dO[i]; dK = sum_i dS[i][t] q_i ----
-    float kk[HD], vv2[HD], dk[HD], dvv[HD];
+    f32x4 kk[HD / 4], vv2[HD / 4], dk[HD / 4], dvv[HD / 4];
 #pragma unroll
-    for (int c = 0; c < HD; ++c) { kk[c] = Ks[g][t][c]; vv2[c] = Vs[g][t][c]; dk[c] = 0.f; dvv[c] = 0.f; }
-#pragma unroll 2
-    for (int i = 0; i < T; ++i) {
-      const int qy = i / WS, qx = i % WS;
-      float a = 0.f, dpv = 0.f;
-#pragma unroll
-      for (int c = 0; c < HD; ++c) { a = fmaf(Qs[g][i][c], kk[c], a); dpv = fmaf(Ds[g][i][c], vv2[c], dpv); }
-      a += Bias[(qy - ty + WS - 1) * (2 * WS - 1) + (qx - tx + WS - 1)];
-      const float pij = masked(p, wy, wx, qy, qx, ty, tx) ? 0.f : expf(a - Lse[g][i]);
-      const float ds = pij * (dpv - Dd[g][i]);
-#pragma unroll
-      for (int c = 0; c < HD; ++c) { dvv[c] = fmaf(pij, Ds[g][i][c], dvv[c]); dk[c] = fmaf(ds, Qs[g][i][c], dk[c]); }
+    for (int c = 0; c < HD / 4; ++c) {
+      kk[c] = *reinterpret_cast<const f32x4*>(&Ks[g][t][c * 4]); vv2[c] = *reinterpret_cast<const f32x4*>(&Vs[g][t][c * 4]);
+      dk[c] = (f32x4){0.f, 0.f, 0.f, 0.f}; dvv[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+#pragma unroll 1
+    for (int qy = 0; qy < WS; ++qy)
+#pragma unroll 1
+      for (int qx0 = 0; qx0 < WS; qx0 += UNR)
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int qx = qx0 + u, i = qy * WS + qx;
+        float a = 0.f, dpv = 0.f;
+        f32x4 qr[HD / 4], dr[HD / 4];
+#pragma unroll
+        for (int c = 0; c < HD; c += 4) {
+          qr[c / 4] = *reinterpret_cast<const f32x4*>(&Qs[g][i][c]);
+          dr[c / 4] = *reinterpret_cast<const f32x4*>(&Ds[g][i][c]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { a = fmaf(qr[c / 4][e], kk[c / 4][e], a); dpv = fmaf(dr[c / 4][e], vv2[c / 4][e], dpv); }
+        }
+        a += bias_k[qy * NBW + qx];
+        const bool m = (edge_y && ((qy < sgap) != lo_y)) || (edge_x && ((qx < sgap) != lo_x));
+        const float pij = m ? 0.f : expf(a - Lse[g][i]);
+        const float ds = pij * (dpv - Dd[g][i]);
+#pragma unroll
+        for (int c = 0; c < HD / 4; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { dvv[c][e] = fmaf(pij, dr[c][e], dvv[c][e]); dk[c][e] = fmaf(ds, qr[c][e], dk[c][e]); }
+      }
     float* dkp = p.dqkv + (size_t)pix * p.lddq + p.C + head * HD;
     float* dvp = p.dqkv + (size_t)pix * p.lddq + 2 * p.C + head * HD;
     if (wvalid)
 #pragma unroll
-    for (int c = 0; c < HD; c += 4) {
-      // Qs already carries the hd^-1/2 factor, so dk is complete as is
-      *reinterpret_cast<f32x4*>(dkp + c) = (f32x4){dk[c], dk[c + 1], dk[c + 2], dk[c + 3]};
-      *reinterpret_cast<f32x4*>(dvp + c) = (f32x4){dvv[c], dvv[c + 1], dvv[c + 2], dvv[c + 3]};
-    }
+      for (int c = 0; c < HD; c += 4) {
+        // Qs already carries the hd^-1/2 factor, so dk is complete as is
+        *reinterpret_cast<f32x4*>(dkp + c) = dk[c / 4];
+        *reinterpret_cast<f32x4*>(dvp + c) = dvv[c / 4];
+      }
   }
-  // ---- fold sum_windows dS[p][q] into the (2ws-1)^2 relative-position bins, fixed order ----
+  // ---- per-workgroup partial of the relative-bias gradient (window slots summed in order) ----
   __syncthreads();
   for (int bin = lane; bin < NB; bin += 64) {
-    const int dy = bin / (2 * WS - 1) - (WS - 1), dx = bin % (2 * WS - 1) - (WS - 1);
     float sum = 0.f;
-    for (int gg = 0; gg < G; ++gg)
-      for (int qy = 0; qy < WS; ++qy) {
-        const int ky = qy - dy;
-        if (ky < 0 || ky >= WS) continue;
-        for (int qx = 0; qx < WS; ++qx) {
-          const int kx = qx - dx;
-          if (kx < 0 || kx >= WS) continue;
-          sum += AccS[gg][qy * WS + qx][ky * WS + kx];
-        }
-      }
+    for (int gg = 0; gg < G; ++gg) sum += BinAcc[gg][bin];
     p.dbias_partial[((size_t)blockIdx.x * p.heads + head) * NB + bin] = sum;
   }
 }
 
-__global__ void dbias_reduce_kernel(const float* __restrict__ partial, int nblocks, int n, float* out, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = accumulate ? out[i] : 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * n + i];
-  out[i] = s;
+// out[i] (+)= sum_b partial[b][i]; 32 columns x 8 interleaved block groups per workgroup, combined in a fixed tree
+__global__ __launch_bounds__(256) void dbias_reduce_kernel(const float* __restrict__ partial, int nblocks, int n, float* out, int accumulate) {
+  __shared__ float sm[8][32];
+  const int tx = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + tx;
+  float s = 0.f;
+  if (i < n)
+    for (int b = g; b < nblocks; b += 8) s += partial[(size_t)b * n + i];
+  sm[g][tx] = s;
+  __syncthreads();
+  if (g == 0 && i < n) {
+    const float t = ((sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx])) + ((sm[4][tx] + sm[5][tx]) + (sm[6][tx] + sm[7][tx]));
+    out[i] = (accumulate ? out[i] : 0.f) + t;
+  }
 }
 
 int check_geom(const char* who, int B, int H, int W, int C, int heads, int ws, int ld1, int ld3) {
@@ -301,7 +360,7 @@ extern "C" int clc_winattn_bwd(const float* dout, int lddo, const float* qkv, in
   else DISPATCH(winattn_bwd_kernel, 16, hd, grid, p, (hipStream_t)stream);
   CLC_LAUNCH_CHECK();
   const int n = heads * (2 * ws - 1) * (2 * ws - 1);
-  hipLaunchKernelGGL(dbias_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)wsb, nbx, n, drelbias, accumulate);
+  hipLaunchKernelGGL(dbias_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, (hipStream_t)stream, (const float*)wsb, nbx, n, drelbias, accumulate);
   CLC_LAUNCH_CHECK();
   return 0;
 }
