@@ -247,6 +247,66 @@ __global__ void gdn_bwd_combine_kernel(const float* __restrict__ dxd, const floa
     dx[i] = dxd[i] + 2.f * x[i] * t[i];
 }
 
+// ---------------------------------------------------------------- GDN parameter re-parametrisation
+// CompressAI NonNegativeParametrizer on gamma [C,C] and beta [C] in ONE launch: y = max(x, bound)^2 - pedestal
+// (the torch version is ~20 parameter-sized launches per GDN, forward + backward).  gamma_eff is also written transposed:
+// the data-gradient 1x1 conv wants it as [Cin][Cout].
+__global__ void gdn_reparam_fwd_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, int C, float gbound, float bbound,
+                                       float ped, float* __restrict__ g_eff, float* __restrict__ g_eff_t, float* __restrict__ b_eff) {
+  const int n = C * C + C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (i < C * C) {
+      const float t = fmaxf(gamma[i], gbound), y = t * t - ped;
+      g_eff[i] = y;
+      const int r = i / C, c = i - r * C;
+      g_eff_t[c * C + r] = y;
+    } else {
+      const float t = fmaxf(beta[i - C * C], bbound);
+      b_eff[i - C * C] = t * t - ped;
+    }
+  }
+}
+// backward of the above with the LowerBound gradient rule: dt = 2 max(x,bound) dy; dx = (x >= bound || dt < 0) ? dt : 0
+__global__ void gdn_reparam_bwd_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, int C, float gbound, float bbound,
+                                       const float* __restrict__ dg_eff, const float* __restrict__ db_eff, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int accumulate) {
+  const int n = C * C + C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const bool isg = i < C * C;
+    const int j = isg ? i : i - C * C;
+    const float x = isg ? gamma[j] : beta[j], bound = isg ? gbound : bbound, dy = isg ? dg_eff[j] : db_eff[j];
+    const float dt = 2.f * fmaxf(x, bound) * dy;
+    const float dx = (x >= bound || dt < 0.f) ? dt : 0.f;
+    float* out = isg ? dgamma : dbeta;
+    out[j] = accumulate ? out[j] + dx : dx;
+  }
+}
+
+// ---------------------------------------------------------------- PixelShuffle(2) backward (+ activation backward)
+// dz[n, h, w, 4q + r] = dy[n, 2h + (r>>1), 2w + (r&1), q] * act'(saved[same])   (dy / saved: [N, C/4, 2H, 2W] pixel-major)
+// One pass instead of act_bwd + pixel_unshuffle's reshape/permute clone + the channels_last copy.
+__global__ void unshuffle_act_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ saved, int lds, int use_pre, int act,
+                                         float* __restrict__ dz, int N, int H, int W, int C) {
+  const int Q = C / 4;
+  const long total = (long)N * H * W * Q;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % Q);
+    const long pix = i / Q;
+    const int w = (int)(pix % W);
+    const long t = pix / W;
+    const int h = (int)(t % H), n = (int)(t / H);
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long sp = ((long)(n * 2 * H + 2 * h + (r >> 1)) * (2 * W) + 2 * w + (r & 1));
+      float g = dy[sp * lddy + q];
+      if (saved) g *= act_deriv(saved[sp * lds + q], act, use_pre);
+      v[r] = g;
+    }
+    *reinterpret_cast<f32x4*>(dz + pix * C + q * 4) = v;
+  }
+}
+
 // ---------------------------------------------------------------- gate
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 __global__ void gate_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ idn, float* __restrict__ out, long n) {
@@ -426,6 +486,31 @@ extern "C" int clc_gdn_bwd_elem(const float* dy, const float* x, const float* v,
 extern "C" int clc_gdn_bwd_combine(const float* dx_direct, const float* x, const float* t, float* dx, long n, clc_stream_t stream) {
   CLC_CHECK(dx_direct && x && t && dx && n > 0, "clc_gdn_bwd_combine: bad args");
   hipLaunchKernelGGL(gdn_bwd_combine_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, ST, dx_direct, x, t, dx, n);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int clc_gdn_reparam_fwd(const float* gamma, const float* beta, int C, float gamma_bound, float beta_bound, float pedestal,
+                                   float* gamma_eff, float* gamma_eff_t, float* beta_eff, clc_stream_t stream) {
+  CLC_CHECK(gamma && beta && gamma_eff && gamma_eff_t && beta_eff && C > 0, "clc_gdn_reparam_fwd: bad args");
+  hipLaunchKernelGGL(gdn_reparam_fwd_kernel, dim3(grid_for((long)C * C + C, 256)), dim3(256), 0, ST, gamma, beta, C, gamma_bound, beta_bound, pedestal,
+                     gamma_eff, gamma_eff_t, beta_eff);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int clc_gdn_reparam_bwd(const float* gamma, const float* beta, int C, float gamma_bound, float beta_bound, const float* dgamma_eff,
+                                   const float* dbeta_eff, float* dgamma, float* dbeta, int accumulate, clc_stream_t stream) {
+  CLC_CHECK(gamma && beta && dgamma_eff && dbeta_eff && dgamma && dbeta && C > 0, "clc_gdn_reparam_bwd: bad args");
+  hipLaunchKernelGGL(gdn_reparam_bwd_kernel, dim3(grid_for((long)C * C + C, 256)), dim3(256), 0, ST, gamma, beta, C, gamma_bound, beta_bound,
+                     dgamma_eff, dbeta_eff, dgamma, dbeta, accumulate);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int clc_unshuffle_act_bwd(const float* dy, int lddy, const float* saved, int lds, int use_pre, int act, float* dz, int N, int H,
+                                     int W, int C, clc_stream_t stream) {
+  CLC_CHECK(dy && dz && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "clc_unshuffle_act_bwd: bad args");
+  CLC_CHECK(lddy >= C / 4 && (!saved || lds >= C / 4) && aligned16(dz), "clc_unshuffle_act_bwd: bad leading dims / alignment");
+  hipLaunchKernelGGL(unshuffle_act_bwd_kernel, dim3(grid_for((long)N * H * W * (C / 4), 256)), dim3(256), 0, ST, dy, lddy, saved, lds, use_pre, act, dz,
+                     N, H, W, C);
   CLC_LAUNCH_CHECK();
   return 0;
 }

@@ -149,10 +149,19 @@ class GDN(nn.Module):
         self.gamma_reparam = NonNegativeParametrizer()
         self.gamma = nn.Parameter(self.gamma_reparam.init(float(gamma_init) * torch.eye(in_channels)))
 
+    def _consts(self):
+        """(gamma bound, beta bound, pedestal) as the float32 values of the CompressAI buffers (read once: no sync per step)."""
+        c = getattr(self, "_clc_consts", None)
+        if c is None:
+            c = (float(self.gamma_reparam.lower_bound.bound.item()), float(self.beta_reparam.lower_bound.bound.item()),
+                 float(self.gamma_reparam.pedestal.item()))
+            assert float(self.beta_reparam.pedestal.item()) == c[2]
+            self._clc_consts = c
+        return c
+
     def forward(self, x, res=None):
-        beta = self.beta_reparam(self.beta)      # [C]   tiny parameter-sized torch ops
-        gamma = self.gamma_reparam(self.gamma)   # [C,C]
-        return ops.gdn(x, gamma, beta, inverse=self.inverse, res=res)
+        gb, bb, ped = self._consts()
+        return ops.gdn_param(x, self.gamma, self.beta, gb, bb, ped, inverse=self.inverse, res=res)
 
 
 class ResidualBlockWithStride(nn.Module):

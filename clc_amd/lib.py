@@ -71,6 +71,9 @@ SIGNATURES = {
     "clc_layernorm_bwd": (_i, [fp, _i, fp, _i, fp, fp, fp, fp, _i, fp, fp, _i, _l, _i, fp, _sz, fp]),
     "clc_gdn_bwd_elem": (_i, [fp, fp, fp, fp, fp, _l, _i, fp]),
     "clc_gdn_bwd_combine": (_i, [fp, fp, fp, fp, _l, fp]),
+    "clc_gdn_reparam_fwd": (_i, [fp, fp, _i, _f, _f, _f, fp, fp, fp, fp]),
+    "clc_gdn_reparam_bwd": (_i, [fp, fp, _i, _f, _f, fp, fp, fp, fp, _i, fp]),
+    "clc_unshuffle_act_bwd": (_i, [fp, _i, fp, _i, _i, _i, fp, _i, _i, _i, _i, fp]),
     "clc_gate_fwd": (_i, [fp, fp, fp, fp, _l, fp]),
     "clc_gate_bwd": (_i, [fp, fp, fp, fp, fp, _l, fp]),
     "clc_axpby": (_i, [fp, _f, fp, _f, fp, _l, fp]),

@@ -329,6 +329,17 @@ def act_bwd(dy, saved, use_pre, act):
     return dz
 
 
+def unshuffle_act_bwd(dy, saved, use_pre, act):
+    """dy [N, C/4, 2H, 2W] (gradient of a PixelShuffle(2)-stored conv output) -> dz [N, C, H, W] = unshuffle(dy * act'(saved))."""
+    dy, dyp, N, H2, W2, Q, lddy = nhwc(dy)
+    sp, lds = None, 0
+    if saved is not None:
+        saved, sp, *_r, lds = nhwc(saved)
+    dz = new_act(N, Q * 4, H2 // 2, W2 // 2, dy)
+    _lib.check(_L().clc_unshuffle_act_bwd(dyp, lddy, sp, lds, int(use_pre), act, dz.data_ptr(), N, H2 // 2, W2 // 2, Q * 4, _stream()), "clc_unshuffle_act_bwd")
+    return dz
+
+
 class _ConvFn(Function):
     """y = act(conv(x, w) + b) + res_scale * res, optionally PixelShuffle(2)-stored.  With (w2, b2) the second half of
     the batch is convolved with the second filter set in the same launch (paired layers)."""
@@ -390,13 +401,17 @@ class _ConvFn(Function):
         # pass) unless the unshuffle copy or a pre-activation residual needs dz materialised
         # (only for the one-instruction derivatives: fusing GELU's erf/exp into the loaders measured slower)
         fuse = act in (ACT_LRELU, ACT_RELU) and not shuffle and not (need_res and res_first)
-        dz = dy if (act == ACT_NONE or fuse) else act_bwd(dy, saved_act, ctx.use_pre, act)
+        one_pass_unshuffle = shuffle and not (need_res and res_first)
+        if one_pass_unshuffle:   # PixelShuffle(2) backward and the activation backward in ONE pass over dy
+            dz = unshuffle_act_bwd(dy, saved_act if act != ACT_NONE else None, ctx.use_pre, act)
+        else:
+            dz = dy if (act == ACT_NONE or fuse) else act_bwd(dy, saved_act, ctx.use_pre, act)
         fa = dict(xs=saved_act, xs_act=act, xs_pre=ctx.use_pre) if fuse else {}
         dres = None
         if need_res:
             dsrc = dz if res_first else dy  # residual added before / after the activation
             dres = dsrc if res_scale == 1.0 else dsrc * res_scale
-        if shuffle:  # undo PixelShuffle(2): [N, C/4, 2H, 2W] -> [N, C, H, W] (strided copy; TODO fuse into the gathers)
+        if shuffle and not one_pass_unshuffle:  # undo PixelShuffle(2): [N, C/4, 2H, 2W] -> [N, C, H, W]
             dz = torch.nn.functional.pixel_unshuffle(dz, 2).contiguous(memory_format=CL)
         dx = dw = db = dw2 = db2 = None
         pad = ks // 2
@@ -539,6 +554,60 @@ class _GDNFn(Function):
 
 def gdn(x, gamma_eff, beta_eff, inverse=False, res=None):
     return _GDNFn.apply(x, gamma_eff, beta_eff, res, bool(inverse))
+
+
+class _GDNParamFn(Function):
+    """GDN on the RAW parameters: the NonNegativeParametrizer of gamma and beta is one launch forward (which also emits
+    gamma_eff transposed for the data-gradient conv) and one launch backward, writing straight into the gradient arena —
+    instead of ~20 parameter-sized torch launches per GDN module and step."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, inverse, gamma_bound, beta_bound, pedestal):
+        N, Cc, H, W = x.shape
+        need_grad = any(ctx.needs_input_grad)
+        g_eff = torch.empty((Cc, Cc), device=x.device, dtype=torch.float32)
+        g_eff_t = torch.empty((Cc, Cc), device=x.device, dtype=torch.float32)
+        b_eff = torch.empty((Cc,), device=x.device, dtype=torch.float32)
+        gm = gamma if gamma.is_contiguous() else gamma.contiguous()
+        _lib.check(_L().clc_gdn_reparam_fwd(gm.data_ptr(), beta.data_ptr(), Cc, gamma_bound, beta_bound, pedestal, g_eff.data_ptr(),
+                                            g_eff_t.data_ptr(), b_eff.data_ptr(), _stream()), "clc_gdn_reparam_fwd")
+        v = new_act(N, Cc, H, W, x) if need_grad else None
+        y = conv_raw(x, g_eff, b_eff, ks=1, in_op=IN_SQUARE, norm=NORM_IGDN if inverse else NORM_GDN, mul=x, y_pre=v, res=res)
+        ctx.cfg = (inverse, res is not None, gamma_bound, beta_bound)
+        ctx.params = (gamma, beta)
+        ctx.save_for_backward(x, gm, g_eff_t, v)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gm, g_eff_t, v = ctx.saved_tensors
+        inverse, has_res, gamma_bound, beta_bound = ctx.cfg
+        gamma, beta = ctx.params
+        N, Cc, H, W = x.shape
+        dy, xx = dense(dy), dense(x)
+        n = N * Cc * H * W
+        dxd, dv = new_act(N, Cc, H, W, x), new_act(N, Cc, H, W, x)
+        _lib.check(_L().clc_gdn_bwd_elem(dy.data_ptr(), xx.data_ptr(), v.data_ptr(), dxd.data_ptr(), dv.data_ptr(), n, int(inverse), _stream()), "clc_gdn_bwd_elem")
+        dgamma = dbeta = dx = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dgf, dbe = wgrad_raw(xx, dv, ks=1, stride=1, pad=0, Cout=Cc, Cin=Cc, want_bias=True, in_op=IN_SQUARE)
+            gg, gb = _direct_grad(gamma), _direct_grad(beta)
+            direct = gg is not None and gb is not None and gm is gamma
+            if not direct:
+                gg, gb = torch.empty_like(gm), torch.empty_like(beta)
+            _lib.check(_L().clc_gdn_reparam_bwd(gm.data_ptr(), beta.data_ptr(), Cc, gamma_bound, beta_bound, dgf.data_ptr(), dbe.data_ptr(),
+                                                gg.data_ptr(), gb.data_ptr(), int(direct), _stream()), "clc_gdn_reparam_bwd")
+            if not direct:
+                dgamma, dbeta = gg, gb
+        if ctx.needs_input_grad[0]:
+            t = conv_raw(dv, g_eff_t, None, ks=1, transposed=True, out_hw=(H, W))
+            dx = new_act(N, Cc, H, W, x)
+            _lib.check(_L().clc_gdn_bwd_combine(dxd.data_ptr(), xx.data_ptr(), t.data_ptr(), dx.data_ptr(), n, _stream()), "clc_gdn_bwd_combine")
+        return dx, dgamma, dbeta, (dy if has_res and ctx.needs_input_grad[3] else None), None, None, None, None
+
+
+def gdn_param(x, gamma, beta, gamma_bound, beta_bound, pedestal, inverse=False, res=None):
+    return _GDNParamFn.apply(x, gamma, beta, res, bool(inverse), float(gamma_bound), float(beta_bound), float(pedestal))
 
 
 # ------------------------------------------------------------------------------------- LayerNorm

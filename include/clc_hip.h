@@ -141,6 +141,18 @@ int clc_gdn_bwd_elem(const float* dy, const float* x, const float* v, float* dx_
                      clc_stream_t stream);
 /* dx = dx_direct + 2*x*t  (t = gamma^T . dv from clc_conv2d) */
 int clc_gdn_bwd_combine(const float* dx_direct, const float* x, const float* t, float* dx, long n, clc_stream_t stream);
+/* CompressAI NonNegativeParametrizer (GDN beta / gamma): y = max(x, bound)^2 - pedestal for gamma [C,C] and
+ * beta [C] in one launch (gamma_eff also written transposed for the data-gradient conv); backward with the LowerBound
+ * gradient rule (pass where x >= bound or the gradient pushes x up), optionally accumulating into dgamma / dbeta. */
+int clc_gdn_reparam_fwd(const float* gamma, const float* beta, int C, float gamma_bound, float beta_bound, float pedestal,
+                        float* gamma_eff, float* gamma_eff_t, float* beta_eff, clc_stream_t stream);
+int clc_gdn_reparam_bwd(const float* gamma, const float* beta, int C, float gamma_bound, float beta_bound, const float* dgamma_eff,
+                        const float* dbeta_eff, float* dgamma, float* dbeta, int accumulate, clc_stream_t stream);
+/* backward of PixelShuffle(2) fused with the activation backward of the conv that was stored shuffled:
+ * dz[n,h,w,4q+r] = dy[n,2h+(r>>1),2w+(r&1),q] * act'(saved[same]); dy/saved [N,C/4,2H,2W] pixel-major, dz [N,C,H,W] dense.
+ * saved may be NULL (no activation). */
+int clc_unshuffle_act_bwd(const float* dy, int lddy, const float* saved, int lds, int use_pre, int act, float* dz, int N, int H,
+                          int W, int C, clc_stream_t stream);
 
 /* out = a * sigmoid(b) + idn  (SWAtten gate, CLC_run.py:241-242) and its backward */
 int clc_gate_fwd(const float* a, const float* b, const float* idn, float* out, long n, clc_stream_t stream);

@@ -159,6 +159,35 @@ def test_conv_paired_filters(dev, case):
             assert torch.equal(a.grad, b.grad), f"act {act}: paired {name} gradient differs"
 
 
+@pytest.mark.parametrize("inverse", [False, True])
+def test_gdn_raw_parameters(dev, inverse):
+    """layers.GDN on the raw gamma / beta (fused NonNegativeParametrizer forward + LowerBound-rule backward) against the
+    oracle's CompressAI GDN, with parameters on both sides of the bound and gradients of both signs."""
+    from clc_amd import layers
+    from oracle import leaves
+
+    C = 64
+    torch.manual_seed(5)
+    ref = leaves.GDN(C, inverse=inverse)
+    with torch.no_grad():
+        ref.gamma.add_(torch.randn(C, C) * 0.02)            # many entries end up below the bound (2^-18) and negative
+        ref.beta.add_(torch.randn(C) * 0.5).clamp_(min=-0.5)
+    mod = layers.GDN(C, inverse=inverse)
+    mod.load_state_dict(ref.state_dict())
+    mod = mod.to(dev)
+    x = _rand((2, C, 16, 16), 1)
+    gy = _rand((2, C, 16, 16), 2)
+    xr = x.clone().requires_grad_()
+    ref(xr).backward(gy)
+    xd = _dev(x, dev, grad=True)
+    y = mod(xd)
+    _close(y, ref(x).detach(), 2e-5, "gdn(raw) fwd")
+    y.backward(_dev(gy, dev))
+    _close(xd.grad, xr.grad, 1e-4, "gdn(raw) dx")
+    _close(mod.gamma.grad, ref.gamma.grad, 1e-4, "gdn(raw) dgamma")
+    _close(mod.beta.grad, ref.beta.grad, 1e-4, "gdn(raw) dbeta")
+
+
 def test_conv_residual_slice_shuffle(dev):
     from clc_amd import ops
 
