@@ -59,6 +59,7 @@ __device__ __forceinline__ float act_deriv(float s, int act, int use_pre) {
       const float t = use_pre ? tanhf(s) : 2.f * s;
       return 0.5f * (1.f - t * t);
     }
+    case CLC_ACT_SAVED_DERIV: return s;
     default: return 1.f;
   }
 }

@@ -201,6 +201,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, int lddy, const flo
         d = 0.5f * (1.f - t * t);
         break;
       }
+      case CLC_ACT_SAVED_DERIV: d = s; break;
       default: d = 1.f;
     }
     dz[r * lddz + c] = g * d;
@@ -529,6 +530,44 @@ extern "C" int clc_gate_bwd(const float* dout, const float* a, const float* b, f
 extern "C" int clc_axpby(const float* a, float alpha, const float* b, float beta, float* out, long n, clc_stream_t stream) {
   CLC_CHECK(a && out && n > 0, "clc_axpby: bad args");
   hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, ST, a, alpha, b, beta, out, n);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+// Patch rows of a few-channel image (the RGB heads, Cin = 3): col[m][(kh*ks+kw)*C + c] = x[n, oh*s-pad+kh, ow*s-pad+kw, c],
+// zero outside the image and in the padding columns up to ldc.  One thread per (output pixel, 4-float column group).
+__global__ void im2col_small_kernel(const float* __restrict__ x, int ldx, int H, int W, int C, int ks, int stride, int pad,
+                                    float* __restrict__ col, int ldc, int OH, int OW, long total) {
+  const int groups = ldc / 4, K = ks * ks * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % groups);
+    const long m = i / groups;
+    const int ow = (int)(m % OW);
+    const long t = m / OW;
+    const int oh = (int)(t % OH), n = (int)(t / OH);
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = g * 4 + q;
+      float e = 0.f;
+      if (k < K) {
+        const int tap = k / C, c = k - tap * C;
+        const int kh = tap / ks, kw = tap - kh * ks;
+        const int iy = oh * stride - pad + kh, ix = ow * stride - pad + kw;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) e = x[((long)(n * H + iy) * W + ix) * ldx + c];
+      }
+      v[q] = e;
+    }
+    *reinterpret_cast<f32x4*>(col + m * ldc + g * 4) = v;
+  }
+}
+
+extern "C" int clc_im2col_small(const float* x, int ldx, int N, int H, int W, int C, int ks, int stride, int pad, float* col, int ldc,
+                                int OH, int OW, clc_stream_t stream) {
+  CLC_CHECK(x && col && N > 0 && H > 0 && W > 0 && C > 0 && ks > 0 && stride > 0, "clc_im2col_small: bad args");
+  CLC_CHECK(ldc % 4 == 0 && ldc >= ks * ks * C && aligned16(col), "clc_im2col_small: ldc must be a multiple of 4 and >= ks*ks*C");
+  CLC_CHECK(OH == (H + 2 * pad - ks) / stride + 1 && OW == (W + 2 * pad - ks) / stride + 1, "clc_im2col_small: output dims");
+  const long total = (long)N * OH * OW * (ldc / 4);
+  hipLaunchKernelGGL(im2col_small_kernel, dim3(grid_for(total, 4096)), dim3(256), 0, ST, x, ldx, H, W, C, ks, stride, pad, col, ldc, OH, OW, total);
   CLC_LAUNCH_CHECK();
   return 0;
 }

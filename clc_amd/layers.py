@@ -174,6 +174,17 @@ class ResidualBlockWithStride(nn.Module):
         self.skip = conv1x1(in_ch, out_ch, stride=stride) if (stride != 1 or in_ch != out_ch) else None
 
     def forward(self, x):
+        cin = self.conv1.in_channels
+        if cin <= 3 and self.skip is not None and self.conv1.stride[0] == 2 and not x.requires_grad:
+            # RGB head: K = 27 is far too small for the implicit-GEMM loader's 16-B channel groups.  One patch-row pass
+            # (27 -> 32 zero-padded columns), then conv1 AND the 1x1/s2 skip conv (its input pixel is the 3x3 window's centre
+            # tap, columns 4*cin .. 5*cin) are 1x1 convolutions over those rows on the MFMA kernel.
+            col = ops.im2col_small(x, 3, 2, 32)
+            co = self.conv1.out_channels
+            w1 = torch.nn.functional.pad(self.conv1.weight.permute(0, 2, 3, 1).reshape(co, 9 * cin), (0, 32 - 9 * cin))
+            ws = torch.nn.functional.pad(self.skip.weight.reshape(co, cin), (4 * cin, 32 - 5 * cin))
+            t = self.conv2(ops.linear(col, w1, self.conv1.bias, act=ACT_LRELU))
+            return self.gdn(t, res=ops.linear(col, ws, self.skip.bias))
         t = self.conv2(self.conv1(x, act=ACT_LRELU))
         identity = self.skip(x) if self.skip is not None else x
         return self.gdn(t, res=identity)

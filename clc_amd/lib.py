@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclc_hip.so")
 
-ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU, ACT_HALFTANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU, ACT_HALFTANH, ACT_SIGMOID, ACT_SAVED_DERIV = 0, 1, 2, 3, 4, 5, 6
 IN_NONE, IN_SQUARE = 0, 1
 NORM_NONE, NORM_GDN, NORM_IGDN = 0, 1, 2
 
@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
                 ("y_pre", fp), ("ldp", C.c_int),
                 ("shuffle", C.c_int), ("res_first", C.c_int),
                 ("xs", fp), ("ldxs", C.c_int), ("xs_act", C.c_int), ("xs_pre", C.c_int),
-                ("w2", fp), ("bias2", fp)]
+                ("w2", fp), ("bias2", fp), ("pre_deriv", C.c_int)]
 
 
 class WgradDesc(C.Structure):
@@ -78,6 +78,7 @@ SIGNATURES = {
     "clc_gate_bwd": (_i, [fp, fp, fp, fp, fp, _l, fp]),
     "clc_axpby": (_i, [fp, _f, fp, _f, fp, _l, fp]),
     "clc_copy2d": (_i, [fp, _i, fp, _i, _l, _i, fp]),
+    "clc_im2col_small": (_i, [fp, _i, _i, _i, _i, _i, _i, _i, _i, fp, _i, _i, _i, fp]),
     "clc_winattn_fwd": (_i, [fp, _i, fp, fp, _i, fp, _i, _i, _i, _i, _i, _i, _i, fp]),
     "clc_winattn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "clc_winattn_bwd": (_i, [fp, _i, fp, _i, fp, fp, _i, fp, fp, _i, fp, _i, _i, _i, _i, _i, _i, _i, _i, fp, _sz, fp]),

@@ -19,8 +19,8 @@ import torch
 from torch.autograd import Function
 
 from . import lib as _lib
-from .lib import (ACT_GELU, ACT_HALFTANH, ACT_LRELU, ACT_NONE, ACT_RELU, IN_NONE, IN_SQUARE, NORM_GDN, NORM_IGDN,
-                  NORM_NONE)
+from .lib import (ACT_GELU, ACT_HALFTANH, ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SAVED_DERIV, IN_NONE, IN_SQUARE, NORM_GDN,
+                  NORM_IGDN, NORM_NONE)
 
 CL = torch.channels_last
 
@@ -189,7 +189,7 @@ def to_kernel_weight(w: torch.Tensor) -> torch.Tensor:
 
 def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_NONE, norm=NORM_NONE, mul=None,
              res=None, res_scale=1.0, res_first=False, y_pre=None, shuffle=False, transposed=False, out=None, out_hw=None,
-             xs=None, xs_act=ACT_NONE, xs_pre=False, w2=None, bias2=None):
+             xs=None, xs_act=ACT_NONE, xs_pre=False, w2=None, bias2=None, pre_deriv=False):
     """One clc_conv2d launch. ``w`` must already be in kernel layout [Cout][ks][ks][Cin]."""
     _require_gpu(x, "conv2d")
     x, xp, N, H, W, Cin, ldx = nhwc(x)
@@ -226,6 +226,7 @@ def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_
         q, qp, *_r, ldp = nhwc(y_pre)
         assert q is y_pre
         d.y_pre, d.ldp = qp, ldp
+        d.pre_deriv = int(pre_deriv)
     if xs is not None:   # fused activation backward: x <- x * act'(xs)
         xs_t, xsp, *_r, ldxs = nhwc(xs)
         d.xs, d.ldxs, d.xs_act, d.xs_pre = xsp, ldxs, xs_act, int(xs_pre)
@@ -241,6 +242,19 @@ def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_
         PROFILE.append(("conv_igemm" if variant != 1 else "conv_direct_small", variant, 2.0 * pix * ks * ks * Cin * Cout, e0, e1,
                         f"{'dgrad' if transposed else 'fwd'} {Cin}->{Cout} k{ks} s{stride} {N}x{H}x{W}" + (" +actbwd" if xs is not None else "")))
     return out
+
+
+def im2col_small(x, ks, stride, ldc=32):
+    """Patch rows of a few-channel image: [N,C,H,W] -> [N,ldc,OH,OW] (pixel-major rows of ks*ks*C values, zero-padded to ldc).
+    Not differentiable: the RGB input of the analysis / reference encoders needs no gradient."""
+    _require_gpu(x, "im2col_small")
+    assert not x.requires_grad
+    x, xp, N, H, W, Cc, ldx = nhwc(x)
+    pad = ks // 2
+    OH, OW = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    col = new_act(N, ldc, OH, OW, x)
+    _lib.check(_L().clc_im2col_small(xp, ldx, N, H, W, Cc, ks, stride, pad, col.data_ptr(), ldc, OH, OW, _stream()), "clc_im2col_small")
+    return col
 
 
 def filter_transpose(w, Cout, T, Cin):
@@ -358,9 +372,12 @@ class _ConvFn(Function):
         y_pre = None
         if save_pre:
             y_pre = new_act(N, Cout // 4, 2 * OH, 2 * OW, x) if shuffle else new_act(N, Cout, OH, OW, x)
+        # GELU: the epilogue stores gelu'(v) (it has v in a register) instead of v, so the backward is one multiply inside
+        # the gradient kernels' loaders — no erf/exp there and no elementwise dz pass
+        deriv = save_pre and act == ACT_GELU
         y = conv_raw(x, wk, b, ks=ks, stride=stride, act=act, res=res, res_scale=res_scale, res_first=res_first, y_pre=y_pre, shuffle=shuffle,
-                     w2=wk2, bias2=b2)
-        ctx.cfg = (ks, stride, act, res_scale, shuffle, b is not None, res is not None, res_first)
+                     w2=wk2, bias2=b2, pre_deriv=deriv)
+        ctx.cfg = (ks, stride, ACT_SAVED_DERIV if deriv else act, res_scale, shuffle, b is not None, res is not None, res_first)
         saved_act = y_pre if save_pre else (y if act in (ACT_LRELU, ACT_RELU, ACT_HALFTANH) else None)
         ctx.use_pre = save_pre
         ctx.bias_ref = b
@@ -399,8 +416,8 @@ class _ConvFn(Function):
         need_x, need_w, need_b, need_res = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_b and ctx.needs_input_grad[2], has_res and ctx.needs_input_grad[3]
         # the activation derivative is applied inside the data-/weight-gradient kernels' loaders (no dz tensor, no extra
         # pass) unless the unshuffle copy or a pre-activation residual needs dz materialised
-        # (only for the one-instruction derivatives: fusing GELU's erf/exp into the loaders measured slower)
-        fuse = act in (ACT_LRELU, ACT_RELU) and not shuffle and not (need_res and res_first)
+        # (only for the one-instruction derivatives; GELU arrives here as ACT_SAVED_DERIV: its derivative was stored forward)
+        fuse = act in (ACT_LRELU, ACT_RELU, ACT_SAVED_DERIV) and not shuffle and not (need_res and res_first)
         one_pass_unshuffle = shuffle and not (need_res and res_first)
         if one_pass_unshuffle:   # PixelShuffle(2) backward and the activation backward in ONE pass over dy
             dz = unshuffle_act_bwd(dy, saved_act if act != ACT_NONE else None, ctx.use_pre, act)

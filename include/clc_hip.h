@@ -39,7 +39,8 @@ int clc_version(void);
 
 /* ---- activation / epilogue codes ---------------------------------------------------- */
 enum { CLC_ACT_NONE = 0, CLC_ACT_LRELU = 1, CLC_ACT_RELU = 2, CLC_ACT_GELU = 3, CLC_ACT_HALFTANH = 4 /* 0.5*tanh(v), LRP head */,
-       CLC_ACT_SIGMOID = 5 /* forward only (CLM modulation) */ };
+       CLC_ACT_SIGMOID = 5 /* forward only (CLM modulation) */,
+       CLC_ACT_SAVED_DERIV = 6 /* backward only: the saved tensor IS act'(pre-activation) (see pre_deriv) */ };
 /* input prologue applied to the gathered activations */
 enum { CLC_IN_NONE = 0, CLC_IN_SQUARE = 1 };
 /* norm modes of the epilogue: out = mul * rsqrt(v) (GDN) or mul * sqrt(v) (inverse GDN) */
@@ -80,6 +81,9 @@ typedef struct {
    * scale-parameter nets of a slice, CLC_run.py:560-566) become ONE launch with twice the rows — the 16x16-map layers
    * are latency-bound, so the second one is nearly free.  NULL = ordinary convolution; N must be even. */
   const float* w2; const float* bias2;
+  /* pre_deriv = 1: y_pre receives act'(v) instead of v, so the backward of an expensive activation (GELU: erf + exp) is
+   * one multiply in the gradient kernels' loaders (xs_act / dys_act = CLC_ACT_SAVED_DERIV) — no elementwise pass */
+  int pre_deriv;
 } clc_conv_desc;
 
 int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream);
@@ -162,6 +166,12 @@ int clc_gate_bwd(const float* dout, const float* a, const float* b, float* da, f
 int clc_axpby(const float* a, float alpha, const float* b, float beta, float* out, long n, clc_stream_t stream);
 /* strided copy of a channel slice: dst[r*ldd + c] = src[r*lds + c] (c < C) */
 int clc_copy2d(const float* src, int lds, float* dst, int ldd, long rows, int C, clc_stream_t stream);
+/* Patch rows of a few-channel image (the RGB heads, Cin = 3: g_a.0 / ref_encoder.encoder.0 of CLC_run.py:274,335):
+ * col[m][(kh*ks+kw)*C + c] = x[n, oh*s-pad+kh, ow*s-pad+kw, c], zeros outside the image and in columns ks*ks*C..ldc-1.
+ * The 3x3/s2 conv AND the 1x1/s2 skip conv of ResidualBlockWithStride (its input is the centre tap) then run as
+ * 1x1 convolutions over `col` on the MFMA kernel. */
+int clc_im2col_small(const float* x, int ldx, int N, int H, int W, int C, int ks, int stride, int pad, float* col, int ldc,
+                     int OH, int OW, clc_stream_t stream);
 
 /* ---- window attention (WMSA core, CLC_run.py:142-164) --------------------------------- *
  * qkv: [B,H,W,3C] tokens, channel = which*C + head*hd + c ; out: [B,H,W,C].

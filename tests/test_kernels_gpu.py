@@ -470,3 +470,30 @@ def test_ms_ssim_fwd_bwd(dev, shape):
     assert abs(out.item() - ref.item()) < 2e-5, (out.item(), ref.item())
     out.backward()
     _close(xd.grad, x.grad, 2e-3, "ms-ssim dx")
+
+
+@pytest.mark.parametrize("cout", [64, 128])
+def test_rgb_head_block_patch_rows(dev, cout):
+    """ResidualBlockWithStride(3, C) — the RGB heads g_a.0 / ref_encoder.encoder.0 — runs conv1 (3x3/s2) and the skip conv
+    (1x1/s2) as 1x1 convolutions over zero-padded 27->32 patch rows (clc_im2col_small): forward and every parameter
+    gradient against the plain-PyTorch block (oracle leaves)."""
+    from clc_amd import layers
+    from oracle import leaves as ol
+
+    torch.manual_seed(3)
+    ref = ol.ResidualBlockWithStride(3, cout, stride=2)
+    blk = layers.ResidualBlockWithStride(3, cout, stride=2)
+    blk.load_state_dict(ref.state_dict())
+    blk = blk.to(dev)
+    x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(5))
+    y_ref = ref(x)
+    g = _rand(y_ref.shape, 7)
+    y_ref.backward(g)
+    y = blk(_dev(x, dev))
+    y.backward(_dev(g, dev))
+    _close(y, y_ref, 2e-5, "rgb head fwd")
+    for (n, p), (_, q) in zip(blk.named_parameters(), ref.named_parameters()):
+        _close(p.grad, q.grad, 1e-4, f"rgb head grad {n}")
+    # the no-grad path (compress / decompress) gives the same bits
+    with torch.no_grad():
+        assert torch.equal(blk(_dev(x, dev)), y.detach())
