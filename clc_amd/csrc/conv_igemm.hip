@@ -60,6 +60,13 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0));
 }
 
+// LDS-DMA: 64 lanes x 16 B from per-lane byte offsets of the buffer into LDS at dst (wave-uniform) + 16 * lane.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, unsigned byte_off) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass of hipcc cannot type-check the LDS address-space cast)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, byte_off, 0, 0, 0);
+#endif
+}
+
 // Block-uniform description of the live filter taps: a (nkh x nkw) grid kh = kh0 + step*j.
 struct TapGrid { int kh0, kw0, step, nkh, nkw; };
 __device__ __forceinline__ TapGrid make_taps(const ConvParams& p, int ph, int pw) {
@@ -326,6 +333,151 @@ void conv_igemm_kernel(const ConvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// LDS-DMA variant of conv_igemm_kernel: `buffer_load_dwordx4 ... lds` deposits the operand tiles straight in LDS — no
+// VGPR staging, no ds_write pass (measured: the staging writes cost ~15 % of the register-staged kernel, the loads ~8 %).
+// One DMA wave-instruction writes 1 KiB linearly (lane l -> 16 B at base + 16 l) = 8 tile rows of 32 floats, so rows
+// cannot be padded; instead the 16-B chunk c of tile row r lives in slot c ^ ((r >> 1) & 7): every lane FETCHES the chunk
+// that belongs in its slot (the global source address is per lane) and the fragment reads apply the same XOR — the 16
+// rows of each ds_read_b128 lane group then fall in 16 distinct 16-B bank groups.  Halo pixels / rows past M / channels
+// past Cin go through the SRD's range check and deposit zeros.  K order and MFMA sequence are those of
+// conv_igemm_kernel, so the results are the same bits.  No input prologue (square / fused activation derivative).
+template <int BM, int BN, int WM, int WN, bool TR>
+__global__ __launch_bounds__(64 * WM * WN, (64 * WM * WN) >= 512 ? 4 : ((64 * WM * WN) >= 256 ? 2 : 4))
+void conv_igemm_dma_kernel(const ConvParams p) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_P = BM * 8 / NT, B_P = BN * 8 / NT;
+  static_assert(TM >= 1 && TN >= 1 && A_P * NT == BM * 8 && B_P * NT == BN * 8, "tile");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                    // [2][BM][BK], slot-swizzled
+  float* Bs = smem + 2 * BM * BK;      // [2][BN][BK]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int cls = blockIdx.z, ph = cls >> 1, pw = cls & 1;
+  const bool half = p.transposed && p.stride == 2;
+  const int DH = half ? p.OH / 2 : p.OH, DW = half ? p.OW / 2 : p.OW;
+  const TapGrid tg = make_taps(p, ph, pw);
+
+  const bool second = p.w2 != nullptr && m0 >= p.group_rows;
+  const float* wsel = second ? p.w2 : p.w;
+  const float* bsel = second ? p.bias2 : p.bias;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wsel), 0, p.w_bytes, 0x00020000);
+
+  RowState rows[A_P];
+  int a_c4[A_P], b_c4[B_P];          // channel offset (floats) of the chunk this lane fetches for its slot
+  unsigned b_row_off[B_P];
+  bool b_ok[B_P];
+#pragma unroll
+  for (int i = 0; i < A_P; ++i) {
+    const int r = (tid + i * NT) >> 3;
+    rows[i] = make_row<TR>(p, m0 + r, DH, DW, ph, pw);
+    a_c4[i] = ((tid & 7) ^ ((r >> 1) & 7)) * 4;
+  }
+#pragma unroll
+  for (int i = 0; i < B_P; ++i) {
+    const int r = (tid + i * NT) >> 3;
+    const int co = n0 + r;
+    b_ok[i] = co < p.Cout;
+    b_row_off[i] = (unsigned)co * (unsigned)p.ldw;
+    b_c4[i] = ((tid & 7) ^ ((r >> 1) & 7)) * 4;
+  }
+  const int wave_row = wave * 8;     // first tile row of this wave's DMA pieces (8 rows per wave-instruction)
+
+  auto dma_tile = [&](int buf, int kh, int kw, int kc) {
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) {
+      const int c = kc * BK + a_c4[i];
+      const unsigned pix = a_pixel<TR>(p, rows[i], kh, kw);
+      float* dst = As + (buf * BM + wave_row + i * (NT / 8)) * BK;
+      dma16(xr, dst, pix_off(pix, p.ldx, c, c < p.Cin));
+    }
+    const unsigned tap_off = (unsigned)((kh * p.ks + kw) * p.Cin + kc * BK);
+#pragma unroll
+    for (int i = 0; i < B_P; ++i) {
+      const bool ok = b_ok[i] && (kc * BK + b_c4[i] < p.Cin);
+      float* dst = Bs + (buf * BN + wave_row + i * (NT / 8)) * BK;
+      dma16(wr, dst, ok ? (b_row_off[i] + tap_off + (unsigned)b_c4[i]) * 4u : kOOB);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int total = tg.nkh * tg.nkw * p.kc_tiles;
+  int tj = 0, ti = 0, kc = 0;
+  auto advance = [&]() {
+    if (++kc == p.kc_tiles) { kc = 0; if (++ti == tg.nkw) { ti = 0; ++tj; } }
+  };
+  dma_tile(0, tg.kh0, tg.kw0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // fragment (row lr of a 32-row group, chunk 2*t8 + h) sits in slot (2*t8 + h) ^ ((lr >> 1) & 7)
+  const int lr = lane & 31, hh = lane >> 5, sw = (lr >> 1) & 7;
+  int fo[4];
+#pragma unroll
+  for (int t8 = 0; t8 < 4; ++t8) fo[t8] = ((2 * t8 + hh) ^ sw) * 4;
+  for (int it = 0; it < total; ++it) {
+    const int buf = it & 1;
+    advance();
+    if (it + 1 < total) dma_tile(buf ^ 1, tg.kh0 + tg.step * tj, tg.kw0 + tg.step * ti, kc);   // block-uniform branch
+    const float* Ab = As + (buf * BM + wm * (BM / WM) + lr) * BK;
+    const float* Bb = Bs + (buf * BN + wn * (BN / WN) + lr) * BK;
+#pragma unroll
+    for (int t8 = 0; t8 < 4; ++t8) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * BK + fo[t8]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * BK + fo[t8]);
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][ss], bf[j][ss], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this iteration's DMA pieces have landed
+    __syncthreads();
+  }
+
+  constexpr int LDC = BN + 4;
+  float* Cs = smem;   // [BM][LDC]
+  {
+    const int col = lane & 31, rhalf = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          Cs[(wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf) * LDC + wn * (BN / WN) + j * 32 + col] = acc[i][j][r];
+  }
+  __syncthreads();
+  if (p.vec_epi) {   // block-uniform
+    for (int e = tid; e < BM * BN / 4; e += NT) {
+      const int row = e / (BN / 4), cc = (e - row * (BN / 4)) * 4;
+      const int m = m0 + row, co = n0 + cc;
+      if (m < p.M && co < p.Cout) epilogue_store4(p, bsel, *reinterpret_cast<const f32x4*>(Cs + row * LDC + cc), m, co, DH, DW, ph, pw);
+    }
+    return;
+  }
+  for (int e = tid; e < BM * BN; e += NT) {
+    const int row = e / BN, cc = e - row * BN;
+    const int m = m0 + row, co = n0 + cc;
+    if (m < p.M && co < p.Cout) epilogue_store(p, Cs[row * LDC + cc], bsel ? bsel[co] : 0.f, m, co, DH, DW, ph, pw);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Small maps (<= 16x16 per image): latency, not MFMA rate, is what matters (a 64->64 3x3 at 8x16x16 is 0.15 GFLOP).
 // One 32 x BN output tile per workgroup of KW = 8 waves; wave w owns K-tiles w, w+8, ... and loads its MFMA fragments
 // STRAIGHT from global memory into registers in operand layout (lane (i,h) needs 4 consecutive k of its own row i:
@@ -459,8 +611,25 @@ int launch_t(const ConvParams& p, int classes, hipStream_t st) {
   CLC_LAUNCH_CHECK();
   return BM * 1000 + BN;  // kernel-variant id (>= 0): lets callers attribute time per template instantiation
 }
+template <int BM, int BN, int WM, int WN, bool TR>
+int launch_dma_t(const ConvParams& p, int classes, hipStream_t st) {
+  dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, classes);
+  constexpr size_t lds_ab = (size_t)2 * (BM + BN) * BK * sizeof(float), lds_c = (size_t)BM * (BN + 4) * sizeof(float);
+  constexpr size_t lds = lds_ab > lds_c ? lds_ab : lds_c;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<BM, BN, WM, WN, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, TR>), grid, dim3(64 * WM * WN), lds, st, p);
+  CLC_LAUNCH_CHECK();
+  return BM * 1000 + BN;
+}
 template <int BM, int BN, int WM, int WN>
 int launch(const ConvParams& p, int classes, hipStream_t st) {
+  static const int use_dma = getenv("CLC_DMA") ? atoi(getenv("CLC_DMA")) : 1;   // CLC_DMA=0: register staging everywhere (A/B knob)
+  if (use_dma && p.in_op == CLC_IN_NONE && p.xs == nullptr && BM >= 128)   // no input prologue -> the tiles can go straight to LDS
+    return p.transposed ? launch_dma_t<BM, BN, WM, WN, true>(p, classes, st) : launch_dma_t<BM, BN, WM, WN, false>(p, classes, st);
   return p.transposed ? launch_t<BM, BN, WM, WN, true>(p, classes, st) : launch_t<BM, BN, WM, WN, false>(p, classes, st);
 }
 
