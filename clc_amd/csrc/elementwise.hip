@@ -52,7 +52,7 @@ template <int G>
 __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, float* __restrict__ dx, int lddx,
-                                                              float* __restrict__ ws, long rows) {
+                                                              const float* __restrict__ dadd, int ldadd, float* __restrict__ ws, long rows) {
   constexpr int C = 4 * G, RPB = 256 / G;
   __shared__ f32x4 sm[2][RPB][G];
   const int sub = threadIdx.x % G, rl = threadIdx.x / G;
@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
     db += d;
     const float s1 = group_sum<G>((g[0] + g[1]) + (g[2] + g[3])) / (float)C;
     const float s2 = group_sum<G>((g[0] * xh[0] + g[1] * xh[1]) + (g[2] * xh[2] + g[3] * xh[3])) / (float)C;
-    *reinterpret_cast<f32x4*>(dx + r * lddx + sub * 4) = rs * (g - s1 - xh * s2);
+    f32x4 o = rs * (g - s1 - xh * s2);
+    if (dadd) o += *reinterpret_cast<const f32x4*>(dadd + r * ldadd + sub * 4);   // gradient of the residual branch, folded in
+    *reinterpret_cast<f32x4*>(dx + r * lddx + sub * 4) = o;
   }
   sm[0][rl][sub] = dg; sm[1][rl][sub] = db;
   __syncthreads();
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, float* __restrict__ dx, int lddx,
-                                                          float* __restrict__ ws, long rows, int C) {
+                                                          const float* __restrict__ dadd, int ldadd, float* __restrict__ ws, long rows, int C) {
   extern __shared__ float sm[];  // [4 waves][2][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int per = (C + 63) / 64;
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
       const int c = lane + i * 64;
-      if (i < per && c < C) dx[r * lddx + c] = rs * (g[i] - s1 - xh[i] * s2);
+      if (i < per && c < C) dx[r * lddx + c] = rs * (g[i] - s1 - xh[i] * s2) + (dadd ? dadd[r * ldadd + c] : 0.f);
     }
   }
 #pragma unroll
@@ -431,23 +433,25 @@ extern "C" int clc_layernorm_fwd(const float* x, int ldx, const float* gamma, co
   return 0;
 }
 
-static int ln_bwd_blocks(long rows) { long b = (rows + 127) / 128; return (int)(b < 1 ? 1 : (b > 512 ? 512 : b)); }
+// (16 rows per block on the 16x16 maps of the slice loop: 2048 rows -> 128 blocks instead of 16 serial ones)
+static int ln_bwd_blocks(long rows) { long b = (rows + 15) / 16; return (int)(b < 1 ? 1 : (b > 512 ? 512 : b)); }
 
 extern "C" size_t clc_layernorm_bwd_workspace_bytes(long rows, int C) { return (size_t)ln_bwd_blocks(rows) * 2 * C * sizeof(float); }
 
 extern "C" int clc_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* mean,
-                                 const float* rstd, float* dx, int lddx, float* dgamma, float* dbeta, int accumulate, long rows,
-                                 int C, void* ws, size_t ws_bytes, clc_stream_t stream) {
+                                 const float* rstd, float* dx, int lddx, const float* dx_add, int ld_add, float* dgamma, float* dbeta,
+                                 int accumulate, long rows, int C, void* ws, size_t ws_bytes, clc_stream_t stream) {
   CLC_CHECK(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0, "clc_layernorm_bwd: bad args");
   CLC_CHECK(C <= 64 * LN_MAX_PER_LANE, "clc_layernorm_bwd: C=%d too large", C);
   CLC_CHECK(ws && ws_bytes >= clc_layernorm_bwd_workspace_bytes(rows, C), "clc_layernorm_bwd: workspace too small");
   const int nb = ln_bwd_blocks(rows);
-  const bool vec = (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) && aligned16(ws);
-  if (vec && C == 64) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<16>, dim3(nb), dim3(256), 0, ST, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, (float*)ws, rows);
-  else if (vec && C == 128) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<32>, dim3(nb), dim3(256), 0, ST, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, (float*)ws, rows);
-  else if (vec && C == 256) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<64>, dim3(nb), dim3(256), 0, ST, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, (float*)ws, rows);
+  const bool vec = (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) && aligned16(ws) &&
+                   (dx_add == nullptr || (ld_add % 4 == 0 && aligned16(dx_add)));
+  if (vec && C == 64) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<16>, dim3(nb), dim3(256), 0, ST, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ld_add, (float*)ws, rows);
+  else if (vec && C == 128) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<32>, dim3(nb), dim3(256), 0, ST, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ld_add, (float*)ws, rows);
+  else if (vec && C == 256) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<64>, dim3(nb), dim3(256), 0, ST, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ld_add, (float*)ws, rows);
   else hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), (size_t)8 * C * sizeof(float), ST, dy, lddy, x, ldx, gamma, mean, rstd, dx,
-                     lddx, (float*)ws, rows, C);
+                     lddx, dx_add, ld_add, (float*)ws, rows, C);
   CLC_LAUNCH_CHECK();
   hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, ST, (const float*)ws, nb, C, dgamma, dbeta, accumulate);
   CLC_LAUNCH_CHECK();

@@ -72,11 +72,12 @@ class Conv2d(nn.Conv2d):
         self.weight.data = self.weight.data.contiguous(memory_format=CL)
         self.weight._clc_is_filter = True
 
-    def forward(self, x, act=ACT_NONE, res=None, res_scale=1.0, res_first=False, shuffle=False, pair=None):
-        """pair: a second Conv2d of the same shape applied to the second half of the batch in the same launch."""
+    def forward(self, x, act=ACT_NONE, res=None, res_scale=1.0, res_first=False, shuffle=False, pair=None, fold_in=None, fold_out=None):
+        """pair: a second Conv2d of the same shape applied to the second half of the batch in the same launch.
+        fold_in / fold_out: ops.GradFold of a residual block (see there)."""
         return ops.conv2d(x, self.weight, self.bias, stride=self.stride[0], act=act, res=res, res_scale=res_scale,
                           res_first=res_first, shuffle=shuffle, w2=pair.weight if pair is not None else None,
-                          b2=pair.bias if pair is not None else None)
+                          b2=pair.bias if pair is not None else None, fold_in=fold_in, fold_out=fold_out)
 
 
 class Linear(nn.Linear):
@@ -86,9 +87,9 @@ class Linear(nn.Linear):
         super().__init__(*a, **kw)
         self.weight._clc_is_filter = True
 
-    def forward(self, x, act=ACT_NONE, res=None, pair=None):
+    def forward(self, x, act=ACT_NONE, res=None, pair=None, fold_in=None, fold_out=None):
         return ops.linear(x, self.weight, self.bias, act=act, res=res, w2=pair.weight if pair is not None else None,
-                          b2=pair.bias if pair is not None else None)
+                          b2=pair.bias if pair is not None else None, fold_in=fold_in, fold_out=fold_out)
 
 
 def _halves(x):
@@ -96,9 +97,9 @@ def _halves(x):
 
 
 class LayerNorm(nn.LayerNorm):
-    def forward(self, x, pair=None):
+    def forward(self, x, pair=None, fold_in=None):
         if pair is None:
-            return ops.layernorm(x, self.weight, self.bias)
+            return ops.layernorm(x, self.weight, self.bias, fold_in)
         a, b = _halves(x)   # per-module affine parameters: one launch per half
         return torch.cat((ops.layernorm(a, self.weight, self.bias), ops.layernorm(b, pair.weight, pair.bias)), dim=0)
 
@@ -214,9 +215,11 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x, extra_identity=0.0):
         """lrelu(conv2(lrelu(conv1 x))) + identity (+ extra_identity * x, used by ConvTransBlock's `+ conv_x`)."""
-        t = self.conv1(x, act=ACT_LRELU)
         if self.skip is None:
-            return self.conv2(t, act=ACT_LRELU, res=x, res_scale=1.0 + extra_identity)
+            f = ops.GradFold() if x.requires_grad else None   # d(identity) is added in conv1's data-gradient epilogue
+            t = self.conv1(x, act=ACT_LRELU, fold_in=f)
+            return self.conv2(t, act=ACT_LRELU, res=x, res_scale=1.0 + extra_identity, fold_out=f)
+        t = self.conv1(x, act=ACT_LRELU)
         out = self.conv2(t, act=ACT_LRELU, res=self.skip(x))
         return out + extra_identity * x if extra_identity else out
 
@@ -230,9 +233,10 @@ class ResidualUnit(nn.Module):
 
     def forward(self, x, pair=None):
         q = pair.conv if pair is not None else (None,) * 5
-        t = self.conv[0](x, act=ACT_RELU, pair=q[0])
+        f = ops.GradFold() if x.requires_grad else None
+        t = self.conv[0](x, act=ACT_RELU, pair=q[0], fold_in=f)
         t = self.conv[2](t, act=ACT_RELU, pair=q[2])
-        return self.conv[4](t, act=ACT_RELU, res=x, res_first=True, pair=q[4])
+        return self.conv[4](t, act=ACT_RELU, res=x, res_first=True, pair=q[4], fold_out=f)
 
 
 class AttentionBlock(nn.Module):
@@ -262,11 +266,11 @@ class WMSA(nn.Module):
             torch.nn.init.trunc_normal_(torch.zeros(self.n_heads, 2 * window_size - 1, 2 * window_size - 1), std=0.02))
         self.linear = Linear(input_dim, output_dim)
 
-    def forward(self, x, res=None, pair=None):
+    def forward(self, x, res=None, pair=None, fold_out=None):
         if pair is None:
             qkv = self.embedding_layer(x)
             a = ops.window_attention(qkv, self.relative_position_params, self.n_heads, self.window_size, self.type != "W")
-            return self.linear(a, res=res)
+            return self.linear(a, res=res, fold_out=fold_out)
         qkv = self.embedding_layer(x, pair=pair.embedding_layer)
         q1, q2 = _halves(qkv)   # per-module relative-position tables: one attention launch per half
         a = torch.cat((ops.window_attention(q1, self.relative_position_params, self.n_heads, self.window_size, self.type != "W"),
@@ -289,9 +293,12 @@ class Block(nn.Module):
 
     def forward(self, x, pair=None):
         if pair is None:
-            x = self.msa(self.ln1(x), res=x)
-            h = self.mlp[0](self.ln2(x), act=ACT_GELU)
-            return self.mlp[2](h, res=x)
+            # x + f(LN(x)) twice: the residual gradients are added inside the LayerNorm backward passes
+            f1 = ops.GradFold() if x.requires_grad else None
+            x = self.msa(self.ln1(x, fold_in=f1), res=x, fold_out=f1)
+            f2 = ops.GradFold() if x.requires_grad else None
+            h = self.mlp[0](self.ln2(x, fold_in=f2), act=ACT_GELU)
+            return self.mlp[2](h, res=x, fold_out=f2)
         x = self.msa(self.ln1(x, pair=pair.ln1), res=x, pair=pair.msa)
         h = self.mlp[0](self.ln2(x, pair=pair.ln2), act=ACT_GELU, pair=pair.mlp[0])
         return self.mlp[2](h, res=x, pair=pair.mlp[2])
@@ -307,11 +314,12 @@ class ConvTransBlock(nn.Module):
         self.conv_block = ResidualBlock(conv_dim, conv_dim)
 
     def forward(self, x):
-        u = self.conv1_1(x)
+        f = ops.GradFold() if x.requires_grad else None   # d(x) of the outer residual rides in conv1_1's data-gradient epilogue
+        u = self.conv1_1(x, fold_in=f)
         c, t = ops.split_channels(u, (self.conv_dim, self.trans_dim))   # strided views, read in place by the kernels
         c = self.conv_block(c, extra_identity=1.0)
         t = self.trans_block(t)
-        return self.conv1_2(torch.cat((c, t), dim=1), res=x)
+        return self.conv1_2(torch.cat((c, t), dim=1), res=x, fold_out=f)
 
 
 class SwinBlock(nn.Module):

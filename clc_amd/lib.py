@@ -68,7 +68,7 @@ SIGNATURES = {
     "clc_colsum": (_i, [fp, _i, _l, _i, fp, _i, fp, _sz, fp]),
     "clc_layernorm_fwd": (_i, [fp, _i, fp, fp, fp, _i, fp, fp, _l, _i, fp]),
     "clc_layernorm_bwd_workspace_bytes": (_sz, [_l, _i]),
-    "clc_layernorm_bwd": (_i, [fp, _i, fp, _i, fp, fp, fp, fp, _i, fp, fp, _i, _l, _i, fp, _sz, fp]),
+    "clc_layernorm_bwd": (_i, [fp, _i, fp, _i, fp, fp, fp, fp, _i, fp, _i, fp, fp, _i, _l, _i, fp, _sz, fp]),
     "clc_gdn_bwd_elem": (_i, [fp, fp, fp, fp, fp, _l, _i, fp]),
     "clc_gdn_bwd_combine": (_i, [fp, fp, fp, fp, _l, fp]),
     "clc_gdn_reparam_fwd": (_i, [fp, fp, _i, _f, _f, _f, fp, fp, fp, fp]),

@@ -123,6 +123,34 @@ class fork:
         _KEEPALIVE.append(outputs)
 
 
+class GradFold:
+    """Folds the gradient add of a two-consumer tensor into a kernel epilogue.
+
+    x feeds (a) a residual add inside a later layer's epilogue and (b) an earlier layer (conv / LayerNorm) of the branch
+    that ends in that add — ResidualUnit, ResidualBlock, Block and ConvTransBlock all have this shape (CLC_run.py:172-220,
+    CompressAI layers).  Backward reaches (a) first: instead of returning d(residual) to autograd (which would launch an
+    elementwise add when (b)'s gradient arrives), (a) parks it here and (b)'s gradient kernel adds it in its epilogue.  If the
+    order is ever the other way round, (a) finds `consumed` set and returns its gradient to autograd as usual."""
+
+    __slots__ = ("pending", "scale", "consumed")
+
+    def __init__(self):
+        self.pending, self.scale, self.consumed = None, 1.0, False
+
+    def park(self, g, scale=1.0):
+        """-> True when parked (the caller then returns None for that input)."""
+        if self.consumed or self.pending is not None:
+            return False
+        self.pending, self.scale = g, float(scale)
+        return True
+
+    def take(self):
+        self.consumed = True
+        g, s = self.pending, self.scale
+        self.pending = None
+        return g, s
+
+
 # when set to a list, every conv / wgrad launch is bracketed by HIP events on the launch stream and recorded as
 # (kernel family, tile-variant id, algorithmic FLOPs, start event, end event) — used by bench.py's roofline leg
 PROFILE = None
@@ -359,7 +387,7 @@ class _ConvFn(Function):
     the batch is convolved with the second filter set in the same launch (paired layers)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, res, ks, stride, act, res_scale, shuffle, res_first, w2=None, b2=None):
+    def forward(ctx, x, w, b, res, ks, stride, act, res_scale, shuffle, res_first, w2=None, b2=None, fold_in=None, fold_out=None):
         wk = to_kernel_weight(w)
         wk2 = to_kernel_weight(w2) if w2 is not None else None
         need_grad = any(ctx.needs_input_grad)
@@ -382,6 +410,7 @@ class _ConvFn(Function):
         ctx.use_pre = save_pre
         ctx.bias_ref = b
         ctx.pair = (w2, b2)
+        ctx.folds = (fold_in, fold_out)   # GradFold: fold_in is added in this layer's data-gradient epilogue, fold_out receives d(res)
         ctx.save_for_backward(x, w, saved_act)
         return y
 
@@ -425,9 +454,13 @@ class _ConvFn(Function):
             dz = dy if (act == ACT_NONE or fuse) else act_bwd(dy, saved_act, ctx.use_pre, act)
         fa = dict(xs=saved_act, xs_act=act, xs_pre=ctx.use_pre) if fuse else {}
         dres = None
+        fold_in, fold_out = ctx.folds
         if need_res:
             dsrc = dz if res_first else dy  # residual added before / after the activation
-            dres = dsrc if res_scale == 1.0 else dsrc * res_scale
+            if fold_out is not None and not shuffle and fold_out.park(dsrc, res_scale):
+                dres = None          # the branch's first layer adds res_scale * dsrc in its gradient epilogue
+            else:
+                dres = dsrc if res_scale == 1.0 else dsrc * res_scale
         if shuffle and not one_pass_unshuffle:  # undo PixelShuffle(2): [N, C/4, 2H, 2W] -> [N, C, H, W]
             dz = torch.nn.functional.pixel_unshuffle(dz, 2).contiguous(memory_format=CL)
         dx = dw = db = dw2 = db2 = None
@@ -448,19 +481,23 @@ class _ConvFn(Function):
                 if wt is None:
                     wt = filter_transpose(to_kernel_weight(wp), Cout, ks * ks, Cin)
                 return wt.view(Cin, -1)
+            extra, extra_scale = fold_in.take() if fold_in is not None else (None, 1.0)
             dx = conv_raw(dz, wt_of(w), None, ks=ks, stride=stride, pad=pad, transposed=True, out_hw=(x.shape[2], x.shape[3]),
-                          w2=(wt_of(w2) if w2 is not None else None), **fa)
-        return dx, dw, db, dres, None, None, None, None, None, None, dw2, db2
+                          w2=(wt_of(w2) if w2 is not None else None), res=extra, res_scale=extra_scale, **fa)
+        elif fold_in is not None:
+            fold_in.consumed = True
+        return dx, dw, db, dres, None, None, None, None, None, None, dw2, db2, None, None
 
 
-def conv2d(x, w, b=None, *, stride=1, act=ACT_NONE, res=None, res_scale=1.0, shuffle=False, res_first=False, w2=None, b2=None):
+def conv2d(x, w, b=None, *, stride=1, act=ACT_NONE, res=None, res_scale=1.0, shuffle=False, res_first=False, w2=None, b2=None,
+           fold_in=None, fold_out=None):
     ks = w.shape[2] if w.dim() == 4 else 1
-    return _ConvFn.apply(x, w, b, res, ks, stride, act, float(res_scale), bool(shuffle), bool(res_first), w2, b2)
+    return _ConvFn.apply(x, w, b, res, ks, stride, act, float(res_scale), bool(shuffle), bool(res_first), w2, b2, fold_in, fold_out)
 
 
-def linear(x, w, b=None, *, act=ACT_NONE, res=None, w2=None, b2=None):
+def linear(x, w, b=None, *, act=ACT_NONE, res=None, w2=None, b2=None, fold_in=None, fold_out=None):
     """nn.Linear on channels (tokens are pixels): x [N,Cin,H,W] pixel-major, w [Cout,Cin]."""
-    return _ConvFn.apply(x, w, b, res, 1, 1, act, 1.0, False, False, w2, b2)
+    return _ConvFn.apply(x, w, b, res, 1, 1, act, 1.0, False, False, w2, b2, fold_in, fold_out)
 
 
 # ----------------------------------------------------------------------------------- split / chunk
@@ -632,10 +669,11 @@ def gdn_param(x, gamma, beta, gamma_bound, beta_bound, pedestal, inverse=False, 
 
 class _LayerNormFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta):
+    def forward(ctx, x, gamma, beta, fold_in=None):
         x, xp, N, H, W, Cc, ldx = nhwc(x)
         rows = N * H * W
         y = new_act(N, Cc, H, W, x)
+        ctx.fold_in = fold_in
         need = any(ctx.needs_input_grad)
         mean = torch.empty(rows, device=x.device, dtype=torch.float32) if need else None
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if need else None
@@ -657,13 +695,19 @@ class _LayerNormFn(Function):
         dg, db = (gg, gb) if direct else (torch.empty_like(gamma), torch.empty_like(gamma))
         nbytes = _L().clc_layernorm_bwd_workspace_bytes(rows, Cc)
         ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
-        _lib.check(_L().clc_layernorm_bwd(dyp, lddy, xp, ldx, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), Cc,
+        extra, extra_scale = ctx.fold_in.take() if ctx.fold_in is not None else (None, 1.0)
+        ep, lde = None, 0
+        if extra is not None:
+            if extra_scale != 1.0:
+                extra = extra * extra_scale
+            extra, ep, *_q, lde = nhwc(extra)
+        _lib.check(_L().clc_layernorm_bwd(dyp, lddy, xp, ldx, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), Cc, ep, lde,
                                           dg.data_ptr(), db.data_ptr(), int(direct), rows, Cc, ws.data_ptr(), nbytes, _stream()), "clc_layernorm_bwd")
-        return (dx, None, None) if direct else (dx, dg, db)
+        return (dx, None, None, None) if direct else (dx, dg, db, None)
 
 
-def layernorm(x, gamma, beta):
-    return _LayerNormFn.apply(x, gamma, beta)
+def layernorm(x, gamma, beta, fold_in=None):
+    return _LayerNormFn.apply(x, gamma, beta, fold_in)
 
 
 # ------------------------------------------------------------------------------ window attention

@@ -132,11 +132,12 @@ int clc_colsum(const float* x, int ld, long rows, int C, float* out, int accumul
  * fwd saves mean/rstd per row when non-NULL. */
 int clc_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, float* mean,
                       float* rstd, long rows, int C, clc_stream_t stream);
-/* dx; dgamma/dbeta partial sums go through ws (deterministic two-stage) */
+/* dx (+ dx_add when non-NULL: the gradient of the residual branch x + f(LN(x)), CLC_run.py:190-191, folded into the same
+ * pass); dgamma/dbeta partial sums go through ws (deterministic two-stage) */
 size_t clc_layernorm_bwd_workspace_bytes(long rows, int C);
 int clc_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* mean,
-                      const float* rstd, float* dx, int lddx, float* dgamma, float* dbeta, int accumulate, long rows,
-                      int C, void* ws, size_t ws_bytes, clc_stream_t stream);
+                      const float* rstd, float* dx, int lddx, const float* dx_add, int ld_add, float* dgamma, float* dbeta,
+                      int accumulate, long rows, int C, void* ws, size_t ws_bytes, clc_stream_t stream);
 
 /* GDN backward pieces (CompressAI GDN inside ResidualBlockWithStride / ResidualBlockUpsample):
  * given dy, x, norm v = beta + gamma.x^2 :  dx_direct = dy * f(v);  dv = dy * x * f'(v)
