@@ -441,7 +441,7 @@ extern "C" size_t clc_layernorm_bwd_workspace_bytes(long rows, int C) { return (
 extern "C" int clc_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* mean,
                                  const float* rstd, float* dx, int lddx, const float* dx_add, int ld_add, float* dgamma, float* dbeta,
                                  int accumulate, long rows, int C, void* ws, size_t ws_bytes, clc_stream_t stream) {
-  CLC_CHECK(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && rows > 0, "clc_layernorm_bwd: bad args");
+  CLC_CHECK(dy && x && gamma && mean && rstd && dx && ((dgamma == nullptr) == (dbeta == nullptr)) && rows > 0, "clc_layernorm_bwd: bad args");
   CLC_CHECK(C <= 64 * LN_MAX_PER_LANE, "clc_layernorm_bwd: C=%d too large", C);
   CLC_CHECK(ws && ws_bytes >= clc_layernorm_bwd_workspace_bytes(rows, C), "clc_layernorm_bwd: workspace too small");
   const int nb = ln_bwd_blocks(rows);
@@ -453,8 +453,58 @@ extern "C" int clc_layernorm_bwd(const float* dy, int lddy, const float* x, int 
   else hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), (size_t)8 * C * sizeof(float), ST, dy, lddy, x, ldx, gamma, mean, rstd, dx,
                      lddx, dx_add, ld_add, (float*)ws, rows, C);
   CLC_LAUNCH_CHECK();
+  if (dgamma == nullptr) return 0;   // partial rows [blocks][2][C] stay in ws for clc_partial_reduce_batched
   hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, ST, (const float*)ws, nb, C, dgamma, dbeta, accumulate);
   CLC_LAUNCH_CHECK();
+  return 0;
+}
+
+// Deferred parameter-gradient reductions (LayerNorm gamma/beta, relative-position bias): every backward kernel leaves its
+// per-block partial rows in a workspace; ONE launch per step (per 64 entries) sums them all — instead of one 5-16 us
+// reduce launch behind each of the ~110 LayerNorm / attention backward kernels of a step.
+constexpr int kMaxReduce = 64;
+struct ReduceGroup {
+  int count;
+  int blk_end[kMaxReduce];            // exclusive prefix of workgroups (32 columns each)
+  clc_reduce_entry e[kMaxReduce];
+};
+// out[i] (+)= sum_b partial[b][i]; 32 columns x 8 interleaved block groups per workgroup, combined in a fixed tree
+__global__ __launch_bounds__(256) void partial_reduce_batched_kernel(const ReduceGroup g) {
+  __shared__ float sm[8][32];
+  int idx = 0;
+  while (idx + 1 < g.count && (int)blockIdx.x >= g.blk_end[idx]) ++idx;
+  const clc_reduce_entry e = g.e[idx];
+  const int b0 = idx == 0 ? 0 : g.blk_end[idx - 1];
+  const int tx = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int i = ((int)blockIdx.x - b0) * 32 + tx;
+  float s = 0.f;
+  if (i < e.n)
+    for (int b = grp; b < e.nblocks; b += 8) s += e.partial[(size_t)b * e.n + i];
+  sm[grp][tx] = s;
+  __syncthreads();
+  if (grp == 0 && i < e.n) {
+    const float t = ((sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx])) + ((sm[4][tx] + sm[5][tx]) + (sm[6][tx] + sm[7][tx]));
+    float* out = i < e.split ? e.out0 + i : e.out1 + (i - e.split);
+    *out = (e.accumulate ? *out : 0.f) + t;
+  }
+}
+
+extern "C" int clc_partial_reduce_batched(const clc_reduce_entry* entries, int count, clc_stream_t stream) {
+  CLC_CHECK(entries && count > 0, "clc_partial_reduce_batched: bad args");
+  for (int base = 0; base < count; base += kMaxReduce) {
+    ReduceGroup g;
+    g.count = count - base < kMaxReduce ? count - base : kMaxReduce;
+    int blocks = 0;
+    for (int k = 0; k < g.count; ++k) {
+      const clc_reduce_entry& e = entries[base + k];
+      CLC_CHECK(e.partial && e.out0 && e.nblocks > 0 && e.n > 0 && e.split >= 0 && (e.split >= e.n || e.out1), "clc_partial_reduce_batched: bad entry %d", base + k);
+      g.e[k] = e;
+      blocks += (e.n + 31) / 32;
+      g.blk_end[k] = blocks;
+    }
+    hipLaunchKernelGGL(partial_reduce_batched_kernel, dim3(blocks), dim3(256), 0, ST, g);
+    CLC_LAUNCH_CHECK();
+  }
   return 0;
 }
 

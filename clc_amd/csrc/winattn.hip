@@ -342,7 +342,7 @@ extern "C" size_t clc_winattn_bwd_workspace_bytes(int B, int H, int W, int heads
 extern "C" int clc_winattn_bwd(const float* dout, int lddo, const float* qkv, int ldq, const float* relbias, const float* out, int ldo,
                                const float* lse, float* dqkv, int lddq, float* drelbias, int accumulate, int B, int H, int W, int C,
                                int heads, int ws, int shift, void* wsb, size_t ws_bytes, clc_stream_t stream) {
-  CLC_CHECK(dout && qkv && relbias && out && lse && dqkv && drelbias, "clc_winattn_bwd: null pointer");
+  CLC_CHECK(dout && qkv && relbias && out && lse && dqkv, "clc_winattn_bwd: null pointer");
   CLC_CHECK(ldo >= C && ldo % 4 == 0 && aligned16(out), "clc_winattn_bwd: bad out");
   if (check_geom("clc_winattn_bwd", B, H, W, C, heads, ws, lddo, ldq)) return -1;
   CLC_CHECK(lddq >= 3 * C && lddq % 4 == 0, "clc_winattn_bwd: bad lddq");
@@ -359,6 +359,7 @@ extern "C" int clc_winattn_bwd(const float* dout, int lddo, const float* qkv, in
   if (ws == 8) DISPATCH(winattn_bwd_kernel, 64, hd, grid, p, (hipStream_t)stream);
   else DISPATCH(winattn_bwd_kernel, 16, hd, grid, p, (hipStream_t)stream);
   CLC_LAUNCH_CHECK();
+  if (drelbias == nullptr) return 0;   // partial rows [blocks][n] stay in wsb for clc_partial_reduce_batched
   const int n = heads * (2 * ws - 1) * (2 * ws - 1);
   hipLaunchKernelGGL(dbias_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, (hipStream_t)stream, (const float*)wsb, nbx, n, drelbias, accumulate);
   CLC_LAUNCH_CHECK();

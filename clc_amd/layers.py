@@ -72,12 +72,12 @@ class Conv2d(nn.Conv2d):
         self.weight.data = self.weight.data.contiguous(memory_format=CL)
         self.weight._clc_is_filter = True
 
-    def forward(self, x, act=ACT_NONE, res=None, res_scale=1.0, res_first=False, shuffle=False, pair=None, fold_in=None, fold_out=None):
+    def forward(self, x, act=ACT_NONE, res=None, res_scale=1.0, res_first=False, shuffle=False, pair=None, fold_in=None, fold_out=None, out=None):
         """pair: a second Conv2d of the same shape applied to the second half of the batch in the same launch.
         fold_in / fold_out: ops.GradFold of a residual block (see there)."""
         return ops.conv2d(x, self.weight, self.bias, stride=self.stride[0], act=act, res=res, res_scale=res_scale,
                           res_first=res_first, shuffle=shuffle, w2=pair.weight if pair is not None else None,
-                          b2=pair.bias if pair is not None else None, fold_in=fold_in, fold_out=fold_out)
+                          b2=pair.bias if pair is not None else None, fold_in=fold_in, fold_out=fold_out, out=out)
 
 
 class Linear(nn.Linear):
@@ -87,9 +87,9 @@ class Linear(nn.Linear):
         super().__init__(*a, **kw)
         self.weight._clc_is_filter = True
 
-    def forward(self, x, act=ACT_NONE, res=None, pair=None, fold_in=None, fold_out=None):
+    def forward(self, x, act=ACT_NONE, res=None, pair=None, fold_in=None, fold_out=None, out=None):
         return ops.linear(x, self.weight, self.bias, act=act, res=res, w2=pair.weight if pair is not None else None,
-                          b2=pair.bias if pair is not None else None, fold_in=fold_in, fold_out=fold_out)
+                          b2=pair.bias if pair is not None else None, fold_in=fold_in, fold_out=fold_out, out=out)
 
 
 def _halves(x):
@@ -213,12 +213,13 @@ class ResidualBlock(nn.Module):
         self.conv2 = conv3x3(out_ch, out_ch)
         self.skip = conv1x1(in_ch, out_ch) if in_ch != out_ch else None
 
-    def forward(self, x, extra_identity=0.0):
+    def forward(self, x, extra_identity=0.0, out=None):
         """lrelu(conv2(lrelu(conv1 x))) + identity (+ extra_identity * x, used by ConvTransBlock's `+ conv_x`)."""
         if self.skip is None:
             f = ops.GradFold() if x.requires_grad else None   # d(identity) is added in conv1's data-gradient epilogue
             t = self.conv1(x, act=ACT_LRELU, fold_in=f)
-            return self.conv2(t, act=ACT_LRELU, res=x, res_scale=1.0 + extra_identity, fold_out=f)
+            return self.conv2(t, act=ACT_LRELU, res=x, res_scale=1.0 + extra_identity, fold_out=f, out=out)
+        assert out is None
         t = self.conv1(x, act=ACT_LRELU)
         out = self.conv2(t, act=ACT_LRELU, res=self.skip(x))
         return out + extra_identity * x if extra_identity else out
@@ -291,14 +292,15 @@ class Block(nn.Module):
         self.ln2 = LayerNorm(input_dim)
         self.mlp = nn.Sequential(Linear(input_dim, 4 * input_dim), GELU(), Linear(4 * input_dim, output_dim))
 
-    def forward(self, x, pair=None):
+    def forward(self, x, pair=None, out=None):
         if pair is None:
             # x + f(LN(x)) twice: the residual gradients are added inside the LayerNorm backward passes
             f1 = ops.GradFold() if x.requires_grad else None
             x = self.msa(self.ln1(x, fold_in=f1), res=x, fold_out=f1)
             f2 = ops.GradFold() if x.requires_grad else None
             h = self.mlp[0](self.ln2(x, fold_in=f2), act=ACT_GELU)
-            return self.mlp[2](h, res=x, fold_out=f2)
+            return self.mlp[2](h, res=x, fold_out=f2, out=out)
+        assert out is None
         x = self.msa(self.ln1(x, pair=pair.ln1), res=x, pair=pair.msa)
         h = self.mlp[0](self.ln2(x, pair=pair.ln2), act=ACT_GELU, pair=pair.mlp[0])
         return self.mlp[2](h, res=x, pair=pair.mlp[2])
@@ -317,9 +319,11 @@ class ConvTransBlock(nn.Module):
         f = ops.GradFold() if x.requires_grad else None   # d(x) of the outer residual rides in conv1_1's data-gradient epilogue
         u = self.conv1_1(x, fold_in=f)
         c, t = ops.split_channels(u, (self.conv_dim, self.trans_dim))   # strided views, read in place by the kernels
-        c = self.conv_block(c, extra_identity=1.0)
-        t = self.trans_block(t)
-        return self.conv1_2(torch.cat((c, t), dim=1), res=x, fold_out=f)
+        # the two branches write their results straight into the channel halves of conv1_2's input (no concatenation copy)
+        buf = ops.new_act(u.shape[0], self.conv_dim + self.trans_dim, u.shape[2], u.shape[3], u)
+        c = self.conv_block(c, extra_identity=1.0, out=buf[:, : self.conv_dim])
+        t = self.trans_block(t, out=buf[:, self.conv_dim:])
+        return self.conv1_2(ops.cat_halves(c, t, buf), res=x, fold_out=f)
 
 
 class SwinBlock(nn.Module):

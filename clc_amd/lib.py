@@ -46,6 +46,10 @@ class TransposeEntry(C.Structure):
     _fields_ = [("w", fp), ("wt", fp), ("Cout", C.c_int), ("T", C.c_int), ("Cin", C.c_int), ("tile_begin", C.c_int)]
 
 
+class ReduceEntry(C.Structure):
+    _fields_ = [("partial", fp), ("nblocks", C.c_int), ("n", C.c_int), ("out0", fp), ("out1", fp), ("split", C.c_int), ("accumulate", C.c_int)]
+
+
 class ParamEntry(C.Structure):
     _fields_ = [("p", fp), ("g", fp), ("m", fp), ("v", fp), ("n", C.c_long)]
 
@@ -63,6 +67,7 @@ SIGNATURES = {
     "clc_conv2d_wgrad_batched": (_i, [C.POINTER(WgradDesc), _i, fp]),
     "clc_filter_transpose": (_i, [fp, fp, _i, _i, _i, fp]),
     "clc_filter_transpose_batched": (_i, [fp, _i, _i, fp]),
+    "clc_partial_reduce_batched": (_i, [C.POINTER(ReduceEntry), _i, fp]),
     "clc_act_bwd": (_i, [fp, _i, fp, _i, _i, _i, fp, _i, _l, _i, fp]),
     "clc_colsum_workspace_bytes": (_sz, [_l, _i]),
     "clc_colsum": (_i, [fp, _i, _l, _i, fp, _i, fp, _sz, fp]),

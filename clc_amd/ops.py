@@ -69,10 +69,39 @@ def flush_wgrads():
     _PENDING_FLOP[0] = 0.0
 
 
+# Deferred parameter-gradient reductions (LayerNorm gamma/beta, relative-position bias): the backward kernels leave their
+# per-block partial rows in their workspaces and ONE clc_partial_reduce_batched call per step sums them into the gradient
+# arena (join_side_streams) — instead of a 5-16 us reduce launch behind each of the ~110 backward kernels.
+DEFER_REDUCTIONS = False
+_PENDING_REDUCE = []
+
+
+def enable_deferred_reductions(enable=True):
+    global DEFER_REDUCTIONS
+    DEFER_REDUCTIONS = bool(enable)
+
+
+def defer_reduce(partial, nblocks, n, out0, out1, split):
+    e = _lib.ReduceEntry()
+    e.partial, e.nblocks, e.n = partial.data_ptr(), int(nblocks), int(n)
+    e.out0, e.out1, e.split, e.accumulate = out0.data_ptr(), (out1.data_ptr() if out1 is not None else None), int(split), 1
+    _PENDING_REDUCE.append((e, (partial, out0, out1)))
+
+
+def flush_reductions():
+    if not _PENDING_REDUCE:
+        return
+    arr = (_lib.ReduceEntry * len(_PENDING_REDUCE))(*[e for e, _ in _PENDING_REDUCE])
+    _lib.check(_L().clc_partial_reduce_batched(arr, len(_PENDING_REDUCE), _stream()), "clc_partial_reduce_batched")
+    _KEEPALIVE.append([k for _, k in _PENDING_REDUCE])
+    _PENDING_REDUCE.clear()
+
+
 def join_side_streams():
     if WGRAD_STREAM is not None:
         flush_wgrads()
         torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
+    flush_reductions()
     _KEEPALIVE.clear()
 
 
@@ -387,7 +416,7 @@ class _ConvFn(Function):
     the batch is convolved with the second filter set in the same launch (paired layers)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, res, ks, stride, act, res_scale, shuffle, res_first, w2=None, b2=None, fold_in=None, fold_out=None):
+    def forward(ctx, x, w, b, res, ks, stride, act, res_scale, shuffle, res_first, w2=None, b2=None, fold_in=None, fold_out=None, out_buf=None):
         wk = to_kernel_weight(w)
         wk2 = to_kernel_weight(w2) if w2 is not None else None
         need_grad = any(ctx.needs_input_grad)
@@ -404,7 +433,9 @@ class _ConvFn(Function):
         # the gradient kernels' loaders — no erf/exp there and no elementwise dz pass
         deriv = save_pre and act == ACT_GELU
         y = conv_raw(x, wk, b, ks=ks, stride=stride, act=act, res=res, res_scale=res_scale, res_first=res_first, y_pre=y_pre, shuffle=shuffle,
-                     w2=wk2, bias2=b2, pre_deriv=deriv)
+                     w2=wk2, bias2=b2, pre_deriv=deriv, out=out_buf)
+        if out_buf is not None:   # written in place into the caller's (strided) buffer: hand autograd a fresh alias of it
+            y = out_buf.detach()
         ctx.cfg = (ks, stride, ACT_SAVED_DERIV if deriv else act, res_scale, shuffle, b is not None, res is not None, res_first)
         saved_act = y_pre if save_pre else (y if act in (ACT_LRELU, ACT_RELU, ACT_HALFTANH) else None)
         ctx.use_pre = save_pre
@@ -486,18 +517,38 @@ class _ConvFn(Function):
                           w2=(wt_of(w2) if w2 is not None else None), res=extra, res_scale=extra_scale, **fa)
         elif fold_in is not None:
             fold_in.consumed = True
-        return dx, dw, db, dres, None, None, None, None, None, None, dw2, db2, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, dw2, db2, None, None, None
 
 
 def conv2d(x, w, b=None, *, stride=1, act=ACT_NONE, res=None, res_scale=1.0, shuffle=False, res_first=False, w2=None, b2=None,
-           fold_in=None, fold_out=None):
+           fold_in=None, fold_out=None, out=None):
+    """out: optional destination (a pixel-major view, e.g. a channel slice of a wider buffer) written in place."""
     ks = w.shape[2] if w.dim() == 4 else 1
-    return _ConvFn.apply(x, w, b, res, ks, stride, act, float(res_scale), bool(shuffle), bool(res_first), w2, b2, fold_in, fold_out)
+    return _ConvFn.apply(x, w, b, res, ks, stride, act, float(res_scale), bool(shuffle), bool(res_first), w2, b2, fold_in, fold_out, out)
 
 
-def linear(x, w, b=None, *, act=ACT_NONE, res=None, w2=None, b2=None, fold_in=None, fold_out=None):
+def linear(x, w, b=None, *, act=ACT_NONE, res=None, w2=None, b2=None, fold_in=None, fold_out=None, out=None):
     """nn.Linear on channels (tokens are pixels): x [N,Cin,H,W] pixel-major, w [Cout,Cin]."""
-    return _ConvFn.apply(x, w, b, res, 1, 1, act, 1.0, False, False, w2, b2, fold_in, fold_out)
+    return _ConvFn.apply(x, w, b, res, 1, 1, act, 1.0, False, False, w2, b2, fold_in, fold_out, out)
+
+
+class _CatHalvesFn(Function):
+    """cat((a, b), dim=1) where a and b were WRITTEN as the two channel ranges of `buf` by their producers (conv2d(out=...)):
+    no copy forward; backward hands each producer its channel range of the gradient as a strided view."""
+
+    @staticmethod
+    def forward(ctx, a, b, buf):
+        ctx.ca = a.shape[1]
+        assert a.data_ptr() == buf.data_ptr() and b.data_ptr() == buf.data_ptr() + 4 * ctx.ca and a.shape[1] + b.shape[1] == buf.shape[1]
+        return buf.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, : ctx.ca], g[:, ctx.ca:], None
+
+
+def cat_halves(a, b, buf):
+    return _CatHalvesFn.apply(a, b, buf)
 
 
 # ----------------------------------------------------------------------------------- split / chunk
@@ -701,8 +752,12 @@ class _LayerNormFn(Function):
             if extra_scale != 1.0:
                 extra = extra * extra_scale
             extra, ep, *_q, lde = nhwc(extra)
+        defer = direct and DEFER_REDUCTIONS
         _lib.check(_L().clc_layernorm_bwd(dyp, lddy, xp, ldx, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), Cc, ep, lde,
-                                          dg.data_ptr(), db.data_ptr(), int(direct), rows, Cc, ws.data_ptr(), nbytes, _stream()), "clc_layernorm_bwd")
+                                          None if defer else dg.data_ptr(), None if defer else db.data_ptr(), int(direct), rows, Cc,
+                                          ws.data_ptr(), nbytes, _stream()), "clc_layernorm_bwd")
+        if defer:
+            defer_reduce(ws, nbytes // (8 * Cc), 2 * Cc, dg, db, Cc)
         return (dx, None, None, None) if direct else (dx, dg, db, None)
 
 
@@ -743,8 +798,13 @@ class _WinAttnFn(Function):
         drb = grb if grb is not None else torch.empty_like(rb)
         nbytes = _L().clc_winattn_bwd_workspace_bytes(N, H, W, heads, ws)
         wsb = torch.empty((nbytes + 3) // 4, device=qkv.device, dtype=torch.float32)
+        defer = grb is not None and DEFER_REDUCTIONS
         _lib.check(_L().clc_winattn_bwd(dop, lddo, qp, ldq, rb.data_ptr(), out.data_ptr(), Cc, lse.data_ptr(), dqkv.data_ptr(), C3,
-                                        drb.data_ptr(), int(grb is not None), N, H, W, Cc, heads, ws, int(shift), wsb.data_ptr(), nbytes, _stream()), "clc_winattn_bwd")
+                                        None if defer else drb.data_ptr(), int(grb is not None), N, H, W, Cc, heads, ws, int(shift),
+                                        wsb.data_ptr(), nbytes, _stream()), "clc_winattn_bwd")
+        if defer:
+            nb_ = heads * (2 * ws - 1) * (2 * ws - 1)
+            defer_reduce(wsb, nbytes // (4 * nb_), nb_, drb, None, nb_)
         return dqkv, (None if grb is not None else drb), None, None, None
 
 

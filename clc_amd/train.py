@@ -263,6 +263,7 @@ class TrainEngine:
         if self.side_stream:
             ops.enable_wgrad_stream(True)
             ops.enable_branch_streams(True)
+        ops.enable_deferred_reductions(True)
         self.opt = FusedAdamW(live, lr=self.lr, max_norm=self.clip)
         self.aux_opt = FusedAdamW(aux, lr=self.aux_lr, max_norm=0.0)
         self.transposer = FilterTransposer(live)

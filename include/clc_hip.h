@@ -128,6 +128,14 @@ size_t clc_colsum_workspace_bytes(long rows, int C);
 int clc_colsum(const float* x, int ld, long rows, int C, float* out, int accumulate, void* ws, size_t ws_bytes,
                clc_stream_t stream);
 
+/* Deferred parameter-gradient reductions: out[i] (+)= sum_{b < nblocks} partial[b*n + i], i < n; columns i < split go to
+ * out0[i], the rest to out1[i - split] (LayerNorm: n = 2C, split = C, out0 = dgamma, out1 = dbeta; relative-position bias:
+ * split = n).  clc_layernorm_bwd with dgamma = dbeta = NULL and clc_winattn_bwd with drelbias = NULL leave their partial
+ * rows in the workspace (nblocks = workspace_bytes / (n * 4)); one call here sums up to 64 of them per launch, in a fixed
+ * order.  `entries` is a HOST array (copied into the kernel arguments). */
+typedef struct { const float* partial; int nblocks; int n; float* out0; float* out1; int split; int accumulate; } clc_reduce_entry;
+int clc_partial_reduce_batched(const clc_reduce_entry* entries, int count, clc_stream_t stream);
+
 /* LayerNorm over the channel dim of [rows, C] tokens (nn.LayerNorm, CLC_run.py:180,183), eps = 1e-5.
  * fwd saves mean/rstd per row when non-NULL. */
 int clc_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, float* mean,
