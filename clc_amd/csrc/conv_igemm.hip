@@ -30,6 +30,9 @@
 //                                    in the loop, all its tiles in flight at once), fixed-order
 //                                    tree combine through LDS.
 #include "common.h"
+#ifndef CLC_PF32
+#define CLC_PF32 3
+#endif
 
 namespace {
 
@@ -486,7 +489,7 @@ void conv_igemm_dma_kernel(const ConvParams p) {
 template <int BN, bool TR>
 __global__ __launch_bounds__(512, 1)
 void conv_igemm_splitk_kernel(const ConvParams p) {
-  constexpr int BM = 32, TN = BN / 32, KW = 8, PF = 3;   // PF = K-tiles prefetched per wave
+  constexpr int BM = 32, TN = BN / 32, KW = 8, PF = (BN == 32) ? CLC_PF32 : 3;   // PF = K-tiles prefetched per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];   // combine buffer [KW][TN][16][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
@@ -815,7 +818,15 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
     // re-use, so the smaller tile (2x the workgroups of 32x64) wins on every 16x16 shape measured
     // ... except the slice-parameter nets with multi-MB filters (448..704 -> 224), where halving the number of N tiles
     // halves the filter re-reads that dominate them
-    if ((size_t)d->Cout * d->ks * d->ks * d->Cin > 200000 && C > 32) return launch_splitk<64>(p, classes, st);
+    static const int sk_rule = getenv("CLC_SPLITK_RULE") ? atoi(getenv("CLC_SPLITK_RULE")) : 1;   // 0: old rule (A/B knob)
+    if (sk_rule == 0) {
+      if ((long)d->Cout * d->ks * d->ks * d->Cin > 200000 && C > 32) return launch_splitk<64>(p, classes, st);
+      return launch_splitk<32>(p, classes, st);
+    }
+    // 32x32 tiles while they fit the chip in one round (256 workgroups), 32x64 beyond that.  Both variants give every
+    // output element the same K order (same wave / K-tile assignment, same combine tree), so the choice may look at M.
+    const long wg32 = (long)((p.M + 31) / 32) * ((C + 31) / 32) * classes;
+    if (C > 32 && wg32 > 256) return launch_splitk<64>(p, classes, st);
     return launch_splitk<32>(p, classes, st);
   }
   if (img_pix <= 1024) {

@@ -24,6 +24,13 @@ SHAPES = [  # name, N, Cin, H, W, Cout, ks, stride
     ("n16_c448_224_3x3_16", 16, 448, 16, 16, 224, 3, 1),
     ("n16_c224_128_3x3_16", 16, 224, 16, 16, 128, 3, 1),
     ("c224_128_3x3_16", 8, 224, 16, 16, 128, 3, 1),
+    ("c128_512_1x1_16", 8, 128, 16, 16, 512, 1, 1),
+    ("c128_384_1x1_16", 8, 128, 16, 16, 384, 1, 1),
+    ("c384_128_1x1_16", 8, 384, 16, 16, 128, 1, 1),
+    ("c128_128_1x1_16", 8, 128, 16, 16, 128, 1, 1),
+    ("c128_64_3x3_16", 8, 128, 16, 16, 64, 3, 1),
+    ("c192_512_3x3_4", 8, 192, 4, 4, 512, 3, 1),
+    ("c128_1280_3x3_8", 8, 128, 8, 8, 1280, 3, 1),
 ]
 g = torch.Generator().manual_seed(0)
 for name, N, Cin, H, W, Cout, ks, s in SHAPES:
