@@ -57,6 +57,7 @@ struct ConvParams {
   int vec_epi;                 // every epilogue operand is 16-B addressable per 4 channels -> float4 epilogue
   const float* w2; const float* bias2; int group_rows;   // rows >= group_rows (second half of the batch) use w2 / bias2
   int pre_deriv;               // y_pre <- act'(v) instead of v
+  const float* res_gate; int ldg, rg_act, rg_pre;   // residual term *= act'(res_gate)
 };
 
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
@@ -154,14 +155,19 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, float acc, f
     pix = (size_t)m;
   }
   float v = acc + bv;
-  if (p.res && p.res_first) v += p.res_scale * p.res[pix * p.ldr + ch];
+  float rterm = 0.f;
+  if (p.res) {
+    rterm = p.res_scale * p.res[pix * p.ldr + ch];
+    if (p.res_gate) rterm *= act_deriv(p.res_gate[pix * p.ldg + ch], p.rg_act, p.rg_pre);
+  }
+  if (p.res && p.res_first) v += rterm;
   if (p.y_pre) p.y_pre[pix * p.ldp + ch] = p.pre_deriv ? act_deriv(v, p.act, 1) : v;
   if (p.norm != CLC_NORM_NONE) {
     const float mv = p.mul[pix * p.ldm + ch];
     v = (p.norm == CLC_NORM_GDN) ? mv * rsqrtf(v) : mv * sqrtf(v);
   }
   v = apply_act(v, p.act);
-  if (p.res && !p.res_first) v += p.res_scale * p.res[pix * p.ldr + ch];
+  if (p.res && !p.res_first) v += rterm;
   p.y[pix * p.ldy + ch] = v;
 }
 
@@ -180,8 +186,11 @@ __device__ __forceinline__ void epilogue_store4(const ConvParams& p, const float
   if (bias) { v[0] += bias[co]; v[1] += bias[co + 1]; v[2] += bias[co + 2]; v[3] += bias[co + 3]; }
   else { v[0] += 0.f; v[1] += 0.f; v[2] += 0.f; v[3] += 0.f; }
   f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-  if (p.res) rv = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + co);
-  if (p.res && p.res_first) v = v + p.res_scale * rv;
+  if (p.res) {
+    rv = p.res_scale * *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + co);
+    if (p.res_gate) rv = rv * act_deriv4(*reinterpret_cast<const f32x4*>(p.res_gate + pix * p.ldg + co), p.rg_act, p.rg_pre);
+  }
+  if (p.res && p.res_first) v = v + rv;
   if (p.y_pre) *reinterpret_cast<f32x4*>(p.y_pre + pix * p.ldp + co) = p.pre_deriv ? act_deriv4(v, p.act, 1) : v;
   if (p.norm != CLC_NORM_NONE) {
     const f32x4 mv = *reinterpret_cast<const f32x4*>(p.mul + pix * p.ldm + co);
@@ -190,7 +199,7 @@ __device__ __forceinline__ void epilogue_store4(const ConvParams& p, const float
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], p.act);
-  if (p.res && !p.res_first) v = v + p.res_scale * rv;
+  if (p.res && !p.res_first) v = v + rv;
   *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + co) = v;
 }
 
@@ -786,12 +795,13 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   }
   {
     auto ok4 = [](const void* ptr, int ld) { return ptr == nullptr || (aligned16(ptr) && ld % 4 == 0); };
-    p.vec_epi = !d->shuffle && d->Cout % 4 == 0 && ok4(d->y, d->ldy) && ok4(d->res, d->ldr) && ok4(d->mul, d->ldm) && ok4(d->y_pre, d->ldp);
+    p.vec_epi = !d->shuffle && d->Cout % 4 == 0 && ok4(d->y, d->ldy) && ok4(d->res, d->ldr) && ok4(d->mul, d->ldm) && ok4(d->y_pre, d->ldp) && ok4(d->res_gate, d->ldg);
   }
   int classes = 1;
   p.M = d->N * d->OH * d->OW;
   if (d->transposed && d->stride == 2) { classes = 4; p.M = d->N * (d->OH / 2) * (d->OW / 2); }
   p.w2 = d->w2; p.bias2 = d->bias2; p.group_rows = 0; p.pre_deriv = d->pre_deriv;
+  p.res_gate = d->res ? d->res_gate : nullptr; p.ldg = d->ldg; p.rg_act = d->res_gate_act; p.rg_pre = d->res_gate_pre;
   if (d->w2) {   // second half of the batch on a second filter set; rows are image-major, so the halves split at M/2
     CLC_CHECK(d->N % 2 == 0, "clc_conv2d: w2 needs an even batch (got N=%d)", d->N);
     CLC_CHECK((d->bias == nullptr) == (d->bias2 == nullptr), "clc_conv2d: bias / bias2 must both be given or both NULL");

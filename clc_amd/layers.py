@@ -72,12 +72,13 @@ class Conv2d(nn.Conv2d):
         self.weight.data = self.weight.data.contiguous(memory_format=CL)
         self.weight._clc_is_filter = True
 
-    def forward(self, x, act=ACT_NONE, res=None, res_scale=1.0, res_first=False, shuffle=False, pair=None, fold_in=None, fold_out=None, out=None):
+    def forward(self, x, act=ACT_NONE, res=None, res_scale=1.0, res_first=False, shuffle=False, pair=None, fold_in=None, fold_out=None, out=None,
+                grad_slot=None):
         """pair: a second Conv2d of the same shape applied to the second half of the batch in the same launch.
         fold_in / fold_out: ops.GradFold of a residual block (see there)."""
         return ops.conv2d(x, self.weight, self.bias, stride=self.stride[0], act=act, res=res, res_scale=res_scale,
                           res_first=res_first, shuffle=shuffle, w2=pair.weight if pair is not None else None,
-                          b2=pair.bias if pair is not None else None, fold_in=fold_in, fold_out=fold_out, out=out)
+                          b2=pair.bias if pair is not None else None, fold_in=fold_in, fold_out=fold_out, out=out, grad_slot=grad_slot)
 
 
 class Linear(nn.Linear):
@@ -97,9 +98,9 @@ def _halves(x):
 
 
 class LayerNorm(nn.LayerNorm):
-    def forward(self, x, pair=None, fold_in=None):
+    def forward(self, x, pair=None, fold_in=None, grad_slot=None):
         if pair is None:
-            return ops.layernorm(x, self.weight, self.bias, fold_in)
+            return ops.layernorm(x, self.weight, self.bias, fold_in, grad_slot)
         a, b = _halves(x)   # per-module affine parameters: one launch per half
         return torch.cat((ops.layernorm(a, self.weight, self.bias), ops.layernorm(b, pair.weight, pair.bias)), dim=0)
 
@@ -213,11 +214,11 @@ class ResidualBlock(nn.Module):
         self.conv2 = conv3x3(out_ch, out_ch)
         self.skip = conv1x1(in_ch, out_ch) if in_ch != out_ch else None
 
-    def forward(self, x, extra_identity=0.0, out=None):
+    def forward(self, x, extra_identity=0.0, out=None, grad_slot=None):
         """lrelu(conv2(lrelu(conv1 x))) + identity (+ extra_identity * x, used by ConvTransBlock's `+ conv_x`)."""
         if self.skip is None:
             f = ops.GradFold() if x.requires_grad else None   # d(identity) is added in conv1's data-gradient epilogue
-            t = self.conv1(x, act=ACT_LRELU, fold_in=f)
+            t = self.conv1(x, act=ACT_LRELU, fold_in=f, grad_slot=grad_slot)
             return self.conv2(t, act=ACT_LRELU, res=x, res_scale=1.0 + extra_identity, fold_out=f, out=out)
         assert out is None
         t = self.conv1(x, act=ACT_LRELU)
@@ -234,7 +235,7 @@ class ResidualUnit(nn.Module):
 
     def forward(self, x, pair=None):
         q = pair.conv if pair is not None else (None,) * 5
-        f = ops.GradFold() if x.requires_grad else None
+        f = ops.GradFold(gated=True) if x.requires_grad else None
         t = self.conv[0](x, act=ACT_RELU, pair=q[0], fold_in=f)
         t = self.conv[2](t, act=ACT_RELU, pair=q[2])
         return self.conv[4](t, act=ACT_RELU, res=x, res_first=True, pair=q[4], fold_out=f)
@@ -292,11 +293,11 @@ class Block(nn.Module):
         self.ln2 = LayerNorm(input_dim)
         self.mlp = nn.Sequential(Linear(input_dim, 4 * input_dim), GELU(), Linear(4 * input_dim, output_dim))
 
-    def forward(self, x, pair=None, out=None):
+    def forward(self, x, pair=None, out=None, grad_slot=None):
         if pair is None:
             # x + f(LN(x)) twice: the residual gradients are added inside the LayerNorm backward passes
             f1 = ops.GradFold() if x.requires_grad else None
-            x = self.msa(self.ln1(x, fold_in=f1), res=x, fold_out=f1)
+            x = self.msa(self.ln1(x, fold_in=f1, grad_slot=grad_slot), res=x, fold_out=f1)
             f2 = ops.GradFold() if x.requires_grad else None
             h = self.mlp[0](self.ln2(x, fold_in=f2), act=ACT_GELU)
             return self.mlp[2](h, res=x, fold_out=f2, out=out)
@@ -318,11 +319,13 @@ class ConvTransBlock(nn.Module):
     def forward(self, x):
         f = ops.GradFold() if x.requires_grad else None   # d(x) of the outer residual rides in conv1_1's data-gradient epilogue
         u = self.conv1_1(x, fold_in=f)
-        c, t = ops.split_channels(u, (self.conv_dim, self.trans_dim))   # strided views, read in place by the kernels
+        slots = ops.GradSlots() if u.requires_grad else None
+        cd, td = self.conv_dim, self.trans_dim
+        c, t = ops.split_channels(u, (cd, td), slots)   # strided views, read in place by the kernels
         # the two branches write their results straight into the channel halves of conv1_2's input (no concatenation copy)
         buf = ops.new_act(u.shape[0], self.conv_dim + self.trans_dim, u.shape[2], u.shape[3], u)
-        c = self.conv_block(c, extra_identity=1.0, out=buf[:, : self.conv_dim])
-        t = self.trans_block(t, out=buf[:, self.conv_dim:])
+        c = self.conv_block(c, extra_identity=1.0, out=buf[:, :cd], grad_slot=(slots, cd + td, 0) if slots is not None else None)
+        t = self.trans_block(t, out=buf[:, cd:], grad_slot=(slots, cd + td, cd) if slots is not None else None)
         return self.conv1_2(ops.cat_halves(c, t, buf), res=x, fold_out=f)
 
 

@@ -29,7 +29,8 @@ class ConvDesc(C.Structure):
                 ("y_pre", fp), ("ldp", C.c_int),
                 ("shuffle", C.c_int), ("res_first", C.c_int),
                 ("xs", fp), ("ldxs", C.c_int), ("xs_act", C.c_int), ("xs_pre", C.c_int),
-                ("w2", fp), ("bias2", fp), ("pre_deriv", C.c_int)]
+                ("w2", fp), ("bias2", fp), ("pre_deriv", C.c_int),
+                ("res_gate", fp), ("ldg", C.c_int), ("res_gate_act", C.c_int), ("res_gate_pre", C.c_int)]
 
 
 class WgradDesc(C.Structure):

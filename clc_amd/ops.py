@@ -165,23 +165,44 @@ class GradFold:
     elementwise add when (b)'s gradient arrives), (a) parks it here and (b)'s gradient kernel adds it in its epilogue.  If the
     order is ever the other way round, (a) finds `consumed` set and returns its gradient to autograd as usual."""
 
-    __slots__ = ("pending", "scale", "consumed")
+    __slots__ = ("pending", "scale", "gate", "consumed", "gated")
 
-    def __init__(self):
-        self.pending, self.scale, self.consumed = None, 1.0, False
+    def __init__(self, gated=False):
+        """gated: the folding layer is a convolution (its data-gradient epilogue can apply an activation-derivative gate)."""
+        self.pending, self.scale, self.gate, self.consumed, self.gated = None, 1.0, None, False, bool(gated)
 
-    def park(self, g, scale=1.0):
-        """-> True when parked (the caller then returns None for that input)."""
-        if self.consumed or self.pending is not None:
+    def can_park(self):
+        return not self.consumed and self.pending is None
+
+    def park(self, g, scale=1.0, gate=None):
+        """-> True when parked (the caller then returns None for that input).  gate = (saved, act, saved_is_pre): the parked
+        gradient still has to be multiplied by act'(saved) — only conv data-gradient epilogues can do that."""
+        if not self.can_park():
             return False
-        self.pending, self.scale = g, float(scale)
+        self.pending, self.scale, self.gate = g, float(scale), gate
         return True
 
     def take(self):
         self.consumed = True
-        g, s = self.pending, self.scale
-        self.pending = None
-        return g, s
+        g, s, gate = self.pending, self.scale, self.gate
+        self.pending = self.gate = None
+        return g, s, gate
+
+
+class GradSlots:
+    """One gradient buffer for the consumers of a channel split (ConvTransBlock: conv1_1's output feeds the conv branch and
+    the transformer branch, CLC_run.py:212-214): each consumer's backward kernel writes its gradient straight into its
+    channel range of the buffer, and the split's backward returns the buffer as it is — no strided gather copies."""
+
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+    def view(self, like, total_c, off, n):
+        if self.buf is None:
+            self.buf = new_act(like.shape[0], total_c, like.shape[2], like.shape[3], like)
+        return self.buf[:, off:off + n]
 
 
 # when set to a list, every conv / wgrad launch is bracketed by HIP events on the launch stream and recorded as
@@ -250,7 +271,7 @@ def to_kernel_weight(w: torch.Tensor) -> torch.Tensor:
 
 def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_NONE, norm=NORM_NONE, mul=None,
              res=None, res_scale=1.0, res_first=False, y_pre=None, shuffle=False, transposed=False, out=None, out_hw=None,
-             xs=None, xs_act=ACT_NONE, xs_pre=False, w2=None, bias2=None, pre_deriv=False):
+             xs=None, xs_act=ACT_NONE, xs_pre=False, w2=None, bias2=None, pre_deriv=False, res_gate=None):
     """One clc_conv2d launch. ``w`` must already be in kernel layout [Cout][ks][ks][Cin]."""
     _require_gpu(x, "conv2d")
     x, xp, N, H, W, Cin, ldx = nhwc(x)
@@ -283,6 +304,10 @@ def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_
         r, rp, *_r, ldr = nhwc(res)
         d.res, d.ldr, d.res_scale, d.res_first = rp, ldr, float(res_scale), int(res_first)
         keep.append(r)
+        if res_gate is not None:   # (saved tensor, activation, saved-is-pre-activation): res term *= act'(saved)
+            gt, gp, *_r, ldg = nhwc(res_gate[0])
+            d.res_gate, d.ldg, d.res_gate_act, d.res_gate_pre = gp, ldg, int(res_gate[1]), int(res_gate[2])
+            keep.append(gt)
     if y_pre is not None:
         q, qp, *_r, ldp = nhwc(y_pre)
         assert q is y_pre
@@ -420,7 +445,8 @@ class _ConvFn(Function):
     the batch is convolved with the second filter set in the same launch (paired layers)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, res, ks, stride, act, res_scale, shuffle, res_first, w2=None, b2=None, fold_in=None, fold_out=None, out_buf=None):
+    def forward(ctx, x, w, b, res, ks, stride, act, res_scale, shuffle, res_first, w2=None, b2=None, fold_in=None, fold_out=None, out_buf=None,
+                grad_slot=None):
         wk = to_kernel_weight(w)
         wk2 = to_kernel_weight(w2) if w2 is not None else None
         need_grad = any(ctx.needs_input_grad)
@@ -445,6 +471,7 @@ class _ConvFn(Function):
         ctx.use_pre = save_pre
         ctx.bias_ref = b
         ctx.pair = (w2, b2)
+        ctx.grad_slot = grad_slot   # (GradSlots, total channels, offset): where the data gradient is to be written
         ctx.folds = (fold_in, fold_out)   # GradFold: fold_in is added in this layer's data-gradient epilogue, fold_out receives d(res)
         ctx.save_for_backward(x, w, saved_act)
         return y
@@ -481,7 +508,12 @@ class _ConvFn(Function):
         # the activation derivative is applied inside the data-/weight-gradient kernels' loaders (no dz tensor, no extra
         # pass) unless the unshuffle copy or a pre-activation residual needs dz materialised
         # (only for the one-instruction derivatives; GELU arrives here as ACT_SAVED_DERIV: its derivative was stored forward)
-        fuse = act in (ACT_LRELU, ACT_RELU, ACT_SAVED_DERIV) and not shuffle and not (need_res and res_first)
+        fold_in, fold_out = ctx.folds
+        # residual added BEFORE the activation (ResidualUnit): d(res) = dy * act'(out).  When the branch's first layer will fold it
+        # into its data-gradient epilogue, park the RAW dy with the gate and skip the activation-backward pass altogether
+        gate_park = (need_res and res_first and not shuffle and act in (ACT_LRELU, ACT_RELU) and fold_out is not None
+                     and fold_out.gated and fold_out.can_park())
+        fuse = act in (ACT_LRELU, ACT_RELU, ACT_SAVED_DERIV) and not shuffle and (not (need_res and res_first) or gate_park)
         one_pass_unshuffle = shuffle and not (need_res and res_first)
         if one_pass_unshuffle:   # PixelShuffle(2) backward and the activation backward in ONE pass over dy
             dz = unshuffle_act_bwd(dy, saved_act if act != ACT_NONE else None, ctx.use_pre, act)
@@ -489,8 +521,9 @@ class _ConvFn(Function):
             dz = dy if (act == ACT_NONE or fuse) else act_bwd(dy, saved_act, ctx.use_pre, act)
         fa = dict(xs=saved_act, xs_act=act, xs_pre=ctx.use_pre) if fuse else {}
         dres = None
-        fold_in, fold_out = ctx.folds
-        if need_res:
+        if need_res and gate_park:
+            fold_out.park(dy, res_scale, gate=(saved_act, act, ctx.use_pre))
+        elif need_res:
             dsrc = dz if res_first else dy  # residual added before / after the activation
             if fold_out is not None and not shuffle and fold_out.park(dsrc, res_scale):
                 dres = None          # the branch's first layer adds res_scale * dsrc in its gradient epilogue
@@ -516,19 +549,22 @@ class _ConvFn(Function):
                 if wt is None:
                     wt = filter_transpose(to_kernel_weight(wp), Cout, ks * ks, Cin)
                 return wt.view(Cin, -1)
-            extra, extra_scale = fold_in.take() if fold_in is not None else (None, 1.0)
+            extra, extra_scale, gate = fold_in.take() if fold_in is not None else (None, 1.0, None)
+            gs = ctx.grad_slot
+            dx_out = gs[0].view(x, gs[1], gs[2], x.shape[1]) if gs is not None else None
             dx = conv_raw(dz, wt_of(w), None, ks=ks, stride=stride, pad=pad, transposed=True, out_hw=(x.shape[2], x.shape[3]),
-                          w2=(wt_of(w2) if w2 is not None else None), res=extra, res_scale=extra_scale, **fa)
+                          w2=(wt_of(w2) if w2 is not None else None), res=extra, res_scale=extra_scale, res_gate=gate, out=dx_out, **fa)
         elif fold_in is not None:
             fold_in.consumed = True
-        return dx, dw, db, dres, None, None, None, None, None, None, dw2, db2, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, dw2, db2, None, None, None, None
 
 
 def conv2d(x, w, b=None, *, stride=1, act=ACT_NONE, res=None, res_scale=1.0, shuffle=False, res_first=False, w2=None, b2=None,
-           fold_in=None, fold_out=None, out=None):
+           fold_in=None, fold_out=None, out=None, grad_slot=None):
     """out: optional destination (a pixel-major view, e.g. a channel slice of a wider buffer) written in place."""
     ks = w.shape[2] if w.dim() == 4 else 1
-    return _ConvFn.apply(x, w, b, res, ks, stride, act, float(res_scale), bool(shuffle), bool(res_first), w2, b2, fold_in, fold_out, out)
+    return _ConvFn.apply(x, w, b, res, ks, stride, act, float(res_scale), bool(shuffle), bool(res_first), w2, b2, fold_in, fold_out, out,
+                         grad_slot)
 
 
 def linear(x, w, b=None, *, act=ACT_NONE, res=None, w2=None, b2=None, fold_in=None, fold_out=None, out=None):
@@ -590,8 +626,9 @@ class _SplitFn(Function):
     tensor per slice and then add them all up (2n+1 full passes instead of n partial ones)."""
 
     @staticmethod
-    def forward(ctx, x, *sizes):
+    def forward(ctx, x, slots, *sizes):
         ctx.sizes = sizes
+        ctx.slots = slots
         ctx.shape = x.shape
         outs, o = [], 0
         for sz in sizes:
@@ -603,6 +640,14 @@ class _SplitFn(Function):
     def backward(ctx, *grads):
         N, Cc, H, W = ctx.shape
         ref = next(g for g in grads if g is not None)
+        buf = ctx.slots.buf if ctx.slots is not None else None
+        if buf is not None and tuple(buf.shape) == tuple(ctx.shape):   # every consumer wrote its range of the shared buffer
+            o, ok = 0, True
+            for sz, g in zip(ctx.sizes, grads):
+                ok = ok and g is not None and g.data_ptr() == buf.data_ptr() + 4 * o and g.stride() == buf.stride() and g.shape[1] == sz
+                o += sz
+            if ok:
+                return (buf, None) + (None,) * len(ctx.sizes)
         dx = torch.empty((N, Cc, H, W), device=ref.device, dtype=torch.float32, memory_format=CL)
         rows, o = N * H * W, 0
         for sz, g in zip(ctx.sizes, grads):
@@ -613,13 +658,14 @@ class _SplitFn(Function):
                 g, gp, *_r, ldg = nhwc(g)
                 _lib.check(_L().clc_copy2d(gp, ldg, dst, Cc, rows, sz, _stream()), "clc_copy2d")
             o += sz
-        return (dx,) + (None,) * len(ctx.sizes)
+        return (dx, None) + (None,) * len(ctx.sizes)
 
 
-def split_channels(x, sizes):
-    """Channel split as zero-copy views (kernels read them through their leading dimension)."""
+def split_channels(x, sizes, slots=None):
+    """Channel split as zero-copy views (kernels read them through their leading dimension).  slots: a GradSlots the
+    consumers write their gradients into (see there)."""
     x, *_ = nhwc(x)
-    return _SplitFn.apply(x, *[int(s) for s in sizes])
+    return _SplitFn.apply(x, slots, *[int(s) for s in sizes])
 
 
 # ------------------------------------------------------------------------------------------- GDN
@@ -724,7 +770,8 @@ def gdn_param(x, gamma, beta, gamma_bound, beta_bound, pedestal, inverse=False, 
 
 class _LayerNormFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, fold_in=None):
+    def forward(ctx, x, gamma, beta, fold_in=None, grad_slot=None):
+        ctx.grad_slot = grad_slot
         x, xp, N, H, W, Cc, ldx = nhwc(x)
         rows = N * H * W
         y = new_act(N, Cc, H, W, x)
@@ -744,29 +791,32 @@ class _LayerNormFn(Function):
         x, xp, N, H, W, Cc, ldx = nhwc(x)
         dy, dyp, *_r, lddy = nhwc(dy)
         rows = N * H * W
-        dx = new_act(N, Cc, H, W, x)
+        gs = ctx.grad_slot
+        dx = gs[0].view(x, gs[1], gs[2], Cc) if gs is not None else new_act(N, Cc, H, W, x)
+        lddx = nhwc(dx)[6]
         gg, gb = _direct_grad(gamma), _direct_grad(ctx.beta_ref)
         direct = gg is not None and gb is not None
         dg, db = (gg, gb) if direct else (torch.empty_like(gamma), torch.empty_like(gamma))
         nbytes = _L().clc_layernorm_bwd_workspace_bytes(rows, Cc)
         ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
-        extra, extra_scale = ctx.fold_in.take() if ctx.fold_in is not None else (None, 1.0)
+        extra, extra_scale, gate = ctx.fold_in.take() if ctx.fold_in is not None else (None, 1.0, None)
+        assert gate is None, "gated residual gradients are folded by conv data-gradient kernels only"
         ep, lde = None, 0
         if extra is not None:
             if extra_scale != 1.0:
                 extra = extra * extra_scale
             extra, ep, *_q, lde = nhwc(extra)
         defer = direct and DEFER_REDUCTIONS
-        _lib.check(_L().clc_layernorm_bwd(dyp, lddy, xp, ldx, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), Cc, ep, lde,
+        _lib.check(_L().clc_layernorm_bwd(dyp, lddy, xp, ldx, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), lddx, ep, lde,
                                           None if defer else dg.data_ptr(), None if defer else db.data_ptr(), int(direct), rows, Cc,
                                           ws.data_ptr(), nbytes, _stream()), "clc_layernorm_bwd")
         if defer:
             defer_reduce(ws, nbytes // (8 * Cc), 2 * Cc, dg, db, Cc)
-        return (dx, None, None, None) if direct else (dx, dg, db, None)
+        return (dx, None, None, None, None) if direct else (dx, dg, db, None, None)
 
 
-def layernorm(x, gamma, beta, fold_in=None):
-    return _LayerNormFn.apply(x, gamma, beta, fold_in)
+def layernorm(x, gamma, beta, fold_in=None, grad_slot=None):
+    return _LayerNormFn.apply(x, gamma, beta, fold_in, grad_slot)
 
 
 # ------------------------------------------------------------------------------ window attention

@@ -84,6 +84,10 @@ typedef struct {
   /* pre_deriv = 1: y_pre receives act'(v) instead of v, so the backward of an expensive activation (GELU: erf + exp) is
    * one multiply in the gradient kernels' loaders (xs_act / dys_act = CLC_ACT_SAVED_DERIV) — no elementwise pass */
   int pre_deriv;
+  /* optional gate on the residual term: v += res_scale * res * act'(res_gate) (res_gate_pre as xs_pre).  Lets a data-gradient
+   * kernel add the gradient of a residual branch that passed through an activation (ResidualUnit: relu(conv(..) + x)) without a
+   * separate activation-backward pass */
+  const float* res_gate; int ldg; int res_gate_act; int res_gate_pre;
 } clc_conv_desc;
 
 int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream);
