@@ -34,11 +34,16 @@ __device__ __forceinline__ float group_sum(float v) {
 template <int G>   // G lanes per row, C = 4*G
 __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ y, int ldy,
-                                                              float* __restrict__ mean, float* __restrict__ rstd, long rows) {
+                                                              float* __restrict__ mean, float* __restrict__ rstd, long rows,
+                                                              const float* __restrict__ gamma2, const float* __restrict__ beta2, long half_rows) {
+  // gamma2 / beta2 (paired modules): rows >= half_rows are normalised with the second module's affine parameters
   constexpr int C = 4 * G, RPB = 256 / G;   // rows per block pass
   const int sub = threadIdx.x % G, rl = threadIdx.x / G;
-  const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + sub * 4), bt = *reinterpret_cast<const f32x4*>(beta + sub * 4);
+  const f32x4 gm1 = *reinterpret_cast<const f32x4*>(gamma + sub * 4), bt1 = *reinterpret_cast<const f32x4*>(beta + sub * 4);
+  const f32x4 gm2 = gamma2 ? *reinterpret_cast<const f32x4*>(gamma2 + sub * 4) : gm1, bt2 = gamma2 ? *reinterpret_cast<const f32x4*>(beta2 + sub * 4) : bt1;
   for (long r = (long)blockIdx.x * RPB + rl; r < rows; r += (long)gridDim.x * RPB) {
+    const bool sec = gamma2 != nullptr && r >= half_rows;
+    const f32x4 gm = sec ? gm2 : gm1, bt = sec ? bt2 : bt1;
     const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + sub * 4);
     const float mu = group_sum<G>((v[0] + v[1]) + (v[2] + v[3])) / (float)C;
     const f32x4 d = v - mu;
@@ -52,13 +57,19 @@ template <int G>
 __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, float* __restrict__ dx, int lddx,
-                                                              const float* __restrict__ dadd, int ldadd, float* __restrict__ ws, long rows) {
+                                                              const float* __restrict__ dadd, int ldadd, float* __restrict__ ws, long rows,
+                                                              const float* __restrict__ gamma2, long half_rows) {
+  // gamma2 (paired modules): the first half of the grid works on rows [0, half_rows) with gamma, the second half on
+  // [half_rows, rows) with gamma2, so every block's partial dgamma/dbeta row belongs to exactly one module
   constexpr int C = 4 * G, RPB = 256 / G;
   __shared__ f32x4 sm[2][RPB][G];
   const int sub = threadIdx.x % G, rl = threadIdx.x / G;
-  const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + sub * 4);
+  const int nbh = gamma2 ? (int)gridDim.x / 2 : (int)gridDim.x;
+  const int side = (gamma2 && (int)blockIdx.x >= nbh) ? 1 : 0;
+  const long r_begin = side ? half_rows : 0, r_end = gamma2 ? (side ? rows : half_rows) : rows;
+  const f32x4 gm = *reinterpret_cast<const f32x4*>((side ? gamma2 : gamma) + sub * 4);
   f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
-  for (long r = (long)blockIdx.x * RPB + rl; r < rows; r += (long)gridDim.x * RPB) {
+  for (long r = r_begin + (long)((int)blockIdx.x - side * nbh) * RPB + rl; r < r_end; r += (long)nbh * RPB) {
     const f32x4 d = *reinterpret_cast<const f32x4*>(dy + r * lddy + sub * 4);
     const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * ldx + sub * 4);
     const float mu = mean[r], rs = rstd[r];
@@ -419,44 +430,82 @@ extern "C" int clc_scaled_diff(const float* a, const float* b, long n, const flo
   return 0;
 }
 
-extern "C" int clc_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, float* mean,
-                                 float* rstd, long rows, int C, clc_stream_t stream) {
+static int ln_fwd_impl(const float* x, int ldx, const float* gamma, const float* beta, const float* gamma2, const float* beta2, long half_rows,
+                       float* y, int ldy, float* mean, float* rstd, long rows, int C, clc_stream_t stream) {
   CLC_CHECK(x && gamma && beta && y && rows > 0 && C > 0, "clc_layernorm_fwd: bad args");
   CLC_CHECK(C <= 64 * LN_MAX_PER_LANE, "clc_layernorm_fwd: C=%d too large", C);
   CLC_CHECK((mean == nullptr) == (rstd == nullptr), "clc_layernorm_fwd: mean/rstd must both be given or both NULL");
-  const bool vec = (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta);
-  if (vec && C == 64) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<16>, dim3(grid_for(rows, 16)), dim3(256), 0, ST, x, ldx, gamma, beta, y, ldy, mean, rstd, rows);
-  else if (vec && C == 128) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<32>, dim3(grid_for(rows, 8)), dim3(256), 0, ST, x, ldx, gamma, beta, y, ldy, mean, rstd, rows);
-  else if (vec && C == 256) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<64>, dim3(grid_for(rows, 4)), dim3(256), 0, ST, x, ldx, gamma, beta, y, ldy, mean, rstd, rows);
+  const bool vec = (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) &&
+                   (gamma2 == nullptr || (aligned16(gamma2) && aligned16(beta2)));
+  CLC_CHECK(gamma2 == nullptr || (vec && (C == 64 || C == 128 || C == 256)), "clc_layernorm_fwd_pair: needs C in {64,128,256} and 16-B aligned operands");
+  if (vec && C == 64) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<16>, dim3(grid_for(rows, 16)), dim3(256), 0, ST, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, gamma2, beta2, half_rows);
+  else if (vec && C == 128) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<32>, dim3(grid_for(rows, 8)), dim3(256), 0, ST, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, gamma2, beta2, half_rows);
+  else if (vec && C == 256) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<64>, dim3(grid_for(rows, 4)), dim3(256), 0, ST, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, gamma2, beta2, half_rows);
   else hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, ST, x, ldx, gamma, beta, y, ldy, mean, rstd, rows, C);
   CLC_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int clc_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, float* mean,
+                                 float* rstd, long rows, int C, clc_stream_t stream) {
+  return ln_fwd_impl(x, ldx, gamma, beta, nullptr, nullptr, 0, y, ldy, mean, rstd, rows, C, stream);
+}
+extern "C" int clc_layernorm_fwd_pair(const float* x, int ldx, const float* gamma, const float* beta, const float* gamma2, const float* beta2,
+                                      long half_rows, float* y, int ldy, float* mean, float* rstd, long rows, int C, clc_stream_t stream) {
+  CLC_CHECK(gamma2 && beta2 && half_rows > 0 && half_rows < rows, "clc_layernorm_fwd_pair: bad args");
+  return ln_fwd_impl(x, ldx, gamma, beta, gamma2, beta2, half_rows, y, ldy, mean, rstd, rows, C, stream);
 }
 
 // (16 rows per block on the 16x16 maps of the slice loop: 2048 rows -> 128 blocks instead of 16 serial ones)
 static int ln_bwd_blocks(long rows) { long b = (rows + 15) / 16; return (int)(b < 1 ? 1 : (b > 512 ? 512 : b)); }
 
-extern "C" size_t clc_layernorm_bwd_workspace_bytes(long rows, int C) { return (size_t)ln_bwd_blocks(rows) * 2 * C * sizeof(float); }
+extern "C" int clc_layernorm_bwd_blocks(long rows, int paired) {
+  const int nb = ln_bwd_blocks(rows);
+  return paired ? (nb + 1) / 2 * 2 : nb;
+}
+extern "C" size_t clc_layernorm_bwd_workspace_bytes(long rows, int C) { return (size_t)(ln_bwd_blocks(rows) + 1) * 2 * C * sizeof(float); }
 
-extern "C" int clc_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* mean,
-                                 const float* rstd, float* dx, int lddx, const float* dx_add, int ld_add, float* dgamma, float* dbeta,
-                                 int accumulate, long rows, int C, void* ws, size_t ws_bytes, clc_stream_t stream) {
+static int ln_bwd_impl(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* gamma2, long half_rows,
+                       const float* mean, const float* rstd, float* dx, int lddx, const float* dx_add, int ld_add, float* dgamma,
+                       float* dbeta, float* dgamma2, float* dbeta2, int accumulate, long rows, int C, void* ws, size_t ws_bytes,
+                       clc_stream_t stream) {
   CLC_CHECK(dy && x && gamma && mean && rstd && dx && ((dgamma == nullptr) == (dbeta == nullptr)) && rows > 0, "clc_layernorm_bwd: bad args");
   CLC_CHECK(C <= 64 * LN_MAX_PER_LANE, "clc_layernorm_bwd: C=%d too large", C);
   CLC_CHECK(ws && ws_bytes >= clc_layernorm_bwd_workspace_bytes(rows, C), "clc_layernorm_bwd: workspace too small");
-  const int nb = ln_bwd_blocks(rows);
+  int nb = ln_bwd_blocks(rows);
+  if (gamma2) nb = (nb + 1) / 2 * 2;   // an even grid: half of it per module (the workspace has room for one more block)
   const bool vec = (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma) && aligned16(ws) &&
-                   (dx_add == nullptr || (ld_add % 4 == 0 && aligned16(dx_add)));
-  if (vec && C == 64) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<16>, dim3(nb), dim3(256), 0, ST, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ld_add, (float*)ws, rows);
-  else if (vec && C == 128) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<32>, dim3(nb), dim3(256), 0, ST, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ld_add, (float*)ws, rows);
-  else if (vec && C == 256) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<64>, dim3(nb), dim3(256), 0, ST, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ld_add, (float*)ws, rows);
+                   (dx_add == nullptr || (ld_add % 4 == 0 && aligned16(dx_add))) && (gamma2 == nullptr || aligned16(gamma2));
+  CLC_CHECK(gamma2 == nullptr || (vec && (C == 64 || C == 128 || C == 256)), "clc_layernorm_bwd_pair: needs C in {64,128,256} and 16-B aligned operands");
+  if (vec && C == 64) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<16>, dim3(nb), dim3(256), 0, ST, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ld_add, (float*)ws, rows, gamma2, half_rows);
+  else if (vec && C == 128) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<32>, dim3(nb), dim3(256), 0, ST, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ld_add, (float*)ws, rows, gamma2, half_rows);
+  else if (vec && C == 256) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<64>, dim3(nb), dim3(256), 0, ST, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_add, ld_add, (float*)ws, rows, gamma2, half_rows);
   else hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), (size_t)8 * C * sizeof(float), ST, dy, lddy, x, ldx, gamma, mean, rstd, dx,
                      lddx, dx_add, ld_add, (float*)ws, rows, C);
   CLC_LAUNCH_CHECK();
   if (dgamma == nullptr) return 0;   // partial rows [blocks][2][C] stay in ws for clc_partial_reduce_batched
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, ST, (const float*)ws, nb, C, dgamma, dbeta, accumulate);
+  const int nb1 = gamma2 ? nb / 2 : nb;
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, ST, (const float*)ws, nb1, C, dgamma, dbeta, accumulate);
   CLC_LAUNCH_CHECK();
+  if (gamma2) {
+    CLC_CHECK(dgamma2 && dbeta2, "clc_layernorm_bwd_pair: dgamma2 / dbeta2 missing");
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, ST, (const float*)ws + (size_t)nb1 * 2 * C, nb1, C, dgamma2, dbeta2, accumulate);
+    CLC_LAUNCH_CHECK();
+  }
   return 0;
+}
+extern "C" int clc_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* mean,
+                                 const float* rstd, float* dx, int lddx, const float* dx_add, int ld_add, float* dgamma, float* dbeta,
+                                 int accumulate, long rows, int C, void* ws, size_t ws_bytes, clc_stream_t stream) {
+  return ln_bwd_impl(dy, lddy, x, ldx, gamma, nullptr, 0, mean, rstd, dx, lddx, dx_add, ld_add, dgamma, dbeta, nullptr, nullptr, accumulate, rows, C, ws,
+                     ws_bytes, stream);
+}
+extern "C" int clc_layernorm_bwd_pair(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* gamma2, long half_rows,
+                                      const float* mean, const float* rstd, float* dx, int lddx, const float* dx_add, int ld_add,
+                                      float* dgamma, float* dbeta, float* dgamma2, float* dbeta2, int accumulate, long rows, int C, void* ws,
+                                      size_t ws_bytes, clc_stream_t stream) {
+  CLC_CHECK(gamma2 && half_rows > 0 && half_rows < rows, "clc_layernorm_bwd_pair: bad args");
+  return ln_bwd_impl(dy, lddy, x, ldx, gamma, gamma2, half_rows, mean, rstd, dx, lddx, dx_add, ld_add, dgamma, dbeta, dgamma2, dbeta2, accumulate, rows, C,
+                     ws, ws_bytes, stream);
 }
 
 // Deferred parameter-gradient reductions (LayerNorm gamma/beta, relative-position bias): every backward kernel leaves its

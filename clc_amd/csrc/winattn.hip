@@ -25,6 +25,7 @@ struct AttnParams {
   int groups_total;        // total window groups (= ceil(B*nwin/G))
   int windows_total;       // B*nwin; the last group may be partial (its surplus slots recompute window 0 and store nothing)
   int groups_per_block;
+  const float* relbias2; int half_windows;   // paired modules: windows >= half_windows use the second bias table
 };
 
 // pixel index (in the un-rolled image) of token (ty,tx) of window (wy,wx)
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(64) void winattn_fwd_kernel(const AttnParams p) {
   const int lane = threadIdx.x, g = lane / T, t = lane % T, ty = t / WS, tx = t % WS;
   const int head = blockIdx.y;
   const float scale = rsqrtf((float)HD);
-  for (int i = lane; i < NBW * NBW; i += 64) Bias[i] = p.relbias[head * NBW * NBW + i];
+  int cur_side = -1;
   const int nwin = p.nwin_y * p.nwin_x;
   const float* bias_t = Bias + (ty + WS - 1) * NBW + (tx + WS - 1);   // Bias[(ty-ky+WS-1)*NBW + tx-kx+WS-1] = bias_t[-(ky*NBW+kx)]
   const int sgap = WS - WS / 2;
@@ -64,6 +65,13 @@ __global__ __launch_bounds__(64) void winattn_fwd_kernel(const AttnParams p) {
   for (int gi = 0; gi < p.groups_per_block; ++gi) {
     const int grp = blockIdx.x * p.groups_per_block + gi;
     if (grp >= p.groups_total) break;
+    const int side = (p.relbias2 != nullptr && grp * G >= p.half_windows) ? 1 : 0;   // block-uniform
+    if (side != cur_side) {
+      __syncthreads();
+      const float* rb = (side ? p.relbias2 : p.relbias) + head * NBW * NBW;
+      for (int i = lane; i < NBW * NBW; i += 64) Bias[i] = rb[i];
+      cur_side = side;
+    }
     const bool wvalid = grp * G + g < p.windows_total;
     const int widx = wvalid ? grp * G + g : 0;            // global window index (b, wy, wx)
     const int b = widx / nwin, wr = widx - b * nwin, wy = wr / p.nwin_x, wx = wr - wy * p.nwin_x;
@@ -141,7 +149,10 @@ __global__ __launch_bounds__(64) void winattn_bwd_kernel(const AttnParams p) {
   const int lane = threadIdx.x, g = lane / T, t = lane % T, ty = t / WS, tx = t % WS;
   const int head = blockIdx.y;
   const float scale = rsqrtf((float)HD);
-  for (int i = lane; i < NB; i += 64) Bias[i] = p.relbias[head * NB + i];
+  {   // (paired modules: the launcher makes sure a workgroup's windows all belong to one module)
+    const float* rb = ((p.relbias2 != nullptr && (int)blockIdx.x * p.groups_per_block * G >= p.half_windows) ? p.relbias2 : p.relbias) + head * NB;
+    for (int i = lane; i < NB; i += 64) Bias[i] = rb[i];
+  }
   for (int i = lane; i < G * NB; i += 64) (&BinAcc[0][0])[i] = 0.f;
   const int nwin = p.nwin_y * p.nwin_x;
   const float* bias_q = Bias + (ty + WS - 1) * NBW + (tx + WS - 1);   // lane = query: Bias[q - k] = bias_q[-(ky*NBW+kx)]
@@ -292,7 +303,7 @@ int check_geom(const char* who, int B, int H, int W, int C, int heads, int ws, i
   return 0;
 }
 
-void fill(AttnParams& p, int B, int H, int W, int C, int heads, int ws, int shift, int target_blocks) {
+void fill(AttnParams& p, int B, int H, int W, int C, int heads, int ws, int shift, int target_blocks, bool paired = false) {
   p.B = B; p.H = H; p.W = W; p.C = C; p.heads = heads; p.ws = ws; p.shift = shift;
   p.nwin_y = H / ws; p.nwin_x = W / ws;
   const int T = ws * ws, G = 64 / T;
@@ -300,6 +311,12 @@ void fill(AttnParams& p, int B, int H, int W, int C, int heads, int ws, int shif
   p.groups_total = (p.windows_total + G - 1) / G;
   int per = (p.groups_total * heads + target_blocks - 1) / target_blocks;
   if (per < 1) per = 1;
+  p.half_windows = 0;
+  if (paired) {   // a workgroup's windows must all belong to one module: groups per block divides the groups of a half
+    p.half_windows = p.windows_total / 2;
+    const int half_groups = p.half_windows / G;
+    while (half_groups % per) --per;
+  }
   p.groups_per_block = per;
 }
 
@@ -312,14 +329,35 @@ void fill(AttnParams& p, int B, int H, int W, int C, int heads, int ws, int shif
 
 }  // namespace
 
-extern "C" int clc_winattn_fwd(const float* qkv, int ldq, const float* relbias, float* out, int ldo, float* lse, int B, int H, int W,
-                               int C, int heads, int ws, int shift, clc_stream_t stream) {
+static int bwd_blocks_x(int B, int H, int W, int heads, int ws, bool paired) {
+  AttnParams p{};
+  fill(p, B, H, W, heads /*C unused*/, heads, ws, 0, 2048, paired);
+  return (p.groups_total + p.groups_per_block - 1) / p.groups_per_block;
+}
+
+extern "C" int clc_winattn_bwd_blocks(int B, int H, int W, int heads, int ws, int paired) { return bwd_blocks_x(B, H, W, heads, ws, paired != 0); }
+extern "C" size_t clc_winattn_bwd_workspace_bytes(int B, int H, int W, int heads, int ws) {
+  const int nb = (2 * ws - 1) * (2 * ws - 1);
+  const int bx = bwd_blocks_x(B, H, W, heads, ws, false), bp = (B % 2 == 0) ? bwd_blocks_x(B, H, W, heads, ws, true) : 0;
+  return (size_t)(bx > bp ? bx : bp) * heads * nb * sizeof(float);
+}
+
+static int pair_ok(const char* who, int B, int H, int W, int ws) {
+  const int T = ws * ws, G = 64 / T;
+  CLC_CHECK(B % 2 == 0 && ((B / 2) * (H / ws) * (W / ws)) % G == 0, "%s: the paired form needs an even batch whose half holds whole window groups", who);
+  return 0;
+}
+
+static int winattn_fwd_impl(const float* qkv, int ldq, const float* relbias, const float* relbias2, float* out, int ldo, float* lse, int B, int H,
+                            int W, int C, int heads, int ws, int shift, clc_stream_t stream) {
   CLC_CHECK(qkv && relbias && out, "clc_winattn_fwd: null pointer");
   if (check_geom("clc_winattn_fwd", B, H, W, C, heads, ws, ldo, ldq)) return -1;
   CLC_CHECK(aligned16(qkv) && aligned16(out), "clc_winattn_fwd: unaligned");
+  if (relbias2 && pair_ok("clc_winattn_fwd_pair", B, H, W, ws)) return -1;
   AttnParams p{};
   p.qkv = qkv; p.relbias = relbias; p.out = out; p.lse = lse; p.ldq = ldq; p.ldo = ldo;
-  fill(p, B, H, W, C, heads, ws, shift, 8192);
+  fill(p, B, H, W, C, heads, ws, shift, 8192, relbias2 != nullptr);
+  p.relbias2 = relbias2;
   dim3 grid((p.groups_total + p.groups_per_block - 1) / p.groups_per_block, heads);
   const int hd = C / heads;
   if (ws == 8) DISPATCH(winattn_fwd_kernel, 64, hd, grid, p, (hipStream_t)stream);
@@ -327,32 +365,32 @@ extern "C" int clc_winattn_fwd(const float* qkv, int ldq, const float* relbias, 
   CLC_LAUNCH_CHECK();
   return 0;
 }
-
-static int bwd_blocks_x(int B, int H, int W, int heads, int ws) {
-  AttnParams p{};
-  fill(p, B, H, W, heads /*C unused*/, heads, ws, 0, 2048);
-  return (p.groups_total + p.groups_per_block - 1) / p.groups_per_block;
+extern "C" int clc_winattn_fwd(const float* qkv, int ldq, const float* relbias, float* out, int ldo, float* lse, int B, int H, int W,
+                               int C, int heads, int ws, int shift, clc_stream_t stream) {
+  return winattn_fwd_impl(qkv, ldq, relbias, nullptr, out, ldo, lse, B, H, W, C, heads, ws, shift, stream);
+}
+extern "C" int clc_winattn_fwd_pair(const float* qkv, int ldq, const float* relbias, const float* relbias2, float* out, int ldo, float* lse,
+                                    int B, int H, int W, int C, int heads, int ws, int shift, clc_stream_t stream) {
+  CLC_CHECK(relbias2, "clc_winattn_fwd_pair: relbias2 missing");
+  return winattn_fwd_impl(qkv, ldq, relbias, relbias2, out, ldo, lse, B, H, W, C, heads, ws, shift, stream);
 }
 
-extern "C" size_t clc_winattn_bwd_workspace_bytes(int B, int H, int W, int heads, int ws) {
-  const int nb = (2 * ws - 1) * (2 * ws - 1);
-  return (size_t)bwd_blocks_x(B, H, W, heads, ws) * heads * nb * sizeof(float);
-}
-
-extern "C" int clc_winattn_bwd(const float* dout, int lddo, const float* qkv, int ldq, const float* relbias, const float* out, int ldo,
-                               const float* lse, float* dqkv, int lddq, float* drelbias, int accumulate, int B, int H, int W, int C,
-                               int heads, int ws, int shift, void* wsb, size_t ws_bytes, clc_stream_t stream) {
+static int winattn_bwd_impl(const float* dout, int lddo, const float* qkv, int ldq, const float* relbias, const float* relbias2, const float* out,
+                            int ldo, const float* lse, float* dqkv, int lddq, float* drelbias, float* drelbias2, int accumulate, int B, int H,
+                            int W, int C, int heads, int ws, int shift, void* wsb, size_t ws_bytes, clc_stream_t stream) {
   CLC_CHECK(dout && qkv && relbias && out && lse && dqkv, "clc_winattn_bwd: null pointer");
   CLC_CHECK(ldo >= C && ldo % 4 == 0 && aligned16(out), "clc_winattn_bwd: bad out");
   if (check_geom("clc_winattn_bwd", B, H, W, C, heads, ws, lddo, ldq)) return -1;
   CLC_CHECK(lddq >= 3 * C && lddq % 4 == 0, "clc_winattn_bwd: bad lddq");
   CLC_CHECK(aligned16(qkv) && aligned16(dout) && aligned16(dqkv), "clc_winattn_bwd: unaligned");
   CLC_CHECK(wsb && ws_bytes >= clc_winattn_bwd_workspace_bytes(B, H, W, heads, ws), "clc_winattn_bwd: workspace too small");
+  if (relbias2 && pair_ok("clc_winattn_bwd_pair", B, H, W, ws)) return -1;
   AttnParams p{};
   p.qkv = qkv; p.relbias = relbias; p.dout = dout; p.dqkv = dqkv; p.dbias_partial = (float*)wsb;
   p.out = const_cast<float*>(out); p.lse = const_cast<float*>(lse);
   p.ldq = ldq; p.lddo = lddo; p.lddq = lddq; p.ldo = ldo;
-  fill(p, B, H, W, C, heads, ws, shift, 2048);
+  fill(p, B, H, W, C, heads, ws, shift, 2048, relbias2 != nullptr);
+  p.relbias2 = relbias2;
   const int nbx = (p.groups_total + p.groups_per_block - 1) / p.groups_per_block;
   dim3 grid(nbx, heads);
   const int hd = C / heads;
@@ -361,7 +399,27 @@ extern "C" int clc_winattn_bwd(const float* dout, int lddo, const float* qkv, in
   CLC_LAUNCH_CHECK();
   if (drelbias == nullptr) return 0;   // partial rows [blocks][n] stay in wsb for clc_partial_reduce_batched
   const int n = heads * (2 * ws - 1) * (2 * ws - 1);
-  hipLaunchKernelGGL(dbias_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, (hipStream_t)stream, (const float*)wsb, nbx, n, drelbias, accumulate);
+  const int nb1 = relbias2 ? nbx / 2 : nbx;
+  hipLaunchKernelGGL(dbias_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, (hipStream_t)stream, (const float*)wsb, nb1, n, drelbias, accumulate);
   CLC_LAUNCH_CHECK();
+  if (relbias2) {
+    CLC_CHECK(drelbias2, "clc_winattn_bwd_pair: drelbias2 missing");
+    hipLaunchKernelGGL(dbias_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, (hipStream_t)stream, (const float*)wsb + (size_t)nb1 * n, nbx - nb1, n, drelbias2, accumulate);
+    CLC_LAUNCH_CHECK();
+  }
   return 0;
+}
+extern "C" int clc_winattn_bwd(const float* dout, int lddo, const float* qkv, int ldq, const float* relbias, const float* out, int ldo,
+                               const float* lse, float* dqkv, int lddq, float* drelbias, int accumulate, int B, int H, int W, int C,
+                               int heads, int ws, int shift, void* wsb, size_t ws_bytes, clc_stream_t stream) {
+  return winattn_bwd_impl(dout, lddo, qkv, ldq, relbias, nullptr, out, ldo, lse, dqkv, lddq, drelbias, nullptr, accumulate, B, H, W, C, heads, ws, shift,
+                          wsb, ws_bytes, stream);
+}
+extern "C" int clc_winattn_bwd_pair(const float* dout, int lddo, const float* qkv, int ldq, const float* relbias, const float* relbias2,
+                                    const float* out, int ldo, const float* lse, float* dqkv, int lddq, float* drelbias, float* drelbias2,
+                                    int accumulate, int B, int H, int W, int C, int heads, int ws, int shift, void* wsb, size_t ws_bytes,
+                                    clc_stream_t stream) {
+  CLC_CHECK(relbias2, "clc_winattn_bwd_pair: relbias2 missing");
+  return winattn_bwd_impl(dout, lddo, qkv, ldq, relbias, relbias2, out, ldo, lse, dqkv, lddq, drelbias, drelbias2, accumulate, B, H, W, C, heads, ws,
+                          shift, wsb, ws_bytes, stream);
 }

@@ -101,8 +101,7 @@ class LayerNorm(nn.LayerNorm):
     def forward(self, x, pair=None, fold_in=None, grad_slot=None):
         if pair is None:
             return ops.layernorm(x, self.weight, self.bias, fold_in, grad_slot)
-        a, b = _halves(x)   # per-module affine parameters: one launch per half
-        return torch.cat((ops.layernorm(a, self.weight, self.bias), ops.layernorm(b, pair.weight, pair.bias)), dim=0)
+        return ops.layernorm(x, self.weight, self.bias, fold_in, grad_slot, pair.weight, pair.bias)   # one launch, per-half parameters
 
 
 class GELU(nn.Module):
@@ -274,10 +273,9 @@ class WMSA(nn.Module):
             a = ops.window_attention(qkv, self.relative_position_params, self.n_heads, self.window_size, self.type != "W")
             return self.linear(a, res=res, fold_out=fold_out)
         qkv = self.embedding_layer(x, pair=pair.embedding_layer)
-        q1, q2 = _halves(qkv)   # per-module relative-position tables: one attention launch per half
-        a = torch.cat((ops.window_attention(q1, self.relative_position_params, self.n_heads, self.window_size, self.type != "W"),
-                       ops.window_attention(q2, pair.relative_position_params, self.n_heads, self.window_size, self.type != "W")), dim=0)
-        return self.linear(a, res=res, pair=pair.linear)
+        a = ops.window_attention(qkv, self.relative_position_params, self.n_heads, self.window_size, self.type != "W",
+                                 relbias2=pair.relative_position_params)   # one launch, per-half relative-position tables
+        return self.linear(a, res=res, pair=pair.linear, fold_out=fold_out)
 
 
 class Block(nn.Module):
@@ -302,9 +300,11 @@ class Block(nn.Module):
             h = self.mlp[0](self.ln2(x, fold_in=f2), act=ACT_GELU)
             return self.mlp[2](h, res=x, fold_out=f2, out=out)
         assert out is None
-        x = self.msa(self.ln1(x, pair=pair.ln1), res=x, pair=pair.msa)
-        h = self.mlp[0](self.ln2(x, pair=pair.ln2), act=ACT_GELU, pair=pair.mlp[0])
-        return self.mlp[2](h, res=x, pair=pair.mlp[2])
+        f1 = ops.GradFold() if x.requires_grad else None
+        x = self.msa(self.ln1(x, pair=pair.ln1, fold_in=f1), res=x, pair=pair.msa, fold_out=f1)
+        f2 = ops.GradFold() if x.requires_grad else None
+        h = self.mlp[0](self.ln2(x, pair=pair.ln2, fold_in=f2), act=ACT_GELU, pair=pair.mlp[0])
+        return self.mlp[2](h, res=x, pair=pair.mlp[2], fold_out=f2)
 
 
 class ConvTransBlock(nn.Module):

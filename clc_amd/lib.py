@@ -74,6 +74,9 @@ SIGNATURES = {
     "clc_colsum": (_i, [fp, _i, _l, _i, fp, _i, fp, _sz, fp]),
     "clc_layernorm_fwd": (_i, [fp, _i, fp, fp, fp, _i, fp, fp, _l, _i, fp]),
     "clc_layernorm_bwd_workspace_bytes": (_sz, [_l, _i]),
+    "clc_layernorm_bwd_blocks": (_i, [_l, _i]),
+    "clc_layernorm_fwd_pair": (_i, [fp, _i, fp, fp, fp, fp, _l, fp, _i, fp, fp, _l, _i, fp]),
+    "clc_layernorm_bwd_pair": (_i, [fp, _i, fp, _i, fp, fp, _l, fp, fp, fp, _i, fp, _i, fp, fp, fp, fp, _i, _l, _i, fp, _sz, fp]),
     "clc_layernorm_bwd": (_i, [fp, _i, fp, _i, fp, fp, fp, fp, _i, fp, _i, fp, fp, _i, _l, _i, fp, _sz, fp]),
     "clc_gdn_bwd_elem": (_i, [fp, fp, fp, fp, fp, _l, _i, fp]),
     "clc_gdn_bwd_combine": (_i, [fp, fp, fp, fp, _l, fp]),
@@ -87,6 +90,9 @@ SIGNATURES = {
     "clc_im2col_small": (_i, [fp, _i, _i, _i, _i, _i, _i, _i, _i, fp, _i, _i, _i, fp]),
     "clc_winattn_fwd": (_i, [fp, _i, fp, fp, _i, fp, _i, _i, _i, _i, _i, _i, _i, fp]),
     "clc_winattn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "clc_winattn_bwd_blocks": (_i, [_i, _i, _i, _i, _i, _i]),
+    "clc_winattn_fwd_pair": (_i, [fp, _i, fp, fp, fp, _i, fp, _i, _i, _i, _i, _i, _i, _i, fp]),
+    "clc_winattn_bwd_pair": (_i, [fp, _i, fp, _i, fp, fp, fp, _i, fp, fp, _i, fp, fp, _i, _i, _i, _i, _i, _i, _i, _i, fp, _sz, fp]),
     "clc_winattn_bwd": (_i, [fp, _i, fp, _i, fp, fp, _i, fp, fp, _i, fp, _i, _i, _i, _i, _i, _i, _i, _i, fp, _sz, fp]),
     "clc_gauss_lik_partials": (_i, [_l, _i]),
     "clc_gauss_lik_fwd": (_i, [fp, _i, fp, _i, fp, _i, fp, _i, fp, _i, fp, _i, _l, _i, _i, fp, _i, fp]),

@@ -85,9 +85,10 @@ def enable_deferred_reductions(enable=True):
     DEFER_REDUCTIONS = bool(enable)
 
 
-def defer_reduce(partial, nblocks, n, out0, out1, split):
+def defer_reduce(partial, nblocks, n, out0, out1, split, offset=0):
+    """offset: first float of this entry's partial rows inside `partial`."""
     e = _lib.ReduceEntry()
-    e.partial, e.nblocks, e.n = partial.data_ptr(), int(nblocks), int(n)
+    e.partial, e.nblocks, e.n = partial.data_ptr() + 4 * int(offset), int(nblocks), int(n)
     e.out0, e.out1, e.split, e.accumulate = out0.data_ptr(), (out1.data_ptr() if out1 is not None else None), int(split), 1
     _PENDING_REDUCE.append((e, (partial, out0, out1)))
 
@@ -769,8 +770,10 @@ def gdn_param(x, gamma, beta, gamma_bound, beta_bound, pedestal, inverse=False, 
 
 
 class _LayerNormFn(Function):
+    """nn.LayerNorm over channels.  (gamma2, beta2): paired modules — the second half of the batch uses them."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, fold_in=None, grad_slot=None):
+    def forward(ctx, x, gamma, beta, fold_in=None, grad_slot=None, gamma2=None, beta2=None):
         ctx.grad_slot = grad_slot
         x, xp, N, H, W, Cc, ldx = nhwc(x)
         rows = N * H * W
@@ -779,24 +782,33 @@ class _LayerNormFn(Function):
         need = any(ctx.needs_input_grad)
         mean = torch.empty(rows, device=x.device, dtype=torch.float32) if need else None
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if need else None
-        _lib.check(_L().clc_layernorm_fwd(xp, ldx, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), Cc,
-                                          mean.data_ptr() if need else None, rstd.data_ptr() if need else None, rows, Cc, _stream()), "clc_layernorm_fwd")
-        ctx.beta_ref = beta
+        mp, rp = (mean.data_ptr(), rstd.data_ptr()) if need else (None, None)
+        if gamma2 is None:
+            _lib.check(_L().clc_layernorm_fwd(xp, ldx, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), Cc, mp, rp, rows, Cc, _stream()), "clc_layernorm_fwd")
+        else:
+            assert N % 2 == 0
+            _lib.check(_L().clc_layernorm_fwd_pair(xp, ldx, gamma.data_ptr(), beta.data_ptr(), gamma2.data_ptr(), beta2.data_ptr(), rows // 2,
+                                                   y.data_ptr(), Cc, mp, rp, rows, Cc, _stream()), "clc_layernorm_fwd_pair")
+        ctx.refs = (beta, gamma2, beta2)
         ctx.save_for_backward(x, gamma, mean, rstd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
+        beta, gamma2, beta2 = ctx.refs
+        paired = gamma2 is not None
         x, xp, N, H, W, Cc, ldx = nhwc(x)
         dy, dyp, *_r, lddy = nhwc(dy)
         rows = N * H * W
         gs = ctx.grad_slot
         dx = gs[0].view(x, gs[1], gs[2], Cc) if gs is not None else new_act(N, Cc, H, W, x)
         lddx = nhwc(dx)[6]
-        gg, gb = _direct_grad(gamma), _direct_grad(ctx.beta_ref)
-        direct = gg is not None and gb is not None
-        dg, db = (gg, gb) if direct else (torch.empty_like(gamma), torch.empty_like(gamma))
+        sets = [(gamma, beta)] + ([(gamma2, beta2)] if paired else [])
+        grads = [(_direct_grad(g), _direct_grad(b)) for g, b in sets]
+        direct = all(g is not None and b is not None for g, b in grads)
+        if not direct:
+            grads = [(torch.empty_like(g), torch.empty_like(g)) for g, _ in sets]
         nbytes = _L().clc_layernorm_bwd_workspace_bytes(rows, Cc)
         ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
         extra, extra_scale, gate = ctx.fold_in.take() if ctx.fold_in is not None else (None, 1.0, None)
@@ -807,63 +819,91 @@ class _LayerNormFn(Function):
                 extra = extra * extra_scale
             extra, ep, *_q, lde = nhwc(extra)
         defer = direct and DEFER_REDUCTIONS
-        _lib.check(_L().clc_layernorm_bwd(dyp, lddy, xp, ldx, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), lddx, ep, lde,
-                                          None if defer else dg.data_ptr(), None if defer else db.data_ptr(), int(direct), rows, Cc,
-                                          ws.data_ptr(), nbytes, _stream()), "clc_layernorm_bwd")
+        gp = [(None, None) if defer else (g.data_ptr(), b.data_ptr()) for g, b in grads]
+        if not paired:
+            _lib.check(_L().clc_layernorm_bwd(dyp, lddy, xp, ldx, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), lddx, ep, lde,
+                                              gp[0][0], gp[0][1], int(direct), rows, Cc, ws.data_ptr(), nbytes, _stream()), "clc_layernorm_bwd")
+        else:
+            _lib.check(_L().clc_layernorm_bwd_pair(dyp, lddy, xp, ldx, gamma.data_ptr(), gamma2.data_ptr(), rows // 2, mean.data_ptr(), rstd.data_ptr(),
+                                                   dx.data_ptr(), lddx, ep, lde, gp[0][0], gp[0][1], gp[1][0], gp[1][1], int(direct), rows, Cc,
+                                                   ws.data_ptr(), nbytes, _stream()), "clc_layernorm_bwd_pair")
         if defer:
-            defer_reduce(ws, nbytes // (8 * Cc), 2 * Cc, dg, db, Cc)
-        return (dx, None, None, None, None) if direct else (dx, dg, db, None, None)
+            nb = _L().clc_layernorm_bwd_blocks(rows, int(paired))
+            per = nb // len(sets)
+            for k, (g, b) in enumerate(grads):   # partial rows [nb][2][C]: module k owns rows [k*per, (k+1)*per)
+                defer_reduce(ws, per, 2 * Cc, g, b, Cc, offset=k * per * 2 * Cc)
+        if direct:
+            return (dx, None, None, None, None, None, None)
+        return (dx, grads[0][0], grads[0][1], None, None) + ((grads[1][0], grads[1][1]) if paired else (None, None))
 
 
-def layernorm(x, gamma, beta, fold_in=None, grad_slot=None):
-    return _LayerNormFn.apply(x, gamma, beta, fold_in, grad_slot)
+def layernorm(x, gamma, beta, fold_in=None, grad_slot=None, gamma2=None, beta2=None):
+    return _LayerNormFn.apply(x, gamma, beta, fold_in, grad_slot, gamma2, beta2)
 
 
 # ------------------------------------------------------------------------------ window attention
 
 
 class _WinAttnFn(Function):
-    """qkv [N,3C,H,W] pixel-major -> attention output [N,C,H,W]; relbias [heads,2ws-1,2ws-1]."""
+    """qkv [N,3C,H,W] pixel-major -> attention output [N,C,H,W]; relbias [heads,2ws-1,2ws-1].
+    relbias2: paired modules — the second half of the batch uses the second module's table."""
 
     @staticmethod
-    def forward(ctx, qkv, relbias, heads, ws, shift):
+    def forward(ctx, qkv, relbias, heads, ws, shift, relbias2=None):
         qkv, qp, N, H, W, C3, ldq = nhwc(qkv)
         Cc = C3 // 3
         out = new_act(N, Cc, H, W, qkv)
         need = any(ctx.needs_input_grad)
         lse = torch.empty(N * H * W * heads, device=qkv.device, dtype=torch.float32) if need else None
-        rb = relbias if relbias.is_contiguous() else relbias.contiguous()
-        ctx.rb_param = relbias if rb is relbias else None
-        _lib.check(_L().clc_winattn_fwd(qp, ldq, rb.data_ptr(), out.data_ptr(), Cc, lse.data_ptr() if need else None,
-                                        N, H, W, Cc, heads, ws, int(shift), _stream()), "clc_winattn_fwd")
-        ctx.cfg = (heads, ws, shift)
-        ctx.save_for_backward(qkv, rb, out, lse)
+        tabs = [relbias] + ([relbias2] if relbias2 is not None else [])
+        rbs = [t if t.is_contiguous() else t.contiguous() for t in tabs]
+        ctx.rb_params = [t if r is t else None for t, r in zip(tabs, rbs)]
+        lp = lse.data_ptr() if need else None
+        if relbias2 is None:
+            _lib.check(_L().clc_winattn_fwd(qp, ldq, rbs[0].data_ptr(), out.data_ptr(), Cc, lp, N, H, W, Cc, heads, ws, int(shift), _stream()), "clc_winattn_fwd")
+        else:
+            _lib.check(_L().clc_winattn_fwd_pair(qp, ldq, rbs[0].data_ptr(), rbs[1].data_ptr(), out.data_ptr(), Cc, lp, N, H, W, Cc, heads, ws, int(shift),
+                                                 _stream()), "clc_winattn_fwd_pair")
+        ctx.cfg = (heads, ws, shift, len(tabs))
+        ctx.save_for_backward(qkv, out, lse, *rbs)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        heads, ws, shift = ctx.cfg
-        qkv, rb, out, lse = ctx.saved_tensors
+        heads, ws, shift, ntab = ctx.cfg
+        qkv, out, lse, *rbs = ctx.saved_tensors
+        paired = ntab == 2
         qkv, qp, N, H, W, C3, ldq = nhwc(qkv)
         Cc = C3 // 3
         dout, dop, *_r, lddo = nhwc(dout)
         dqkv = new_act(N, C3, H, W, qkv)
-        grb = _direct_grad(ctx.rb_param)
-        drb = grb if grb is not None else torch.empty_like(rb)
+        grbs = [_direct_grad(t) for t in ctx.rb_params]
+        direct = all(g is not None for g in grbs)
+        drbs = grbs if direct else [torch.empty_like(r) for r in rbs]
         nbytes = _L().clc_winattn_bwd_workspace_bytes(N, H, W, heads, ws)
         wsb = torch.empty((nbytes + 3) // 4, device=qkv.device, dtype=torch.float32)
-        defer = grb is not None and DEFER_REDUCTIONS
-        _lib.check(_L().clc_winattn_bwd(dop, lddo, qp, ldq, rb.data_ptr(), out.data_ptr(), Cc, lse.data_ptr(), dqkv.data_ptr(), C3,
-                                        None if defer else drb.data_ptr(), int(grb is not None), N, H, W, Cc, heads, ws, int(shift),
-                                        wsb.data_ptr(), nbytes, _stream()), "clc_winattn_bwd")
+        defer = direct and DEFER_REDUCTIONS
+        dp = [None if defer else d.data_ptr() for d in drbs]
+        if not paired:
+            _lib.check(_L().clc_winattn_bwd(dop, lddo, qp, ldq, rbs[0].data_ptr(), out.data_ptr(), Cc, lse.data_ptr(), dqkv.data_ptr(), C3,
+                                            dp[0], int(direct), N, H, W, Cc, heads, ws, int(shift), wsb.data_ptr(), nbytes, _stream()), "clc_winattn_bwd")
+        else:
+            _lib.check(_L().clc_winattn_bwd_pair(dop, lddo, qp, ldq, rbs[0].data_ptr(), rbs[1].data_ptr(), out.data_ptr(), Cc, lse.data_ptr(),
+                                                 dqkv.data_ptr(), C3, dp[0], dp[1], int(direct), N, H, W, Cc, heads, ws, int(shift), wsb.data_ptr(),
+                                                 nbytes, _stream()), "clc_winattn_bwd_pair")
         if defer:
-            nb_ = heads * (2 * ws - 1) * (2 * ws - 1)
-            defer_reduce(wsb, nbytes // (4 * nb_), nb_, drb, None, nb_)
-        return dqkv, (None if grb is not None else drb), None, None, None
+            n_ = heads * (2 * ws - 1) * (2 * ws - 1)
+            nb = _L().clc_winattn_bwd_blocks(N, H, W, heads, ws, int(paired))
+            per = nb // ntab
+            for k, d in enumerate(drbs):
+                defer_reduce(wsb, per, n_, d, None, n_, offset=k * per * n_)
+        if direct:
+            return dqkv, None, None, None, None, None
+        return dqkv, drbs[0], None, None, None, (drbs[1] if paired else None)
 
 
-def window_attention(qkv, relbias, heads, ws, shift):
-    return _WinAttnFn.apply(qkv, relbias, int(heads), int(ws), bool(shift))
+def window_attention(qkv, relbias, heads, ws, shift, relbias2=None):
+    return _WinAttnFn.apply(qkv, relbias, int(heads), int(ws), bool(shift), relbias2)
 
 
 # ------------------------------------------------------------------------------------------ gate

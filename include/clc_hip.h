@@ -147,9 +147,21 @@ int clc_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* 
 /* dx (+ dx_add when non-NULL: the gradient of the residual branch x + f(LN(x)), CLC_run.py:190-191, folded into the same
  * pass); dgamma/dbeta partial sums go through ws (deterministic two-stage) */
 size_t clc_layernorm_bwd_workspace_bytes(long rows, int C);
+/* number of partial rows ([2][C] each) the backward leaves in the workspace (paired: the first half of them belongs to the
+ * first module, the second half to the second) */
+int clc_layernorm_bwd_blocks(long rows, int paired);
 int clc_layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* mean,
                       const float* rstd, float* dx, int lddx, const float* dx_add, int ld_add, float* dgamma, float* dbeta,
                       int accumulate, long rows, int C, void* ws, size_t ws_bytes, clc_stream_t stream);
+
+/* Paired modules (the mean- and scale-parameter nets of a slice run as ONE stacked batch, see clc_conv_desc.w2): rows
+ * [0, half_rows) use gamma / beta, rows [half_rows, rows) use gamma2 / beta2.  C must be 64, 128 or 256. */
+int clc_layernorm_fwd_pair(const float* x, int ldx, const float* gamma, const float* beta, const float* gamma2, const float* beta2,
+                           long half_rows, float* y, int ldy, float* mean, float* rstd, long rows, int C, clc_stream_t stream);
+int clc_layernorm_bwd_pair(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* gamma2, long half_rows,
+                           const float* mean, const float* rstd, float* dx, int lddx, const float* dx_add, int ld_add,
+                           float* dgamma, float* dbeta, float* dgamma2, float* dbeta2, int accumulate, long rows, int C, void* ws,
+                           size_t ws_bytes, clc_stream_t stream);
 
 /* GDN backward pieces (CompressAI GDN inside ResidualBlockWithStride / ResidualBlockUpsample):
  * given dy, x, norm v = beta + gamma.x^2 :  dx_direct = dy * f(v);  dv = dy * x * f'(v)
@@ -200,6 +212,15 @@ size_t clc_winattn_bwd_workspace_bytes(int B, int H, int W, int heads, int ws);
 int clc_winattn_bwd(const float* dout, int lddo, const float* qkv, int ldq, const float* relbias, const float* out,
                     int ldo, const float* lse, float* dqkv, int lddq, float* drelbias, int accumulate, int B, int H, int W,
                     int C, int heads, int ws, int shift, void* wsb, size_t ws_bytes, clc_stream_t stream);
+/* Paired modules: images [B/2, B) use relbias2 (clc_conv_desc.w2 explains the pairing); B even.  The backward's partial
+ * rows: the first half of clc_winattn_bwd_blocks(..., 1) belongs to the first module. */
+int clc_winattn_bwd_blocks(int B, int H, int W, int heads, int ws, int paired);
+int clc_winattn_fwd_pair(const float* qkv, int ldq, const float* relbias, const float* relbias2, float* out, int ldo, float* lse,
+                         int B, int H, int W, int C, int heads, int ws, int shift, clc_stream_t stream);
+int clc_winattn_bwd_pair(const float* dout, int lddo, const float* qkv, int ldq, const float* relbias, const float* relbias2,
+                         const float* out, int ldo, const float* lse, float* dqkv, int lddq, float* drelbias, float* drelbias2,
+                         int accumulate, int B, int H, int W, int C, int heads, int ws, int shift, void* wsb, size_t ws_bytes,
+                         clc_stream_t stream);
 
 /* ---- entropy-model kernels ------------------------------------------------------------ *
  * GaussianConditional likelihood + rate (CLC_run.py:569-571, train_CLC.py:48-51)

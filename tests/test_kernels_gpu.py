@@ -497,3 +497,42 @@ def test_rgb_head_block_patch_rows(dev, cout):
     # the no-grad path (compress / decompress) gives the same bits
     with torch.no_grad():
         assert torch.equal(blk(_dev(x, dev)), y.detach())
+
+
+def test_layernorm_and_attention_paired_modules(dev):
+    """Paired form (second half of the batch on a second module's parameters, one launch): LayerNorm and window attention,
+    forward and every gradient, against the two single-module launches — bit for bit forward, 1e-6 on parameter gradients
+    (different partial-sum grouping)."""
+    from clc_amd import ops
+
+    C, heads, ws = 128, 8, 8
+    x = _dev(_rand((4, C, 16, 16), 1), dev, grad=True)
+    g1, b1, g2, b2 = (_dev(_rand((C,), s) * 0.3 + (1.0 if s % 2 else 0.0), dev, grad=True) for s in (2, 3, 4, 5))
+    gy = _dev(_rand((4, C, 16, 16), 6), dev)
+    y = ops.layernorm(x, g1, b1, None, None, g2, b2)
+    y.backward(gy)
+    got = [t.grad.clone() for t in (x, g1, b1, g2, b2)]
+    for t in (x, g1, b1, g2, b2):
+        t.grad = None
+    ya, yb = ops.layernorm(x[:2], g1, b1), ops.layernorm(x[2:], g2, b2)
+    assert torch.equal(y, torch.cat((ya, yb), 0))
+    torch.cat((ya, yb), 0).backward(gy)
+    for a, t, n in zip(got, (x, g1, b1, g2, b2), ("dx", "dgamma", "dbeta", "dgamma2", "dbeta2")):
+        _close(a, t.grad, 1e-6, f"paired LN {n}")
+
+    qkv = _dev(_rand((4, 3 * C, 16, 16), 7, 0.5), dev, grad=True)
+    r1, r2 = (_dev(_rand((heads, 2 * ws - 1, 2 * ws - 1), s, 0.2), dev, grad=True) for s in (8, 9))
+    go = _dev(_rand((4, C, 16, 16), 10), dev)
+    for shift in (False, True):
+        for t in (qkv, r1, r2):
+            t.grad = None
+        o = ops.window_attention(qkv, r1, heads, ws, shift, relbias2=r2)
+        o.backward(go)
+        got = [t.grad.clone() for t in (qkv, r1, r2)]
+        for t in (qkv, r1, r2):
+            t.grad = None
+        oa, ob = ops.window_attention(qkv[:2], r1, heads, ws, shift), ops.window_attention(qkv[2:], r2, heads, ws, shift)
+        assert torch.equal(o, torch.cat((oa, ob), 0))
+        torch.cat((oa, ob), 0).backward(go)
+        for a, t, n in zip(got, (qkv, r1, r2), ("dqkv", "drelbias", "drelbias2")):
+            _close(a, t.grad, 1e-6, f"paired attention {n} shift={shift}")

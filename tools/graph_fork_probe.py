@@ -1,5 +1,6 @@
 """Does a forked branch of a captured hipGraph run concurrently with its sibling?  Two independent chains of K small
-kernels: (a) both on one stream, (b) second chain on a forked stream.  Prints replay times; concurrency => (b) ~ half of (a)."""
+kernels: serial on one stream; fork A = side chain captured first, main chain second; fork B = main chain captured first
+(fork event recorded before it), side chain second.  Prints replay times; real concurrency => about half of serial."""
 import torch, time, sys
 dev = torch.device("cuda:0")
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 40
@@ -9,31 +10,38 @@ side = torch.cuda.Stream()
 
 def chain(t):
     for _ in range(K):
-        t = torch.sin(t) * 1.0001 + 0.1   # a few ~5 us kernels
+        t = torch.sin(t) * 1.0001 + 0.1
     return t
 
-def run(forked):
+def run(mode):
     cur = torch.cuda.current_stream()
-    if forked:
+    if mode == "A":
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             y = chain(b)
         x = chain(a)
         cur.wait_stream(side)
+    elif mode == "B":
+        e = torch.cuda.Event(); e.record(cur)
+        x = chain(a)
+        side.wait_event(e)
+        with torch.cuda.stream(side):
+            y = chain(b)
+        cur.wait_stream(side)
     else:
         y = chain(b); x = chain(a)
     return x + y
 
-for forked in (False, True):
+for mode in ("serial", "A", "B"):
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
-        for _ in range(3): run(forked)
+        for _ in range(3): run(mode)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=s):
-            out = run(forked)
+            out = run(mode)
         g.replay(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(20): g.replay()
         torch.cuda.synchronize()
-        print(f"forked={forked}: {(time.perf_counter()-t0)/20*1e6:.1f} us per replay ({3*2*K} kernels)")
+        print(f"{mode:6s}: {(time.perf_counter()-t0)/20*1e6:.1f} us per replay ({3*2*K} kernels, n={n})")
