@@ -117,7 +117,7 @@ def join_side_streams():
 BRANCH_STREAMS = False
 # Paired layers: the mean- and scale-parameter nets of a slice run as one launch per layer over a stacked batch (CLC_PAIR=0:
 # two launches, optionally on forked streams).
-PAIR_SLICES = int(os.environ.get("CLC_PAIR", "0"))   # measured neutral against the forked-stream default (163 vs 165 img/s)
+PAIR_SLICES = int(os.environ.get("CLC_PAIR", "1"))   # default on: half the launches of the slice loop, no reliance on hipGraph branch concurrency
 BRANCH_SLOTS = set(os.environ.get("CLC_BRANCH", "scale").split(","))   # which forks are taken (debug knob)
 _BRANCH_POOL = {}
 
