@@ -495,10 +495,13 @@ void conv_igemm_dma_kernel(const ConvParams p) {
 // STRAIGHT from global memory into registers in operand layout (lane (i,h) needs 4 consecutive k of its own row i:
 // one buffer_load_dwordx4) — no LDS staging, no barrier and no ds round trip in the loop, all of a wave's K-tiles in
 // flight at once.  Partial tiles are combined through LDS in the fixed order ((w0+w1)+(w2+w3))+((w4+w5)+(w6+w7)).
-template <int BN, bool TR>
-__global__ __launch_bounds__(512, 1)
+// KW = waves per tile = K-split factor: 8, or 4 for layers of at most 4 K-tiles (1x1 convolutions with Cin <= 128: most of
+// the SWAtten / Swin linears) — half of an 8-wave workgroup would idle there and the wide ones (128 -> 512 on 4096 stacked
+// rows = 1024 tiles) would need 4 rounds of 512-thread workgroups instead of one round of 256-thread ones.
+template <int BN, bool TR, int KW>
+__global__ __launch_bounds__(64 * KW, KW == 8 ? 1 : 2)
 void conv_igemm_splitk_kernel(const ConvParams p) {
-  constexpr int BM = 32, TN = BN / 32, KW = 8, PF = (BN == 32) ? CLC_PF32 : 3;   // PF = K-tiles prefetched per wave
+  constexpr int BM = 32, TN = BN / 32, PF = (KW == 4) ? 1 : 3;   // PF = K-tiles prefetched per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];   // combine buffer [KW][TN][16][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
@@ -585,25 +588,27 @@ void conv_igemm_splitk_kernel(const ConvParams p) {
     for (int r = 0; r < 16; ++r) red[((wave * TN + j) * 16 + r) * 64 + lane] = acc[j][r];
   __syncthreads();
   if (p.vec_epi) {   // block-uniform: 4 consecutive channels = 4 consecutive lanes of one (wave, j, r) row of the buffer
-    for (int e = tid; e < BM * BN / 4; e += 512) {
+    for (int e = tid; e < BM * BN / 4; e += 64 * KW) {
       const int rowi = e / (BN / 4), cc = (e - rowi * (BN / 4)) * 4;
       const int j = cc >> 5, r = (rowi & 3) + 4 * (rowi >> 3), ln = (cc & 31) + 32 * ((rowi >> 2) & 1);
       f32x4 q[KW];
 #pragma unroll
       for (int w = 0; w < KW; ++w) q[w] = *reinterpret_cast<const f32x4*>(red + ((w * TN + j) * 16 + r) * 64 + ln);
-      const f32x4 v = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+      f32x4 v = (q[0] + q[1]) + (q[2] + q[3]);
+      if constexpr (KW == 8) v = v + ((q[4] + q[5]) + (q[6] + q[7]));
       const int m = m0 + rowi, co = n0 + cc;
       if (m < p.M && co < p.Cout) epilogue_store4(p, bsel, v, m, co, DH, DW, ph, pw);
     }
     return;
   }
-  for (int e = tid; e < BM * BN; e += 512) {
+  for (int e = tid; e < BM * BN; e += 64 * KW) {
     const int rowi = e / BN, cc = e - rowi * BN;         // rowi = (r&3) + 8*(r>>2) + 4*h ; cc = j*32 + (lane&31)
     const int j = cc >> 5, r = (rowi & 3) + 4 * (rowi >> 3), ln = (cc & 31) + 32 * ((rowi >> 2) & 1);
     float q[KW];
 #pragma unroll
     for (int w = 0; w < KW; ++w) q[w] = red[((w * TN + j) * 16 + r) * 64 + ln];
-    const float v = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+    float v = (q[0] + q[1]) + (q[2] + q[3]);
+    if constexpr (KW == 8) v = v + ((q[4] + q[5]) + (q[6] + q[7]));
     const int m = m0 + rowi, co = n0 + cc;
     if (m < p.M && co < p.Cout) epilogue_store(p, v, bsel ? bsel[co] : 0.f, m, co, DH, DW, ph, pw);
   }
@@ -645,22 +650,26 @@ int launch(const ConvParams& p, int classes, hipStream_t st) {
   return p.transposed ? launch_t<BM, BN, WM, WN, true>(p, classes, st) : launch_t<BM, BN, WM, WN, false>(p, classes, st);
 }
 
-template <int BN, bool TR>
+template <int BN, bool TR, int KW>
 int launch_splitk_t(const ConvParams& p, int classes, hipStream_t st) {
   dim3 grid((p.M + 31) / 32, (p.Cout + BN - 1) / BN, classes);
-  const size_t lds = (size_t)8 * (BN / 32) * 16 * 64 * sizeof(float);
+  const size_t lds = (size_t)KW * (BN / 32) * 16 * 64 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_splitk_kernel<BN, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_splitk_kernel<BN, TR, KW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_splitk_kernel<BN, TR>), grid, dim3(512), lds, st, p);
+  hipLaunchKernelGGL((conv_igemm_splitk_kernel<BN, TR, KW>), grid, dim3(64 * KW), lds, st, p);
   CLC_LAUNCH_CHECK();
   return 32 * 1000 + BN + 500;  // 32x<BN> split-K family
 }
 template <int BN>
 int launch_splitk(const ConvParams& p, int classes, hipStream_t st) {
-  return p.transposed ? launch_splitk_t<BN, true>(p, classes, st) : launch_splitk_t<BN, false>(p, classes, st);
+  // the K-split factor is a function of the layer shape alone (never of the batch), like the family itself
+  static const int kw4 = getenv("CLC_SPLITK_KW4") ? atoi(getenv("CLC_SPLITK_KW4")) : 1;   // 0: always 8 waves (A/B knob)
+  if (kw4 && p.ks * p.ks * p.kc_tiles <= 4)
+    return p.transposed ? launch_splitk_t<BN, true, 4>(p, classes, st) : launch_splitk_t<BN, false, 4>(p, classes, st);
+  return p.transposed ? launch_splitk_t<BN, true, 8>(p, classes, st) : launch_splitk_t<BN, false, 8>(p, classes, st);
 }
 
 // small-Cin (image, Cin<=4, unaligned) direct convolution: one thread per (pixel, 4 output channels)
