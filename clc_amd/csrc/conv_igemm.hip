@@ -626,7 +626,7 @@ int launch_t(const ConvParams& p, int classes, hipStream_t st) {
   }
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, TR>), grid, dim3(64 * WM * WN), lds, st, p);
   CLC_LAUNCH_CHECK();
-  return BM * 1000 + BN;  // kernel-variant id (>= 0): lets callers attribute time per template instantiation
+  return (1 << 20) | (WM << 16) | (WN << 12) | (BM << 3) | (BN >> 5);  // kernel-variant id (> 1): family 1 = conv_igemm_kernel<BM,BN,WM,WN>
 }
 template <int BM, int BN, int WM, int WN, bool TR>
 int launch_dma_t(const ConvParams& p, int classes, hipStream_t st) {
@@ -640,7 +640,7 @@ int launch_dma_t(const ConvParams& p, int classes, hipStream_t st) {
   }
   hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, TR>), grid, dim3(64 * WM * WN), lds, st, p);
   CLC_LAUNCH_CHECK();
-  return BM * 1000 + BN;
+  return (2 << 20) | (WM << 16) | (WN << 12) | (BM << 3) | (BN >> 5);  // family 2 = conv_igemm_dma_kernel<BM,BN,WM,WN>
 }
 template <int BM, int BN, int WM, int WN>
 int launch(const ConvParams& p, int classes, hipStream_t st) {
@@ -661,7 +661,7 @@ int launch_splitk_t(const ConvParams& p, int classes, hipStream_t st) {
   }
   hipLaunchKernelGGL((conv_igemm_splitk_kernel<BN, TR, KW>), grid, dim3(64 * KW), lds, st, p);
   CLC_LAUNCH_CHECK();
-  return 32 * 1000 + BN + 500;  // 32x<BN> split-K family
+  return (3 << 20) | (KW << 16) | (32 << 3) | (BN >> 5);  // family 3 = conv_igemm_splitk_kernel<BN,TR,KW>
 }
 template <int BN>
 int launch_splitk(const ConvParams& p, int classes, hipStream_t st) {
@@ -833,6 +833,14 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   const int img_pix = (d->transposed && d->stride == 2) ? (d->OH / 2) * (d->OW / 2) : d->OH * d->OW;
   const int C = d->Cout;
   if (img_pix <= 256) {
+    // Heavy data gradients of the slice loop (3x3, 128/224 -> 224..768 on the stacked batch): enough 64x64 tiles to fill the
+    // chip without splitting K, and the LDS-tiled kernel shares each operand tile among 4 waves where the split-K family
+    // re-fetches fragments per wave (224 -> 704 @ 4096 rows: 192 -> 130 us).  Data gradients exist in training only, so the
+    // codec path's batch-invariant family rule is untouched.  (The forward layers of the same nets measured slower this way.)
+    static const int heavy_dgrad = getenv("CLC_HEAVY_DGRAD") ? atoi(getenv("CLC_HEAVY_DGRAD")) : 1;   // 0: A/B knob
+    if (heavy_dgrad && d->transposed && d->ks * d->ks * p.kc_tiles >= 36 && C >= 128 &&
+        (long)((p.M + 63) / 64) * ((C + 63) / 64) * classes >= 128)
+      return launch<64, 64, 2, 2>(p, classes, st);
     // 32x32 tiles: these layers are bound by how many CUs get MFMA work (f32 MFMA = 64 cycles each), not by operand
     // re-use, so the smaller tile (2x the workgroups of 32x64) wins on every 16x16 shape measured
     // ... except the slice-parameter nets with multi-MB filters (448..704 -> 224), where halving the number of N tiles

@@ -31,6 +31,9 @@ SHAPES = [  # name, N, Cin, H, W, Cout, ks, stride
     ("c128_64_3x3_16", 8, 128, 16, 16, 64, 3, 1),
     ("c192_512_3x3_4", 8, 192, 4, 4, 512, 3, 1),
     ("c128_1280_3x3_8", 8, 128, 8, 8, 1280, 3, 1),
+    ("n16_c704_224_3x3_16", 16, 704, 16, 16, 224, 3, 1),
+    ("c768_224_3x3_16", 8, 768, 16, 16, 224, 3, 1),
+    ("c512_224_3x3_16", 8, 512, 16, 16, 224, 3, 1),
 ]
 g = torch.Generator().manual_seed(0)
 for name, N, Cin, H, W, Cout, ks, s in SHAPES:
