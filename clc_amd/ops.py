@@ -24,42 +24,45 @@ from .lib import (ACT_GELU, ACT_HALFTANH, ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SAV
 
 CL = torch.channels_last
 
-# Side stream for weight-gradient kernels: in backward the data-gradient chain is the critical path, the filter
-# gradients are only needed by the optimizer, so they run concurrently on WGRAD_STREAM (fork per layer, one join before the
-# optimizer: ops.join_side_streams()).  Tensors the side stream still reads are kept alive in _KEEPALIVE until the join,
-# so the caching allocator cannot hand their memory to main-stream work in the meantime.
+# Filter gradients are only needed by the optimizer, so they are DEFERRED: queued per layer and launched WGRAD_GROUP at a
+# time through clc_conv2d_wgrad_batched (one grid per tile shape + one slab reduce for the whole group) instead of 2-3
+# launch-bound kernels per layer.  Where they run:
+#   * in line on the launching stream (default).  Under hipGraph replay on ROCm 7.2 a graph with parallel branches pays
+#     ~4.4 us of cross-queue marker latency in front of EVERY kernel that follows an event record, and the branches barely
+#     overlap (tools/graph_fork_probe.py; bench: 1 graph queue 216 img/s vs 4 queues 210) — a linear graph is faster;
+#   * on a side stream (CLC_WGRAD_STREAM=1), concurrent with the data-gradient chain: the better choice for eager execution.
+# Tensors a deferred launch still reads are kept alive in _KEEPALIVE until join_side_streams().
+WGRAD_DEFER = False
 WGRAD_STREAM = None
 _KEEPALIVE = []
 
 
 def enable_wgrad_stream(enable=True):
-    global WGRAD_STREAM
-    WGRAD_STREAM = torch.cuda.Stream() if enable else None
+    """Turn on deferred, grouped filter gradients (and the side stream when CLC_WGRAD_STREAM=1)."""
+    global WGRAD_STREAM, WGRAD_DEFER
+    WGRAD_DEFER = bool(enable)
+    WGRAD_STREAM = torch.cuda.Stream() if (enable and os.environ.get("CLC_WGRAD_STREAM", "0") == "1") else None
 
 
-# Deferred filter gradients: the side stream's problems are independent of each other, so they are queued and launched
-# WGRAD_GROUP at a time through clc_conv2d_wgrad_batched (one grid per tile shape + one slab reduce for the whole group)
-# instead of 2-3 launch-bound kernels per layer.
 WGRAD_GROUP = int(os.environ.get("CLC_WGRAD_GROUP", "64"))             # problems per grouped launch (library cap: 64)
-# ... or as soon as this much work is queued.  Default: effectively never — the ~61 filter gradients of the synthesis
-# transform (the first, MFMA-bound part of backward) then stay queued until the 64th problem arrives, i.e. until the
-# latency-bound slice loop's backward has begun, and run in ITS shadow instead of competing with g_s's own data gradients
-# (measured 198 -> 202 img/s against a 100-GFLOP threshold).
+# ... or as soon as this much work is queued.  Default: effectively never (flush by count).
 WGRAD_FLUSH_GFLOP = float(os.environ.get("CLC_WGRAD_FLUSH_GFLOP", "1000"))
 _PENDING = []
 _PENDING_FLOP = [0.0]
+_PENDING_STREAMS = {}   # streams that queued a problem since the last flush (their work must be ordered before the launch)
 
 
 def flush_wgrads():
     if not _PENDING:
         return
     arr = (_lib.WgradDesc * len(_PENDING))(*[d for d, _ in _PENDING])
-    if os.environ.get("CLC_WGRAD_SERIAL", "0") == "1":   # analysis knob: run the groups in line with the data-gradient chain
-        torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
-        stream_ctx = torch.cuda.stream(torch.cuda.current_stream())
-    else:
-        stream_ctx = torch.cuda.stream(WGRAD_STREAM)
-    with stream_ctx:
+    cur = torch.cuda.current_stream()
+    target = WGRAD_STREAM if WGRAD_STREAM is not None else cur
+    for sid, st in _PENDING_STREAMS.items():   # the operands were produced on these streams
+        if sid != target.cuda_stream:
+            target.wait_stream(st)
+    _PENDING_STREAMS.clear()
+    with torch.cuda.stream(target):
         if PROFILE is None:
             _lib.check(_L().clc_conv2d_wgrad_batched(arr, len(_PENDING), _stream()), "clc_conv2d_wgrad_batched")
         else:
@@ -103,8 +106,8 @@ def flush_reductions():
 
 
 def join_side_streams():
+    flush_wgrads()
     if WGRAD_STREAM is not None:
-        flush_wgrads()
         torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
     flush_reductions()
     _KEEPALIVE.clear()
@@ -386,7 +389,8 @@ def wgrad_raw(x, dy, *, ks, stride, pad, Cout, Cin, want_bias, in_op=IN_NONE, dw
     if _collect:
         return d, (x, dy, dys_t, dw, db, ws)
     if defer:
-        WGRAD_STREAM.wait_stream(torch.cuda.current_stream())   # the operands are produced on the current stream
+        cur = torch.cuda.current_stream()   # the operands are produced on this stream: ordered before the launch at flush time
+        _PENDING_STREAMS[cur.cuda_stream] = cur
         _PENDING.append((d, (x, dy, dys_t, dw, db, ws)))
         _PENDING_FLOP[0] += 2.0 * N * OH * OW * ks * ks * Cin * Cout
         if len(_PENDING) >= WGRAD_GROUP or _PENDING_FLOP[0] >= WGRAD_FLUSH_GFLOP * 1e9:
@@ -484,8 +488,8 @@ class _ConvFn(Function):
         gw, gb = _direct_grad(w), (_direct_grad(bias_ref) if has_b else None)
         if gw is not None and (gb is not None or not has_b) and to_kernel_weight(w) is w:
             # write straight into the persistent gradient arena (accumulate) — no temporary, no autograd add kernel
-            if WGRAD_STREAM is not None and (PROFILE is None or WGRAD_GROUP > 1):
-                if WGRAD_GROUP > 1:
+            if WGRAD_DEFER and (PROFILE is None or WGRAD_GROUP > 1):
+                if WGRAD_GROUP > 1 or WGRAD_STREAM is None:
                     wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb, defer=True, **fw)
                 else:
                     cur = torch.cuda.current_stream()
