@@ -29,10 +29,28 @@ void clc_set_error(const char* fmt, ...);
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// GELU (exact-erf form, CLC_run.py's nn.GELU) on the hardware exp2 / rcp: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7
+// absolute, i.e. ~1.5e-7 relative on gelu itself) — OCML's erff + expf cost ~60 VALU instructions per element and made the
+// fc1+GELU epilogues (256 channels at 128x128) epilogue-bound.
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
+  // cdf = Phi(x) = 0.5 (1 + erf(x / sqrt 2)), pdf = phi(x) = exp(-x^2 / 2) / sqrt(2 pi)
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  const float eh = exp2_fast(-0.72134752044448170368f * x * x);            // exp(-x^2/2) = exp(-z^2)
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float erf_abs = 1.0f - poly * eh;                                     // erf(|x|/sqrt2), eh = exp(-z^2)
+  cdf = 0.5f + copysignf(0.5f * erf_abs, x);
+  pdf = 0.39894228040143267794f * eh;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
+  return x * cdf;
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
   return cdf + x * pdf;
 }
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -51,10 +69,7 @@ __device__ __forceinline__ float act_deriv(float s, int act, int use_pre) {
   switch (act) {
     case CLC_ACT_LRELU: return s > 0.f ? 1.f : 0.01f;
     case CLC_ACT_RELU: return s > 0.f ? 1.f : 0.f;
-    case CLC_ACT_GELU: {
-      const float cdf = 0.5f * (1.0f + erff(s * 0.70710678118654752440f));
-      return cdf + s * 0.39894228040143267794f * expf(-0.5f * s * s);
-    }
+    case CLC_ACT_GELU: return gelu_grad_f(s);
     case CLC_ACT_HALFTANH: {
       const float t = use_pre ? tanhf(s) : 2.f * s;
       return 0.5f * (1.f - t * t);

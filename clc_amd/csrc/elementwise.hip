@@ -204,11 +204,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, int lddy, const flo
     switch (act) {
       case CLC_ACT_LRELU: d = s > 0.f ? 1.f : 0.01f; break;
       case CLC_ACT_RELU: d = s > 0.f ? 1.f : 0.f; break;
-      case CLC_ACT_GELU: {
-        const float cdf = 0.5f * (1.0f + erff(s * 0.70710678118654752440f));
-        d = cdf + s * 0.39894228040143267794f * expf(-0.5f * s * s);
-        break;
-      }
+      case CLC_ACT_GELU: d = gelu_grad_f(s); break;
       case CLC_ACT_HALFTANH: {
         const float t = use_pre ? tanhf(s) : 2.f * s;  // output = 0.5*tanh(v)
         d = 0.5f * (1.f - t * t);
