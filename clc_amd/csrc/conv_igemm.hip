@@ -164,7 +164,7 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, float acc, f
   if (p.y_pre) p.y_pre[pix * p.ldp + ch] = p.pre_deriv ? act_deriv(v, p.act, 1) : v;
   if (p.norm != CLC_NORM_NONE) {
     const float mv = p.mul[pix * p.ldm + ch];
-    v = (p.norm == CLC_NORM_GDN) ? mv * rsqrtf(v) : mv * sqrtf(v);
+    v = (p.norm == CLC_NORM_GDN) ? mv * rsqrtf(v) : ((p.norm == CLC_NORM_IGDN) ? mv * sqrtf(v) : 2.f * (mv * v));
   }
   v = apply_act(v, p.act);
   if (p.res && !p.res_first) v += rterm;
@@ -195,7 +195,7 @@ __device__ __forceinline__ void epilogue_store4(const ConvParams& p, const float
   if (p.norm != CLC_NORM_NONE) {
     const f32x4 mv = *reinterpret_cast<const f32x4*>(p.mul + pix * p.ldm + co);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = (p.norm == CLC_NORM_GDN) ? mv[q] * rsqrtf(v[q]) : mv[q] * sqrtf(v[q]);
+    for (int q = 0; q < 4; ++q) v[q] = (p.norm == CLC_NORM_GDN) ? mv[q] * rsqrtf(v[q]) : ((p.norm == CLC_NORM_IGDN) ? mv[q] * sqrtf(v[q]) : 2.f * (mv[q] * v[q]));
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], p.act);

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libclc_hip.so")
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU, ACT_HALFTANH, ACT_SIGMOID, ACT_SAVED_DERIV = 0, 1, 2, 3, 4, 5, 6
 IN_NONE, IN_SQUARE = 0, 1
-NORM_NONE, NORM_GDN, NORM_IGDN = 0, 1, 2
+NORM_NONE, NORM_GDN, NORM_IGDN, NORM_MUL2 = 0, 1, 2, 3
 
 fp = C.c_void_p  # device / host pointers are passed as integers (tensor.data_ptr())
 

@@ -20,7 +20,7 @@ from torch.autograd import Function
 
 from . import lib as _lib
 from .lib import (ACT_GELU, ACT_HALFTANH, ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SAVED_DERIV, IN_NONE, IN_SQUARE, NORM_GDN,
-                  NORM_IGDN, NORM_NONE)
+                  NORM_IGDN, NORM_MUL2, NORM_NONE)
 
 CL = torch.channels_last
 
@@ -50,6 +50,7 @@ WGRAD_FLUSH_GFLOP = float(os.environ.get("CLC_WGRAD_FLUSH_GFLOP", "1000"))
 _PENDING = []
 _PENDING_FLOP = [0.0]
 _PENDING_STREAMS = {}   # streams that queued a problem since the last flush (their work must be ordered before the launch)
+_PENDING_POST = []      # callables run right after the grouped launch, on its stream (consumers of deferred temporaries)
 
 
 def flush_wgrads():
@@ -71,6 +72,9 @@ def flush_wgrads():
             _lib.check(_L().clc_conv2d_wgrad_batched(arr, len(_PENDING), _stream()), "clc_conv2d_wgrad_batched")
             e1.record()
             PROFILE.append(("conv_wgrad_grouped", 0, _PENDING_FLOP[0], e0, e1, f"{len(_PENDING)} problems"))
+        for fn in _PENDING_POST:
+            fn()
+    _PENDING_POST.clear()
     _KEEPALIVE.append([k for _, k in _PENDING])
     _PENDING.clear()
     _PENDING_FLOP[0] = 0.0
@@ -365,7 +369,7 @@ def wgrad_batched(problems):
 
 
 def wgrad_raw(x, dy, *, ks, stride, pad, Cout, Cin, want_bias, in_op=IN_NONE, dw_out=None, db_out=None, dys=None, dys_act=ACT_NONE,
-              dys_pre=False, defer=False, _collect=False):
+              dys_pre=False, defer=False, _collect=False, accumulate=None):
     """Returns (dw [Cout, ks*ks*Cin] flat kernel layout, dbias or None).  With dw_out / db_out (persistent gradient
     buffers in kernel layout) the result is ACCUMULATED into them and (None, None) is returned.  defer=True (direct mode
     on the side stream only) queues the problem for the next grouped launch (flush_wgrads)."""
@@ -378,7 +382,7 @@ def wgrad_raw(x, dy, *, ks, stride, pad, Cout, Cin, want_bias, in_op=IN_NONE, dw
     d.x, d.N, d.H, d.W, d.Cin, d.ldx = xp, N, H, W, Cin, ldx
     d.dy, d.OH, d.OW, d.Cout, d.lddy = dp, OH, OW, Cout, lddy
     d.dw, d.dbias = dw.data_ptr(), (db.data_ptr() if db is not None else None)
-    d.ks, d.stride, d.pad, d.in_op, d.accumulate = ks, stride, pad, in_op, int(direct)
+    d.ks, d.stride, d.pad, d.in_op, d.accumulate = ks, stride, pad, in_op, int(direct if accumulate is None else accumulate)
     dys_t = None
     if dys is not None:   # fused activation backward: dy <- dy * act'(dys)
         dys_t, dysp, *_r, lddys = nhwc(dys)
@@ -750,19 +754,29 @@ class _GDNParamFn(Function):
         _lib.check(_L().clc_gdn_bwd_elem(dy.data_ptr(), xx.data_ptr(), v.data_ptr(), dxd.data_ptr(), dv.data_ptr(), n, int(inverse), _stream()), "clc_gdn_bwd_elem")
         dgamma = dbeta = dx = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            dgf, dbe = wgrad_raw(xx, dv, ks=1, stride=1, pad=0, Cout=Cc, Cin=Cc, want_bias=True, in_op=IN_SQUARE)
             gg, gb = _direct_grad(gamma), _direct_grad(beta)
             direct = gg is not None and gb is not None and gm is gamma
-            if not direct:
-                gg, gb = torch.empty_like(gm), torch.empty_like(beta)
-            _lib.check(_L().clc_gdn_reparam_bwd(gm.data_ptr(), beta.data_ptr(), Cc, gamma_bound, beta_bound, dgf.data_ptr(), dbe.data_ptr(),
-                                                gg.data_ptr(), gb.data_ptr(), int(direct), _stream()), "clc_gdn_reparam_bwd")
-            if not direct:
-                dgamma, dbeta = gg, gb
+            if direct and WGRAD_DEFER:
+                # d(gamma_eff) joins the next grouped filter-gradient launch; the re-parametrisation's backward runs right after it
+                dgf = torch.empty(Cc * Cc, device=x.device, dtype=torch.float32)
+                dbe = torch.empty(Cc, device=x.device, dtype=torch.float32)
+                wgrad_raw(xx, dv, ks=1, stride=1, pad=0, Cout=Cc, Cin=Cc, want_bias=True, in_op=IN_SQUARE, dw_out=dgf, db_out=dbe,
+                          accumulate=False, defer=True)
+                _PENDING_POST.append(lambda: _lib.check(_L().clc_gdn_reparam_bwd(gm.data_ptr(), beta.data_ptr(), Cc, gamma_bound, beta_bound,
+                                                                                  dgf.data_ptr(), dbe.data_ptr(), gg.data_ptr(), gb.data_ptr(), 1,
+                                                                                  _stream()), "clc_gdn_reparam_bwd"))
+                _KEEPALIVE.append((gm, beta, dgf, dbe))
+            else:
+                dgf, dbe = wgrad_raw(xx, dv, ks=1, stride=1, pad=0, Cout=Cc, Cin=Cc, want_bias=True, in_op=IN_SQUARE)
+                if not direct:
+                    gg, gb = torch.empty_like(gm), torch.empty_like(beta)
+                _lib.check(_L().clc_gdn_reparam_bwd(gm.data_ptr(), beta.data_ptr(), Cc, gamma_bound, beta_bound, dgf.data_ptr(), dbe.data_ptr(),
+                                                    gg.data_ptr(), gb.data_ptr(), int(direct), _stream()), "clc_gdn_reparam_bwd")
+                if not direct:
+                    dgamma, dbeta = gg, gb
         if ctx.needs_input_grad[0]:
-            t = conv_raw(dv, g_eff_t, None, ks=1, transposed=True, out_hw=(H, W))
-            dx = new_act(N, Cc, H, W, x)
-            _lib.check(_L().clc_gdn_bwd_combine(dxd.data_ptr(), xx.data_ptr(), t.data_ptr(), dx.data_ptr(), n, _stream()), "clc_gdn_bwd_combine")
+            # dx = dx_direct + 2 x (gamma^T dv): the 2x factor and the add ride in the 1x1 data-gradient conv's epilogue
+            dx = conv_raw(dv, g_eff_t, None, ks=1, transposed=True, out_hw=(H, W), norm=NORM_MUL2, mul=xx, res=dxd)
         return dx, dgamma, dbeta, (dy if has_res and ctx.needs_input_grad[3] else None), None, None, None, None
 
 

@@ -44,7 +44,8 @@ enum { CLC_ACT_NONE = 0, CLC_ACT_LRELU = 1, CLC_ACT_RELU = 2, CLC_ACT_GELU = 3, 
 /* input prologue applied to the gathered activations */
 enum { CLC_IN_NONE = 0, CLC_IN_SQUARE = 1 };
 /* norm modes of the epilogue: out = mul * rsqrt(v) (GDN) or mul * sqrt(v) (inverse GDN) */
-enum { CLC_NORM_NONE = 0, CLC_NORM_GDN = 1, CLC_NORM_IGDN = 2 };
+enum { CLC_NORM_NONE = 0, CLC_NORM_GDN = 1, CLC_NORM_IGDN = 2,
+       CLC_NORM_MUL2 = 3 /* out = 2 * mul * v: the chain-rule factor d(x^2)/dx of GDN's backward, fused into the 1x1 data-gradient conv */ };
 
 /* ---- convolution as implicit GEMM on v_mfma_f32_32x32x2_f32 ------------------------- *
  * Replaces cuDNN conv fwd / bwd-data / bwd-weight behind every nn.Conv2d and nn.Linear
