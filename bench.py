@@ -123,7 +123,6 @@ def roofline_leg(engine, x, refs):
     return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
             "launches_per_step": n, "avg_launch_ms": round(t / n * 1e3, 4), "event_bracket_overhead_ms": round(empty * 1e3, 5),
-            "note": "in-step figure: backward kernels share the chip with the filter-gradient launches of the side stream",
             "all_mfma_kernels": {"tflops": round(total_f / total_t / 1e12, 2), "ms_per_step": round(total_t * 1e3, 2), "gflop_per_step": round(total_f / 1e9, 1)},
             "per_kernel": table}
 
