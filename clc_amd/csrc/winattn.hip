@@ -140,6 +140,146 @@ __global__ __launch_bounds__(64) void winattn_fwd_kernel(const AttnParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// MFMA form of the 8x8-window kernels (T = 64 tokens): the two contractions of a (window, head) run on
+// v_mfma_f32_32x32x2_f32 instead of 64 x HD scalar FMA chains per lane (the VALU kernels above sit at their instruction
+// bound: 11-38 k cycles per window-head).  One wave per (window, head) as before.
+//   MFMA operand / result layout (32x32x2): A lane l -> A[m = l&31][k = l>>5]; B lane l -> B[k = l>>5][n = l&31];
+//   D lane l, register r -> D[m = (r&3) + 8(r>>2) + 4(l>>5)][n = l&31].
+//   Scores are produced TRANSPOSED, S'[j][i] = sum_c K[j][c] Q[i][c] (A = K rows, B = Q rows): lane (li, h) then holds, for
+//   the queries i = li and 32 + li, the keys j = 32 tj + (r&3) + 8(r>>2) + 4h — a query's row is split over the two lanes
+//   li and li + 32 (one cross-lane exchange for max / sum), and the normalised probabilities ARE the A operand of
+//   O = P V (A[m = i][k = j]): step (tj, r) contracts the key pair {j_a, j_a + 4}, j_a = 32 tj + (r&3) + 8(r>>2), whose
+//   B operand is V[j_a + 4h][c] straight from LDS.  No transposes, no score buffer.
+//   The shift mask is compile-time / lane-constant in this layout: y-mask <=> query tile != key tile, x-mask <=>
+//   ((li & 7) < 4) != (h == 0).
+template <int HD>
+__global__ __launch_bounds__(64) void winattn_fwd_mfma_kernel(const AttnParams p) {
+  constexpr int T = 64, WS = 8, LDQ = HD + 4, NBW = 2 * WS - 1, NB = NBW * NBW;
+  __shared__ __attribute__((aligned(16))) float Qs[T][LDQ], Ks[T][LDQ], Vs[T][LDQ];
+  __shared__ float Bias[NB];
+  const int lane = threadIdx.x, li = lane & 31, h = lane >> 5;
+  const int ty = lane >> 3, tx = lane & 7;          // the token whose rows this lane loads / stores
+  const int head = blockIdx.y;
+  const float scale = rsqrtf((float)HD);
+  const int nwin = p.nwin_y * p.nwin_x;
+  int cur_side = -1;
+  // bias index of element (tj, ti, r): (iy - jy + 7) * 15 + (ix - jx + 7), iy = 4 ti + (li >> 3), ix = li & 7,
+  // jy = 4 tj + (r >> 2), jx = (r & 3) + 4 h
+  const float* bias_l = Bias + ((li >> 3) + WS - 1) * NBW + ((li & 7) - 4 * h + WS - 1);
+  const bool xmask_l = ((li & 7) < 4) != (h == 0);
+  for (int gi = 0; gi < p.groups_per_block; ++gi) {
+    const int grp = blockIdx.x * p.groups_per_block + gi;
+    if (grp >= p.groups_total) break;
+    const int side = (p.relbias2 != nullptr && grp >= p.half_windows) ? 1 : 0;   // block-uniform
+    if (side != cur_side) {
+      __syncthreads();
+      const float* rb = (side ? p.relbias2 : p.relbias) + head * NB;
+      for (int i = lane; i < NB; i += 64) Bias[i] = rb[i];
+      cur_side = side;
+    }
+    const int widx = grp;
+    const int b = widx / nwin, wr = widx - b * nwin, wy = wr / p.nwin_x, wx = wr - wy * p.nwin_x;
+    const int pix = token_pixel(p, b, wy, wx, ty, tx);
+    const size_t row = (size_t)pix * p.ldq;
+    const bool edge_y = p.shift && wy == p.nwin_y - 1, edge_x = p.shift && wx == p.nwin_x - 1;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      *reinterpret_cast<f32x4*>(&Qs[lane][c]) = *reinterpret_cast<const f32x4*>(p.qkv + row + head * HD + c) * scale;
+      *reinterpret_cast<f32x4*>(&Ks[lane][c]) = *reinterpret_cast<const f32x4*>(p.qkv + row + p.C + head * HD + c);
+      *reinterpret_cast<f32x4*>(&Vs[lane][c]) = *reinterpret_cast<const f32x4*>(p.qkv + row + 2 * p.C + head * HD + c);
+    }
+    __syncthreads();
+    // ---- S'[j][i]: tiles s[tj][ti] ----
+    f32x16 s[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[a][bq][r] = 0.f;
+#pragma unroll
+    for (int c0 = 0; c0 < HD; c0 += 8) {   // one b128 per operand row feeds 4 MFMAs: step ss contracts c in {c0+ss, c0+4+ss}
+      f32x4 ka[2], qb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        ka[t] = *reinterpret_cast<const f32x4*>(&Ks[32 * t + li][c0 + 4 * h]);
+        qb[t] = *reinterpret_cast<const f32x4*>(&Qs[32 * t + li][c0 + 4 * h]);
+      }
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int ti = 0; ti < 2; ++ti) s[tj][ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[tj][ss], qb[ti][ss], s[tj][ti], 0, 0, 0);
+    }
+    // ---- bias, mask, softmax over the keys of each query (two queries per lane: i = 32 ti + li) ----
+    float lse_out = 0.f;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) {
+        const bool msk = (edge_y && ti != tj) || (edge_x && xmask_l);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = s[tj][ti][r] + bias_l[(4 * ti - 4 * tj - (r >> 2)) * NBW - (r & 3)];
+          s[tj][ti][r] = msk ? -INFINITY : v;
+          mx = fmaxf(mx, s[tj][ti][r]);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float l = 0.f;
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = exp_fast(s[tj][ti][r] - mx);
+          s[tj][ti][r] = e;
+          l += e;
+        }
+      l += __shfl_xor(l, 32, 64);
+      const float inv = 1.f / l;
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[tj][ti][r] *= inv;
+      if (ti == h) lse_out = mx + logf(l);            // lane = li + 32 h stores the statistics of query i = lane
+    }
+    // ---- O[i][c] = sum_j P[i][j] V[j][c] ----
+    f32x16 o[2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[ti][r] = 0.f;
+    const float* vcol = &Vs[4 * h][li & (HD - 1)];     // lanes with li >= HD re-read a valid column; their results are not stored
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float vb = vcol[(32 * tj + (r & 3) + 8 * (r >> 2)) * LDQ];
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) o[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[tj][ti][r], vb, o[ti], 0, 0, 0);
+      }
+    // ---- rows out: stage through LDS (Q's image is dead), then one row per lane ----
+    __syncthreads();
+    if (li < HD) {
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Qs[32 * ti + (r & 3) + 8 * (r >> 2) + 4 * h][li] = o[ti][r];
+    }
+    __syncthreads();
+    {
+      float* op = p.out + (size_t)pix * p.ldo + head * HD;
+#pragma unroll
+      for (int c = 0; c < HD; c += 4) *reinterpret_cast<f32x4*>(op + c) = *reinterpret_cast<const f32x4*>(&Qs[lane][c]);
+      if (p.lse) p.lse[(size_t)pix * p.heads + head] = lse_out;
+    }
+  }
+}
+
 // Backward. Inputs: qkv, the forward output `out` (for D = dO.O), lse = log-sum-exp per (token, head).
 template <int T, int HD>
 __global__ __launch_bounds__(64) void winattn_bwd_kernel(const AttnParams p) {
@@ -281,6 +421,188 @@ __global__ __launch_bounds__(64) void winattn_bwd_kernel(const AttnParams p) {
   }
 }
 
+// MFMA backward for the 8x8 windows (layouts: winattn_fwd_mfma_kernel).  Two passes, as in the VALU kernel:
+//   pass 1, lane = query: S' = K Q^T and dP' = V dO^T (transposed, so the per-query statistics are lane-held) ->
+//           dS' = P' (dP' - D) is the A operand of dQ = dS K; the relative-bias bins take dS' with a plain read-modify-write
+//           per (tile, register) step — inside a half-wave the 32 queries of one key hit 32 distinct bins, the two half-waves
+//           (keys j and j + 4) own separate bin arrays, summed at the end: race-free and in a fixed order;
+//   pass 2, lane = key:   S = Q K^T and dP = dO V^T -> P and dS are the A operands of dV = P^T dO and dK = dS^T Q.
+template <int HD>
+__global__ __launch_bounds__(64) void winattn_bwd_mfma_kernel(const AttnParams p) {
+  constexpr int T = 64, WS = 8, LDQ = HD + 4, NBW = 2 * WS - 1, NB = NBW * NBW;
+  __shared__ __attribute__((aligned(16))) float Qs[T][LDQ], Ks[T][LDQ], Vs[T][LDQ], Ds[T][LDQ], St[T][LDQ];
+  __shared__ float Lse[T], Dd[T], Bias[NB];
+  __shared__ float BinAcc[2][NB];
+  const int lane = threadIdx.x, li = lane & 31, h = lane >> 5;
+  const int ty = lane >> 3, tx = lane & 7;
+  const int head = blockIdx.y;
+  const float scale = rsqrtf((float)HD);
+  const int nwin = p.nwin_y * p.nwin_x;
+  {   // (paired modules: the launcher makes sure a workgroup's windows all belong to one module)
+    const float* rb = ((p.relbias2 != nullptr && (int)blockIdx.x * p.groups_per_block >= p.half_windows) ? p.relbias2 : p.relbias) + head * NB;
+    for (int i = lane; i < NB; i += 64) Bias[i] = rb[i];
+  }
+  for (int i = lane; i < 2 * NB; i += 64) (&BinAcc[0][0])[i] = 0.f;
+  // pass 1 (lane = query i = 32 ti + li; register r of key tile tj = key 32 tj + (r&3) + 8(r>>2) + 4h)
+  const int off_q = ((li >> 3) + WS - 1) * NBW + ((li & 7) - 4 * h + WS - 1);
+  const float* bias_q = Bias + off_q;
+  volatile float* bin_q = &BinAcc[h][off_q];   // volatile: successive steps alias ACROSS lanes -> keep the read-modify-writes in program order
+  // pass 2 (lane = key j = 32 tj + li; register r of query tile ti = query 32 ti + (r&3) + 8(r>>2) + 4h)
+  const float* bias_k = Bias + (WS - 1 - (li >> 3)) * NBW + (WS - 1 - (li & 7) + 4 * h);
+  const bool xmask_l = ((li & 7) < 4) != (h == 0);
+  const int colc = li & (HD - 1);               // lanes with li >= HD re-read a valid column of the B operand; their results are not stored
+  for (int gi = 0; gi < p.groups_per_block; ++gi) {
+    const int grp = blockIdx.x * p.groups_per_block + gi;
+    if (grp >= p.groups_total) break;
+    const int widx = grp;
+    const int b = widx / nwin, wr = widx - b * nwin, wy = wr / p.nwin_x, wx = wr - wy * p.nwin_x;
+    const int pix = token_pixel(p, b, wy, wx, ty, tx);
+    const size_t row = (size_t)pix * p.ldq;
+    const bool edge_y = p.shift && wy == p.nwin_y - 1, edge_x = p.shift && wx == p.nwin_x - 1;
+    float dsum = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const f32x4 qv = *reinterpret_cast<const f32x4*>(p.qkv + row + head * HD + c) * scale;
+      const f32x4 kv = *reinterpret_cast<const f32x4*>(p.qkv + row + p.C + head * HD + c);
+      const f32x4 vv = *reinterpret_cast<const f32x4*>(p.qkv + row + 2 * p.C + head * HD + c);
+      const f32x4 dv = *reinterpret_cast<const f32x4*>(p.dout + (size_t)pix * p.lddo + head * HD + c);
+      const f32x4 ov = *reinterpret_cast<const f32x4*>(p.out + (size_t)pix * p.ldo + head * HD + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dsum = fmaf(dv[e], ov[e], dsum);
+      *reinterpret_cast<f32x4*>(&Qs[lane][c]) = qv; *reinterpret_cast<f32x4*>(&Ks[lane][c]) = kv;
+      *reinterpret_cast<f32x4*>(&Vs[lane][c]) = vv; *reinterpret_cast<f32x4*>(&Ds[lane][c]) = dv;
+    }
+    Lse[lane] = p.lse[(size_t)pix * p.heads + head];
+    Dd[lane] = dsum;
+    __syncthreads();
+
+    // ---------------- pass 1: dQ and the bias bins, one query tile at a time ----------------
+#pragma unroll 1
+    for (int ti = 0; ti < 2; ++ti) {
+      f32x16 sp[2], dp[2];          // [tj]: S'[j][i], dP'[j][i] for the queries i = 32 ti + li
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sp[t][r] = 0.f; dp[t][r] = 0.f; }
+#pragma unroll
+      for (int c0 = 0; c0 < HD; c0 += 8) {
+        const f32x4 qb = *reinterpret_cast<const f32x4*>(&Qs[32 * ti + li][c0 + 4 * h]);
+        const f32x4 db = *reinterpret_cast<const f32x4*>(&Ds[32 * ti + li][c0 + 4 * h]);
+        f32x4 ka[2], va[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          ka[t] = *reinterpret_cast<const f32x4*>(&Ks[32 * t + li][c0 + 4 * h]);
+          va[t] = *reinterpret_cast<const f32x4*>(&Vs[32 * t + li][c0 + 4 * h]);
+        }
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            sp[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[t][ss], qb[ss], sp[t], 0, 0, 0);
+            dp[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[t][ss], db[ss], dp[t], 0, 0, 0);
+          }
+      }
+      const float lse_i = Lse[32 * ti + li], dd_i = Dd[32 * ti + li];
+      f32x16 dq;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) {
+        const bool msk = (edge_y && ti != tj) || (edge_x && xmask_l);
+        const int boff = (4 * ti - 4 * tj) * NBW;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int bo = boff - (r >> 2) * NBW - (r & 3);
+          const float a = sp[tj][r] + bias_q[bo];
+          const float pj = msk ? 0.f : exp_fast(a - lse_i);
+          const float ds = pj * (dp[tj][r] - dd_i);
+          bin_q[bo] = bin_q[bo] + ds;
+          const float kb = Ks[32 * tj + (r & 3) + 8 * (r >> 2) + 4 * h][colc];
+          dq = __builtin_amdgcn_mfma_f32_32x32x2f32(ds, kb, dq, 0, 0, 0);
+        }
+      }
+      if (li < HD) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) St[32 * ti + (r & 3) + 8 * (r >> 2) + 4 * h][li] = dq[r] * scale;
+      }
+    }
+    __syncthreads();
+    {
+      float* dqp = p.dqkv + (size_t)pix * p.lddq + head * HD;
+#pragma unroll
+      for (int c = 0; c < HD; c += 4) *reinterpret_cast<f32x4*>(dqp + c) = *reinterpret_cast<const f32x4*>(&St[lane][c]);
+    }
+
+    // ---------------- pass 2: dK and dV, one key tile at a time ----------------
+    f32x16 dk[2], dvv[2];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {   // (unrolled: dk / dvv must stay in registers)
+      f32x16 s2[2], dp2[2];         // [ti]: S[i][j], dP[i][j] for the keys j = 32 tj + li
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s2[t][r] = 0.f; dp2[t][r] = 0.f; }
+#pragma unroll
+      for (int c0 = 0; c0 < HD; c0 += 8) {
+        const f32x4 kb = *reinterpret_cast<const f32x4*>(&Ks[32 * tj + li][c0 + 4 * h]);
+        const f32x4 vb = *reinterpret_cast<const f32x4*>(&Vs[32 * tj + li][c0 + 4 * h]);
+        f32x4 qa[2], da[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          qa[t] = *reinterpret_cast<const f32x4*>(&Qs[32 * t + li][c0 + 4 * h]);
+          da[t] = *reinterpret_cast<const f32x4*>(&Ds[32 * t + li][c0 + 4 * h]);
+        }
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            s2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[t][ss], kb[ss], s2[t], 0, 0, 0);
+            dp2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[t][ss], vb[ss], dp2[t], 0, 0, 0);
+          }
+      }
+      f32x16 dkt, dvt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dkt[r] = 0.f; dvt[r] = 0.f; }
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) {
+        const bool msk = (edge_y && ti != tj) || (edge_x && xmask_l);
+        const int boff = (4 * ti - 4 * tj) * NBW;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int iq = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * h;    // the query of this register (half-wave uniform)
+          const float a = s2[ti][r] + bias_k[boff + (r >> 2) * NBW + (r & 3)];
+          const float pij = msk ? 0.f : exp_fast(a - Lse[iq]);
+          const float ds = pij * (dp2[ti][r] - Dd[iq]);
+          const float dob = Ds[iq][colc], qb = Qs[iq][colc];
+          dvt = __builtin_amdgcn_mfma_f32_32x32x2f32(pij, dob, dvt, 0, 0, 0);
+          dkt = __builtin_amdgcn_mfma_f32_32x32x2f32(ds, qb, dkt, 0, 0, 0);
+        }
+      }
+      dk[tj] = dkt; dvv[tj] = dvt;
+    }
+    // rows out: dK, then dV, through the staging image
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      __syncthreads();
+      if (li < HD) {
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) St[32 * tj + (r & 3) + 8 * (r >> 2) + 4 * h][li] = which == 0 ? dk[tj][r] : dvv[tj][r];
+      }
+      __syncthreads();
+      float* dst = p.dqkv + (size_t)pix * p.lddq + (which + 1) * p.C + head * HD;
+#pragma unroll
+      for (int c = 0; c < HD; c += 4) *reinterpret_cast<f32x4*>(dst + c) = *reinterpret_cast<const f32x4*>(&St[lane][c]);
+    }
+  }
+  // ---- per-workgroup partial of the relative-bias gradient (the two half-wave bin sets summed in order) ----
+  __syncthreads();
+  for (int bin = lane; bin < NB; bin += 64)
+    p.dbias_partial[((size_t)blockIdx.x * p.heads + head) * NB + bin] = BinAcc[0][bin] + BinAcc[1][bin];
+}
+
 // out[i] (+)= sum_b partial[b][i]; 32 columns x 8 interleaved block groups per workgroup, combined in a fixed tree
 __global__ __launch_bounds__(256) void dbias_reduce_kernel(const float* __restrict__ partial, int nblocks, int n, float* out, int accumulate) {
   __shared__ float sm[8][32];
@@ -365,7 +687,12 @@ static int winattn_fwd_impl(const float* qkv, int ldq, const float* relbias, con
   p.relbias2 = relbias2;
   dim3 grid((p.groups_total + p.groups_per_block - 1) / p.groups_per_block, heads);
   const int hd = C / heads;
-  if (ws == 8) DISPATCH(winattn_fwd_kernel, 64, hd, grid, p, (hipStream_t)stream);
+  static const int use_mfma = getenv("CLC_ATTN_MFMA") ? atoi(getenv("CLC_ATTN_MFMA")) : 1;   // 0: VALU kernels (A/B knob)
+  if (ws == 8 && use_mfma) {
+    if (hd == 8) hipLaunchKernelGGL((winattn_fwd_mfma_kernel<8>), grid, dim3(64), 0, (hipStream_t)stream, p);
+    else if (hd == 16) hipLaunchKernelGGL((winattn_fwd_mfma_kernel<16>), grid, dim3(64), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((winattn_fwd_mfma_kernel<32>), grid, dim3(64), 0, (hipStream_t)stream, p);
+  } else if (ws == 8) DISPATCH(winattn_fwd_kernel, 64, hd, grid, p, (hipStream_t)stream);
   else DISPATCH(winattn_fwd_kernel, 16, hd, grid, p, (hipStream_t)stream);
   CLC_LAUNCH_CHECK();
   return 0;
@@ -399,7 +726,12 @@ static int winattn_bwd_impl(const float* dout, int lddo, const float* qkv, int l
   const int nbx = (p.groups_total + p.groups_per_block - 1) / p.groups_per_block;
   dim3 grid(nbx, heads);
   const int hd = C / heads;
-  if (ws == 8) DISPATCH(winattn_bwd_kernel, 64, hd, grid, p, (hipStream_t)stream);
+  static const int use_mfma = getenv("CLC_ATTN_MFMA") ? atoi(getenv("CLC_ATTN_MFMA")) : 1;   // 0: VALU kernels (A/B knob)
+  if (ws == 8 && use_mfma) {
+    if (hd == 8) hipLaunchKernelGGL((winattn_bwd_mfma_kernel<8>), grid, dim3(64), 0, (hipStream_t)stream, p);
+    else if (hd == 16) hipLaunchKernelGGL((winattn_bwd_mfma_kernel<16>), grid, dim3(64), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((winattn_bwd_mfma_kernel<32>), grid, dim3(64), 0, (hipStream_t)stream, p);
+  } else if (ws == 8) DISPATCH(winattn_bwd_kernel, 64, hd, grid, p, (hipStream_t)stream);
   else DISPATCH(winattn_bwd_kernel, 16, hd, grid, p, (hipStream_t)stream);
   CLC_LAUNCH_CHECK();
   if (drelbias == nullptr) return 0;   // partial rows [blocks][n] stay in wsb for clc_partial_reduce_batched
