@@ -119,9 +119,20 @@ def roofline_leg(engine, x, refs):
     dom = max((single or agg).items(), key=lambda kv: kv[1][1])
     name, (f, t, n) = dom
     achieved = f / t / 1e12
+    # HBM-side bytes per launch of that kernel from the committed PMC passes (separate `rocprofv3 --pmc FETCH_SIZE` /
+    # `--pmc WRITE_SIZE` runs of this same command, gfx950 FETCH_SIZE correction applied: tools/pmc_traffic.py); null when the
+    # file does not list the kernel
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
+            k = json.load(fh)["kernels"].get(name)
+        if k and k["launches_per_step"]:
+            traffic = round((k["fetch_bytes_per_step"] + k["write_bytes_per_step"]) / k["launches_per_step"])
+    except (OSError, KeyError, ValueError):
+        traffic = None
     table = {k: {"launches": v[2], "gflop": round(v[0] / 1e9, 2), "ms": round(v[1] * 1e3, 3), "tflops": round(v[0] / v[1] / 1e12, 2)} for k, v in agg.items()}
     return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
             "launches_per_step": n, "avg_launch_ms": round(t / n * 1e3, 4), "event_bracket_overhead_ms": round(empty * 1e3, 5),
             "all_mfma_kernels": {"tflops": round(total_f / total_t / 1e12, 2), "ms_per_step": round(total_t * 1e3, 2), "gflop_per_step": round(total_f / 1e9, 1)},
             "per_kernel": table}

@@ -645,7 +645,8 @@ int launch_dma_t(const ConvParams& p, int classes, hipStream_t st) {
 template <int BM, int BN, int WM, int WN>
 int launch(const ConvParams& p, int classes, hipStream_t st) {
   static const int use_dma = getenv("CLC_DMA") ? atoi(getenv("CLC_DMA")) : 1;   // CLC_DMA=0: register staging everywhere (A/B knob)
-  if (use_dma && p.in_op == CLC_IN_NONE && p.xs == nullptr && BM >= 128)   // no input prologue -> the tiles can go straight to LDS
+  static const int dma_small = getenv("CLC_DMA_SMALL") ? atoi(getenv("CLC_DMA_SMALL")) : 1;
+  if (use_dma && p.in_op == CLC_IN_NONE && p.xs == nullptr && (BM >= 128 || dma_small))   // no input prologue -> the tiles can go straight to LDS
     return p.transposed ? launch_dma_t<BM, BN, WM, WN, true>(p, classes, st) : launch_dma_t<BM, BN, WM, WN, false>(p, classes, st);
   return p.transposed ? launch_t<BM, BN, WM, WN, true>(p, classes, st) : launch_t<BM, BN, WM, WN, false>(p, classes, st);
 }

@@ -397,7 +397,17 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const SlabGroup sg) {
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (i < n) {
     const bool vec = (i + 3 < n) && ((n & 3) == 0);
-    for (int k = g; k < splits; k += 4) {
+    int k = g;
+    if (vec) {   // 4 slab rows in flight per thread (the loads are independent; the adds keep the ascending order)
+      for (; k + 12 < splits; k += 16) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(partial + (size_t)k * n + i);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(partial + (size_t)(k + 4) * n + i);
+        const f32x4 a2 = *reinterpret_cast<const f32x4*>(partial + (size_t)(k + 8) * n + i);
+        const f32x4 a3 = *reinterpret_cast<const f32x4*>(partial + (size_t)(k + 12) * n + i);
+        s += a0; s += a1; s += a2; s += a3;
+      }
+    }
+    for (; k < splits; k += 4) {
       const float* src = partial + (size_t)k * n + i;
       if (vec) s += *reinterpret_cast<const f32x4*>(src);
       else for (int e = 0; e < 4; ++e) if (i + e < n) s[e] += src[e];

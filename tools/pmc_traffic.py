@@ -4,7 +4,7 @@
     python tools/pmc_traffic.py <dirF>/pmc_counter_collection.csv <dirW>/pmc_counter_collection.csv profiles/r1_pmc_traffic.json
 Counters are in KiB.  gfx950 correction applied as the guide prescribes: FETCH_SIZE counts 128-B requests at 64 B for the
 16-B-per-lane streaming reads all these kernels use -> doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
-The window is the last full training step in the trace (between the last two fused-AdamW launches)."""
+The window is a full hipGraph-replayed training step in the trace (between two grad_sqnorm_kernel launches)."""
 import csv
 import json
 import re
@@ -18,31 +18,18 @@ def step_rows(path):
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], float(r["Counter_Value"])))
     rows.sort()
-    adam = [i for i, r in enumerate(rows) if "adamw_kernel" in r[2]]
-    ends = []
-    for i in adam:
-        if ends and rows[i][0] - rows[ends[-1]][1] < 5_000_000:
-            ends[-1] = i
-        else:
-            ends.append(i)
-    return rows[ends[-2] + 1:ends[-1] + 1]
+    marks = [i for i, r in enumerate(rows) if "grad_sqnorm_kernel" in r[2]]   # one per training step
+    return rows[marks[-3]:marks[-2]]
 
 
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
-    return re.sub(r"\(.*$", "", name)
+    m = re.match(r"([A-Za-z_0-9:]+(?:<[^(]*>)?)\(", name)
+    return m.group(1) if m else name
 
 
-FAMILIES = {  # bench.py roofline key -> kernels that make up one of its launches
-    "conv_wgrad_grouped": r"conv_wgrad_grouped_kernel|conv_wgrad_kernel|slab_reduce_kernel",
-    "conv_igemm<128,128>": r"conv_igemm_kernel<128, 128,",
-    "conv_igemm<128,64>": r"conv_igemm_kernel<128, 64,",
-    "conv_igemm<64,64>": r"conv_igemm_kernel<64, 64,",
-    "conv_igemm<64,32>": r"conv_igemm_kernel<64, 32,",
-    "conv_igemm_splitk<32,32>": r"conv_igemm_splitk_kernel<32,",
-    "conv_igemm_splitk<32,64>": r"conv_igemm_splitk_kernel<64,",
-}
+FAMILIES = {}   # (per-kernel rows only; kernel names are the ones rocprofv3 / bench.py's roofline use)
 
 
 def main():
