@@ -133,8 +133,8 @@ class SubpelConv3x3(nn.Sequential):
         assert r == 2
         super().__init__(Conv2d(i, o * r * r, 3), PixelShuffle2())
 
-    def forward(self, x, act=ACT_NONE, res=None):
-        return self[0](x, act=act, res=res, shuffle=True)
+    def forward(self, x, act=ACT_NONE, res=None, pair=None):
+        return self[0](x, act=act, res=res, shuffle=True, pair=pair[0] if pair is not None else None)
 
 
 def subpel_conv3x3(i, o, r=1):
@@ -160,8 +160,12 @@ class GDN(nn.Module):
             self._clc_consts = c
         return c
 
-    def forward(self, x, res=None):
+    def forward(self, x, res=None, pair=None):
+        """pair: a second GDN of the same shape for the second half of the batch (same launches, per-half parameters)."""
         gb, bb, ped = self._consts()
+        if pair is not None:
+            assert pair._consts() == (gb, bb, ped) and pair.inverse == self.inverse
+            return ops.gdn_param(x, self.gamma, self.beta, gb, bb, ped, inverse=self.inverse, res=res, gamma2=pair.gamma, beta2=pair.beta)
         return ops.gdn_param(x, self.gamma, self.beta, gb, bb, ped, inverse=self.inverse, res=res)
 
 
@@ -200,7 +204,10 @@ class ResidualBlockUpsample(nn.Module):
         self.igdn = GDN(out_ch, inverse=True)
         self.upsample = subpel_conv3x3(in_ch, out_ch, upsample)
 
-    def forward(self, x):
+    def forward(self, x, pair=None):
+        if pair is not None:   # two blocks side by side on a batch-stacked input (the mean / scale hyper-synthesis nets)
+            t = self.conv(self.subpel_conv(x, act=ACT_LRELU, pair=pair.subpel_conv), pair=pair.conv)
+            return self.igdn(t, res=self.upsample(x, pair=pair.upsample), pair=pair.igdn)
         t = self.conv(self.subpel_conv(x, act=ACT_LRELU))
         return self.igdn(t, res=self.upsample(x))
 
@@ -213,12 +220,14 @@ class ResidualBlock(nn.Module):
         self.conv2 = conv3x3(out_ch, out_ch)
         self.skip = conv1x1(in_ch, out_ch) if in_ch != out_ch else None
 
-    def forward(self, x, extra_identity=0.0, out=None, grad_slot=None):
+    def forward(self, x, extra_identity=0.0, out=None, grad_slot=None, pair=None):
         """lrelu(conv2(lrelu(conv1 x))) + identity (+ extra_identity * x, used by ConvTransBlock's `+ conv_x`)."""
         if self.skip is None:
             f = ops.GradFold() if x.requires_grad else None   # d(identity) is added in conv1's data-gradient epilogue
-            t = self.conv1(x, act=ACT_LRELU, fold_in=f, grad_slot=grad_slot)
-            return self.conv2(t, act=ACT_LRELU, res=x, res_scale=1.0 + extra_identity, fold_out=f, out=out)
+            t = self.conv1(x, act=ACT_LRELU, fold_in=f, grad_slot=grad_slot, pair=pair.conv1 if pair is not None else None)
+            return self.conv2(t, act=ACT_LRELU, res=x, res_scale=1.0 + extra_identity, fold_out=f, out=out,
+                              pair=pair.conv2 if pair is not None else None)
+        assert pair is None
         assert out is None
         t = self.conv1(x, act=ACT_LRELU)
         out = self.conv2(t, act=ACT_LRELU, res=self.skip(x))
@@ -292,6 +301,12 @@ class Block(nn.Module):
         self.mlp = nn.Sequential(Linear(input_dim, 4 * input_dim), GELU(), Linear(4 * input_dim, output_dim))
 
     def forward(self, x, pair=None, out=None, grad_slot=None):
+        if pair is not None and (out is not None or grad_slot is not None):   # paired Block inside a paired ConvTransBlock
+            f1 = ops.GradFold() if x.requires_grad else None
+            x = self.msa(self.ln1(x, pair=pair.ln1, fold_in=f1, grad_slot=grad_slot), res=x, pair=pair.msa, fold_out=f1)
+            f2 = ops.GradFold() if x.requires_grad else None
+            h = self.mlp[0](self.ln2(x, pair=pair.ln2, fold_in=f2), act=ACT_GELU, pair=pair.mlp[0])
+            return self.mlp[2](h, res=x, pair=pair.mlp[2], fold_out=f2, out=out)
         if pair is None:
             # x + f(LN(x)) twice: the residual gradients are added inside the LayerNorm backward passes
             f1 = ops.GradFold() if x.requires_grad else None
@@ -316,17 +331,21 @@ class ConvTransBlock(nn.Module):
         self.conv1_2 = Conv2d(conv_dim + trans_dim, conv_dim + trans_dim, 1)
         self.conv_block = ResidualBlock(conv_dim, conv_dim)
 
-    def forward(self, x):
+    def forward(self, x, pair=None):
+        """pair: a second ConvTransBlock of the same shape for the second half of a batch-stacked input."""
+        q = pair
         f = ops.GradFold() if x.requires_grad else None   # d(x) of the outer residual rides in conv1_1's data-gradient epilogue
-        u = self.conv1_1(x, fold_in=f)
+        u = self.conv1_1(x, fold_in=f, pair=q.conv1_1 if q is not None else None)
         slots = ops.GradSlots() if u.requires_grad else None
         cd, td = self.conv_dim, self.trans_dim
         c, t = ops.split_channels(u, (cd, td), slots)   # strided views, read in place by the kernels
         # the two branches write their results straight into the channel halves of conv1_2's input (no concatenation copy)
         buf = ops.new_act(u.shape[0], self.conv_dim + self.trans_dim, u.shape[2], u.shape[3], u)
-        c = self.conv_block(c, extra_identity=1.0, out=buf[:, :cd], grad_slot=(slots, cd + td, 0) if slots is not None else None)
-        t = self.trans_block(t, out=buf[:, cd:], grad_slot=(slots, cd + td, cd) if slots is not None else None)
-        return self.conv1_2(ops.cat_halves(c, t, buf), res=x, fold_out=f)
+        c = self.conv_block(c, extra_identity=1.0, out=buf[:, :cd], grad_slot=(slots, cd + td, 0) if slots is not None else None,
+                            pair=q.conv_block if q is not None else None)
+        t = self.trans_block(t, out=buf[:, cd:], grad_slot=(slots, cd + td, cd) if slots is not None else None,
+                             pair=q.trans_block if q is not None else None)
+        return self.conv1_2(ops.cat_halves(c, t, buf), res=x, fold_out=f, pair=q.conv1_2 if q is not None else None)
 
 
 class SwinBlock(nn.Module):

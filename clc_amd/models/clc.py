@@ -203,6 +203,17 @@ class _SliceCodec(CompressionModel):
             return self.ref_lrp_transforms[i](torch.cat([mean_support, y_hat_slice, ref_features], dim=1), final_act=ACT_HALFTANH, res=y_hat_slice)
         return self.lrp_transforms[i](torch.cat([mean_support, y_hat_slice], dim=1), final_act=ACT_HALFTANH, res=y_hat_slice)
 
+    def _hyper_synthesis(self, z_hat):
+        """(latent_means, latent_scales) = (h_mean_s(z_hat), h_scale_s(z_hat)) (CLC_run.py:532-533): the two nets are the same
+        architecture on the same input — stacked along the batch they run as ONE launch per layer."""
+        rows = z_hat.shape[0] * z_hat.shape[2] * z_hat.shape[3]
+        if ops.PAIR_SLICES and ops.PAIR_HYPER and rows % 128 == 0 and z_hat.shape[0] % 2 == 0:
+            both = torch.cat((z_hat, z_hat), dim=0)
+            for m, q in zip(self.h_mean_s, self.h_scale_s):
+                both = m(both, pair=q)
+            return ops.split_batch(both)
+        return self.h_mean_s(z_hat), self.h_scale_s(z_hat)
+
     @staticmethod
     def _prep(x):
         if not x.is_cuda:
@@ -216,8 +227,7 @@ class _SliceCodec(CompressionModel):
         y_shape = y.shape[2:]
         z = self.h_a(y)
         z_likelihoods, z_hat = self.entropy_bottleneck.likelihood_and_ste(z)
-        latent_scales = self.h_scale_s(z_hat)
-        latent_means = self.h_mean_s(z_hat)
+        latent_means, latent_scales = self._hyper_synthesis(z_hat)
         y_hat_slices, y_lik, mus, scales = [], [], [], []
         ref_pair = torch.cat((ref_features, ref_features), dim=0) if (ref_features is not None and ops.PAIR_SLICES) else None
         for i, y_slice in enumerate(ops.split_channels(y, [y.shape[1] // self.num_slices] * self.num_slices)):

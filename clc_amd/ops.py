@@ -125,6 +125,7 @@ BRANCH_STREAMS = False
 # Paired layers: the mean- and scale-parameter nets of a slice run as one launch per layer over a stacked batch (CLC_PAIR=0:
 # two launches, optionally on forked streams).
 PAIR_SLICES = int(os.environ.get("CLC_PAIR", "1"))   # default on: half the launches of the slice loop, no reliance on hipGraph branch concurrency
+PAIR_HYPER = int(os.environ.get("CLC_PAIR_HYPER", "1"))   # also pair the mean / scale hyper-synthesis nets (h_mean_s, h_scale_s)
 BRANCH_SLOTS = set(os.environ.get("CLC_BRANCH", "scale").split(","))   # which forks are taken (debug knob)
 _BRANCH_POOL = {}
 
@@ -723,65 +724,80 @@ def gdn(x, gamma_eff, beta_eff, inverse=False, res=None):
 class _GDNParamFn(Function):
     """GDN on the RAW parameters: the NonNegativeParametrizer of gamma and beta is one launch forward (which also emits
     gamma_eff transposed for the data-gradient conv) and one launch backward, writing straight into the gradient arena —
-    instead of ~20 parameter-sized torch launches per GDN module and step."""
+    instead of ~20 parameter-sized torch launches per GDN module and step.
+    (gamma2, beta2): paired modules — the second half of the batch is normalised with the second module's parameters."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, res, inverse, gamma_bound, beta_bound, pedestal):
+    def forward(ctx, x, gamma, beta, res, inverse, gamma_bound, beta_bound, pedestal, gamma2=None, beta2=None):
         N, Cc, H, W = x.shape
         need_grad = any(ctx.needs_input_grad)
-        g_eff = torch.empty((Cc, Cc), device=x.device, dtype=torch.float32)
-        g_eff_t = torch.empty((Cc, Cc), device=x.device, dtype=torch.float32)
-        b_eff = torch.empty((Cc,), device=x.device, dtype=torch.float32)
-        gm = gamma if gamma.is_contiguous() else gamma.contiguous()
-        _lib.check(_L().clc_gdn_reparam_fwd(gm.data_ptr(), beta.data_ptr(), Cc, gamma_bound, beta_bound, pedestal, g_eff.data_ptr(),
-                                            g_eff_t.data_ptr(), b_eff.data_ptr(), _stream()), "clc_gdn_reparam_fwd")
+        sets = [(gamma, beta)] + ([(gamma2, beta2)] if gamma2 is not None else [])
+        eff = []
+        for g, b in sets:
+            g_eff = torch.empty((Cc, Cc), device=x.device, dtype=torch.float32)
+            g_eff_t = torch.empty((Cc, Cc), device=x.device, dtype=torch.float32)
+            b_eff = torch.empty((Cc,), device=x.device, dtype=torch.float32)
+            gm = g if g.is_contiguous() else g.contiguous()
+            _lib.check(_L().clc_gdn_reparam_fwd(gm.data_ptr(), b.data_ptr(), Cc, gamma_bound, beta_bound, pedestal, g_eff.data_ptr(),
+                                                g_eff_t.data_ptr(), b_eff.data_ptr(), _stream()), "clc_gdn_reparam_fwd")
+            eff.append((gm, g_eff, g_eff_t, b_eff))
         v = new_act(N, Cc, H, W, x) if need_grad else None
-        y = conv_raw(x, g_eff, b_eff, ks=1, in_op=IN_SQUARE, norm=NORM_IGDN if inverse else NORM_GDN, mul=x, y_pre=v, res=res)
-        ctx.cfg = (inverse, res is not None, gamma_bound, beta_bound)
-        ctx.params = (gamma, beta)
-        ctx.save_for_backward(x, gm, g_eff_t, v)
+        w2 = eff[1][1] if len(eff) == 2 else None
+        y = conv_raw(x, eff[0][1], eff[0][3], ks=1, in_op=IN_SQUARE, norm=NORM_IGDN if inverse else NORM_GDN, mul=x, y_pre=v, res=res,
+                     w2=w2, bias2=(eff[1][3] if len(eff) == 2 else None))
+        ctx.cfg = (inverse, res is not None, gamma_bound, beta_bound, len(sets))
+        ctx.params = sets
+        ctx.save_for_backward(x, v, *[t for e in eff for t in (e[0], e[2])])
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gm, g_eff_t, v = ctx.saved_tensors
-        inverse, has_res, gamma_bound, beta_bound = ctx.cfg
-        gamma, beta = ctx.params
+        x, v, *rest = ctx.saved_tensors
+        inverse, has_res, gamma_bound, beta_bound, nset = ctx.cfg
+        gms, gts = rest[0::2], rest[1::2]
         N, Cc, H, W = x.shape
         dy, xx = dense(dy), dense(x)
         n = N * Cc * H * W
         dxd, dv = new_act(N, Cc, H, W, x), new_act(N, Cc, H, W, x)
         _lib.check(_L().clc_gdn_bwd_elem(dy.data_ptr(), xx.data_ptr(), v.data_ptr(), dxd.data_ptr(), dv.data_ptr(), n, int(inverse), _stream()), "clc_gdn_bwd_elem")
-        dgamma = dbeta = dx = None
+        out_grads = [None, None] * 2
+        dx = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            gg, gb = _direct_grad(gamma), _direct_grad(beta)
-            direct = gg is not None and gb is not None and gm is gamma
-            if direct and WGRAD_DEFER:
-                # d(gamma_eff) joins the next grouped filter-gradient launch; the re-parametrisation's backward runs right after it
-                dgf = torch.empty(Cc * Cc, device=x.device, dtype=torch.float32)
-                dbe = torch.empty(Cc, device=x.device, dtype=torch.float32)
-                wgrad_raw(xx, dv, ks=1, stride=1, pad=0, Cout=Cc, Cin=Cc, want_bias=True, in_op=IN_SQUARE, dw_out=dgf, db_out=dbe,
-                          accumulate=False, defer=True)
-                _PENDING_POST.append(lambda: _lib.check(_L().clc_gdn_reparam_bwd(gm.data_ptr(), beta.data_ptr(), Cc, gamma_bound, beta_bound,
-                                                                                  dgf.data_ptr(), dbe.data_ptr(), gg.data_ptr(), gb.data_ptr(), 1,
-                                                                                  _stream()), "clc_gdn_reparam_bwd"))
-                _KEEPALIVE.append((gm, beta, dgf, dbe))
-            else:
-                dgf, dbe = wgrad_raw(xx, dv, ks=1, stride=1, pad=0, Cout=Cc, Cin=Cc, want_bias=True, in_op=IN_SQUARE)
-                if not direct:
-                    gg, gb = torch.empty_like(gm), torch.empty_like(beta)
-                _lib.check(_L().clc_gdn_reparam_bwd(gm.data_ptr(), beta.data_ptr(), Cc, gamma_bound, beta_bound, dgf.data_ptr(), dbe.data_ptr(),
-                                                    gg.data_ptr(), gb.data_ptr(), int(direct), _stream()), "clc_gdn_reparam_bwd")
-                if not direct:
-                    dgamma, dbeta = gg, gb
+            hb = N // nset
+            for k, ((gamma, beta), gm) in enumerate(zip(ctx.params, gms)):
+                xk, dvk = (xx, dv) if nset == 1 else (xx[k * hb:(k + 1) * hb], dv[k * hb:(k + 1) * hb])   # this module's half of the batch
+                gg, gb = _direct_grad(gamma), _direct_grad(beta)
+                direct = gg is not None and gb is not None and gm is gamma
+                if direct and WGRAD_DEFER:
+                    # d(gamma_eff) joins the next grouped filter-gradient launch; the re-parametrisation's backward runs right after it
+                    dgf = torch.empty(Cc * Cc, device=x.device, dtype=torch.float32)
+                    dbe = torch.empty(Cc, device=x.device, dtype=torch.float32)
+                    wgrad_raw(xk, dvk, ks=1, stride=1, pad=0, Cout=Cc, Cin=Cc, want_bias=True, in_op=IN_SQUARE, dw_out=dgf, db_out=dbe,
+                              accumulate=False, defer=True)
+
+                    def post(gm=gm, beta=beta, dgf=dgf, dbe=dbe, gg=gg, gb=gb):
+                        _lib.check(_L().clc_gdn_reparam_bwd(gm.data_ptr(), beta.data_ptr(), Cc, gamma_bound, beta_bound, dgf.data_ptr(),
+                                                            dbe.data_ptr(), gg.data_ptr(), gb.data_ptr(), 1, _stream()), "clc_gdn_reparam_bwd")
+                    _PENDING_POST.append(post)
+                    _KEEPALIVE.append((gm, beta, dgf, dbe))
+                else:
+                    dgf, dbe = wgrad_raw(xk, dvk, ks=1, stride=1, pad=0, Cout=Cc, Cin=Cc, want_bias=True, in_op=IN_SQUARE)
+                    if not direct:
+                        gg, gb = torch.empty_like(gm), torch.empty_like(beta)
+                    _lib.check(_L().clc_gdn_reparam_bwd(gm.data_ptr(), beta.data_ptr(), Cc, gamma_bound, beta_bound, dgf.data_ptr(), dbe.data_ptr(),
+                                                        gg.data_ptr(), gb.data_ptr(), int(direct), _stream()), "clc_gdn_reparam_bwd")
+                    if not direct:
+                        out_grads[2 * k], out_grads[2 * k + 1] = gg, gb
         if ctx.needs_input_grad[0]:
             # dx = dx_direct + 2 x (gamma^T dv): the 2x factor and the add ride in the 1x1 data-gradient conv's epilogue
-            dx = conv_raw(dv, g_eff_t, None, ks=1, transposed=True, out_hw=(H, W), norm=NORM_MUL2, mul=xx, res=dxd)
-        return dx, dgamma, dbeta, (dy if has_res and ctx.needs_input_grad[3] else None), None, None, None, None
+            dx = conv_raw(dv, gts[0], None, ks=1, transposed=True, out_hw=(H, W), norm=NORM_MUL2, mul=xx, res=dxd,
+                          w2=(gts[1] if nset == 2 else None))
+        return (dx, out_grads[0], out_grads[1], (dy if has_res and ctx.needs_input_grad[3] else None), None, None, None, None,
+                out_grads[2], out_grads[3])
 
 
-def gdn_param(x, gamma, beta, gamma_bound, beta_bound, pedestal, inverse=False, res=None):
-    return _GDNParamFn.apply(x, gamma, beta, res, bool(inverse), float(gamma_bound), float(beta_bound), float(pedestal))
+def gdn_param(x, gamma, beta, gamma_bound, beta_bound, pedestal, inverse=False, res=None, gamma2=None, beta2=None):
+    return _GDNParamFn.apply(x, gamma, beta, res, bool(inverse), float(gamma_bound), float(beta_bound), float(pedestal), gamma2, beta2)
 
 
 # ------------------------------------------------------------------------------------- LayerNorm
