@@ -834,12 +834,13 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   const int img_pix = (d->transposed && d->stride == 2) ? (d->OH / 2) * (d->OW / 2) : d->OH * d->OW;
   const int C = d->Cout;
   if (img_pix <= 256) {
-    // Heavy data gradients of the slice loop (3x3, 128/224 -> 224..768 on the stacked batch): enough 64x64 tiles to fill the
+    // Heavy data gradients of the slice loop (3x3, 224 -> 448..768 on the stacked batch): enough 64x64 tiles to fill the
     // chip without splitting K, and the LDS-tiled kernel shares each operand tile among 4 waves where the split-K family
     // re-fetches fragments per wave (224 -> 704 @ 4096 rows: 192 -> 130 us).  Data gradients exist in training only, so the
     // codec path's batch-invariant family rule is untouched.  (The forward layers of the same nets measured slower this way.)
     static const int heavy_dgrad = getenv("CLC_HEAVY_DGRAD") ? atoi(getenv("CLC_HEAVY_DGRAD")) : 1;   // 0: A/B knob
-    if (heavy_dgrad && d->transposed && d->ks * d->ks * p.kc_tiles >= 36 && C >= 128 &&
+    static const int heavy_min = getenv("CLC_HEAVY_MIN") ? atoi(getenv("CLC_HEAVY_MIN")) : 60;   // K-tiles (224-channel 3x3: 63); the 36-tile ones measured faster on split-K in the step
+    if (heavy_dgrad && d->transposed && d->ks * d->ks * p.kc_tiles >= heavy_min && C >= 128 &&
         (long)((p.M + 63) / 64) * ((C + 63) / 64) * classes >= 128)
       return launch<64, 64, 2, 2>(p, classes, st);
     // 32x32 tiles: these layers are bound by how many CUs get MFMA work (f32 MFMA = 64 cycles each), not by operand
