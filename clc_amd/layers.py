@@ -73,12 +73,13 @@ class Conv2d(nn.Conv2d):
         self.weight._clc_is_filter = True
 
     def forward(self, x, act=ACT_NONE, res=None, res_scale=1.0, res_first=False, shuffle=False, pair=None, fold_in=None, fold_out=None, out=None,
-                grad_slot=None):
+                grad_slot=None, park_dx=None):
         """pair: a second Conv2d of the same shape applied to the second half of the batch in the same launch.
         fold_in / fold_out: ops.GradFold of a residual block (see there)."""
         return ops.conv2d(x, self.weight, self.bias, stride=self.stride[0], act=act, res=res, res_scale=res_scale,
                           res_first=res_first, shuffle=shuffle, w2=pair.weight if pair is not None else None,
-                          b2=pair.bias if pair is not None else None, fold_in=fold_in, fold_out=fold_out, out=out, grad_slot=grad_slot)
+                          b2=pair.bias if pair is not None else None, fold_in=fold_in, fold_out=fold_out, out=out, grad_slot=grad_slot,
+                          park_dx=park_dx)
 
 
 class Linear(nn.Linear):
@@ -133,8 +134,8 @@ class SubpelConv3x3(nn.Sequential):
         assert r == 2
         super().__init__(Conv2d(i, o * r * r, 3), PixelShuffle2())
 
-    def forward(self, x, act=ACT_NONE, res=None, pair=None):
-        return self[0](x, act=act, res=res, shuffle=True, pair=pair[0] if pair is not None else None)
+    def forward(self, x, act=ACT_NONE, res=None, pair=None, fold_in=None, park_dx=None):
+        return self[0](x, act=act, res=res, shuffle=True, pair=pair[0] if pair is not None else None, fold_in=fold_in, park_dx=park_dx)
 
 
 def subpel_conv3x3(i, o, r=1):
@@ -190,6 +191,12 @@ class ResidualBlockWithStride(nn.Module):
             ws = torch.nn.functional.pad(self.skip.weight.reshape(co, cin), (4 * cin, 32 - 5 * cin))
             t = self.conv2(ops.linear(col, w1, self.conv1.bias, act=ACT_LRELU))
             return self.gdn(t, res=ops.linear(col, ws, self.skip.bias))
+        if self.skip is not None and x.requires_grad:
+            # x feeds conv1 and the skip conv: the skip's input gradient (computed first in backward) is parked and added in
+            # conv1's data-gradient epilogue instead of by an autograd add kernel
+            f = ops.GradFold()
+            t = self.conv2(self.conv1(x, act=ACT_LRELU, fold_in=f))
+            return self.gdn(t, res=self.skip(x, park_dx=f))
         t = self.conv2(self.conv1(x, act=ACT_LRELU))
         identity = self.skip(x) if self.skip is not None else x
         return self.gdn(t, res=identity)
@@ -205,11 +212,12 @@ class ResidualBlockUpsample(nn.Module):
         self.upsample = subpel_conv3x3(in_ch, out_ch, upsample)
 
     def forward(self, x, pair=None):
+        f = ops.GradFold() if x.requires_grad else None   # upsample's input gradient is added in subpel_conv's data-gradient epilogue
         if pair is not None:   # two blocks side by side on a batch-stacked input (the mean / scale hyper-synthesis nets)
-            t = self.conv(self.subpel_conv(x, act=ACT_LRELU, pair=pair.subpel_conv), pair=pair.conv)
-            return self.igdn(t, res=self.upsample(x, pair=pair.upsample), pair=pair.igdn)
-        t = self.conv(self.subpel_conv(x, act=ACT_LRELU))
-        return self.igdn(t, res=self.upsample(x))
+            t = self.conv(self.subpel_conv(x, act=ACT_LRELU, pair=pair.subpel_conv, fold_in=f), pair=pair.conv)
+            return self.igdn(t, res=self.upsample(x, pair=pair.upsample, park_dx=f), pair=pair.igdn)
+        t = self.conv(self.subpel_conv(x, act=ACT_LRELU, fold_in=f))
+        return self.igdn(t, res=self.upsample(x, park_dx=f))
 
 
 class ResidualBlock(nn.Module):

@@ -456,8 +456,9 @@ class _ConvFn(Function):
 
     @staticmethod
     def forward(ctx, x, w, b, res, ks, stride, act, res_scale, shuffle, res_first, w2=None, b2=None, fold_in=None, fold_out=None, out_buf=None,
-                grad_slot=None):
+                grad_slot=None, park_dx=None):
         wk = to_kernel_weight(w)
+        ctx.park_dx = park_dx   # GradFold that takes this layer's input gradient (a sibling layer on the same input adds it in its epilogue)
         wk2 = to_kernel_weight(w2) if w2 is not None else None
         need_grad = any(ctx.needs_input_grad)
         # the activation derivative needs the pre-activation whenever the output does not determine it
@@ -566,15 +567,17 @@ class _ConvFn(Function):
                           w2=(wt_of(w2) if w2 is not None else None), res=extra, res_scale=extra_scale, res_gate=gate, out=dx_out, **fa)
         elif fold_in is not None:
             fold_in.consumed = True
-        return dx, dw, db, dres, None, None, None, None, None, None, dw2, db2, None, None, None, None
+        if dx is not None and ctx.park_dx is not None and ctx.park_dx.park(dx):
+            dx = None
+        return dx, dw, db, dres, None, None, None, None, None, None, dw2, db2, None, None, None, None, None
 
 
 def conv2d(x, w, b=None, *, stride=1, act=ACT_NONE, res=None, res_scale=1.0, shuffle=False, res_first=False, w2=None, b2=None,
-           fold_in=None, fold_out=None, out=None, grad_slot=None):
+           fold_in=None, fold_out=None, out=None, grad_slot=None, park_dx=None):
     """out: optional destination (a pixel-major view, e.g. a channel slice of a wider buffer) written in place."""
     ks = w.shape[2] if w.dim() == 4 else 1
     return _ConvFn.apply(x, w, b, res, ks, stride, act, float(res_scale), bool(shuffle), bool(res_first), w2, b2, fold_in, fold_out, out,
-                         grad_slot)
+                         grad_slot, park_dx)
 
 
 def linear(x, w, b=None, *, act=ACT_NONE, res=None, w2=None, b2=None, fold_in=None, fold_out=None, out=None):
