@@ -239,10 +239,14 @@ class GaussianConditional(EntropyModel):
         self._cdf_length = (pmf_length + 2).to(dev)
         self._host_tables = None
 
-    def likelihood_and_ste(self, y, scales, means, training=None):
-        """(likelihood, ste_round(y - means) + means) in one kernel (CLC_run.py:569-571)."""
+    def likelihood_and_ste(self, y, scales, means, training=None, noise=None):
+        """(likelihood, ste_round(y - means) + means) in one kernel (CLC_run.py:569-571).  noise: pre-drawn U(-1/2, 1/2) of y's
+        shape (the model draws all slices' noise in one launch); drawn here when None."""
         training = self.training if training is None else training
-        noise = torch.empty_like(y, memory_format=ops.CL).uniform_(-0.5, 0.5) if training else None
+        if training and noise is None:
+            noise = torch.empty_like(y, memory_format=ops.CL).uniform_(-0.5, 0.5)
+        if not training:
+            noise = None
         return ops.gaussian_likelihood(y, scales, means, noise, training)
 
     def forward(self, inputs, scales, means=None, training=None):

@@ -230,11 +230,15 @@ class _SliceCodec(CompressionModel):
         latent_means, latent_scales = self._hyper_synthesis(z_hat)
         y_hat_slices, y_lik, mus, scales = [], [], [], []
         ref_pair = torch.cat((ref_features, ref_features), dim=0) if (ref_features is not None and ops.PAIR_SLICES) else None
-        for i, y_slice in enumerate(ops.split_channels(y, [y.shape[1] // self.num_slices] * self.num_slices)):
+        S = y.shape[1] // self.num_slices
+        # the additive-noise proxy of training (one uniform draw per latent element): all slices' noise in ONE launch
+        noise_all = torch.empty_like(y, memory_format=CL).uniform_(-0.5, 0.5) if self.gaussian_conditional.training else None
+        for i, y_slice in enumerate(ops.split_channels(y, [S] * self.num_slices)):
             mean_support, mu, scale = self._slice_params(i, latent_means, latent_scales, y_hat_slices, ref_features, y_shape, ref_pair)
             mus.append(mu)
             scales.append(scale)
-            lik, y_hat_slice = self.gaussian_conditional.likelihood_and_ste(y_slice, scale, mu)
+            lik, y_hat_slice = self.gaussian_conditional.likelihood_and_ste(
+                y_slice, scale, mu, noise=noise_all[:, i * S:(i + 1) * S] if noise_all is not None else None)
             y_lik.append(lik)
             y_hat_slices.append(self._refine(i, mean_support, y_hat_slice, ref_features))
         x_hat = self.g_s(torch.cat(y_hat_slices, dim=1))
