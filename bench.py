@@ -134,6 +134,9 @@ def roofline_leg(engine, x, refs):
     return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
             "launches_per_step": n, "avg_launch_ms": round(t / n * 1e3, 4), "event_bracket_overhead_ms": round(empty * 1e3, 5),
+            "timing_note": "event-bracketed EAGER step (HIP events cannot be recorded inside a hipGraph on ROCm 7.2): the host paces it, the GPU "
+                           "idles between launches and holds a lower clock, so these per-kernel times read 3-25 % above the graph-replay times "
+                           "that rocprofv3 reports for the timed region (profiles/)",
             "all_mfma_kernels": {"tflops": round(total_f / total_t / 1e12, 2), "ms_per_step": round(total_t * 1e3, 2), "gflop_per_step": round(total_f / 1e9, 1)},
             "per_kernel": table}
 
