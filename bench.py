@@ -175,7 +175,7 @@ def main():
 
     from clc_amd import models
     from clc_amd.train import TrainEngine, broadcast_parameters
-    from oracle.recipe import apply_weight_recipe  # checker-side weight recipe: same named weights as the cpu_baseline leg
+    from clc_amd.recipe import apply_weight_recipe  # by-name seeded weights: the cpu_baseline leg gives the oracle the same ones
 
     torch.manual_seed(0)
     model = models.CLC(N=64, num_ref_frames=args.n_refs)

@@ -28,8 +28,8 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const clc_param_entry*
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(const clc_param_entry* __restrict__ table, const int2* __restrict__ chunks,
-                                                  const float* __restrict__ total_sqnorm, float max_norm, float lr, float beta1, float beta2,
-                                                  float eps, float wd, const float* __restrict__ step) {
+                                                  const float* __restrict__ total_sqnorm, float max_norm, const float* __restrict__ lr_dev, float omb1,
+                                                  float beta2, float omb2, float eps, float wd, const float* __restrict__ step) {
   const int2 ch = chunks[blockIdx.x];
   const clc_param_entry e = table[ch.x];
   const long beg = (long)ch.y, end = min(e.n, beg + kChunk);
@@ -38,21 +38,30 @@ __global__ __launch_bounds__(256) void adamw_kernel(const clc_param_entry* __res
     const float c = max_norm / (sqrtf(total_sqnorm[0]) + 1e-6f);
     clip = c < 1.f ? c : (c >= 1.f ? 1.f : c);  // NaN propagates like torch.clamp(max=1)
   }
-  const float t = step[0];
-  const float bc1 = 1.f - powf(beta1, t), bc2 = 1.f - powf(beta2, t);
-  const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+  const float lr = lr_dev[0];   // device-resident: a captured hipGraph follows the learning-rate schedule (MultiStepLR, train_CLC.py:453,497)
+  // step = {t, 1 - beta1^t, sqrt(1 - beta2^t)}: the bias corrections are evaluated once per step in double (adam_tick_kernel),
+  // as torch.optim.AdamW's host code does, not 49 M times in float
+  const float step_size = lr / step[1], bc2_sqrt = step[2];
   for (long i = beg + threadIdx.x; i < end; i += 256) {
     float g = e.g[i] * clip;
     if (isnan(g)) g = 0.f; else if (isinf(g)) g = g > 0.f ? 3.402823466e+38f : -3.402823466e+38f;  // nan_to_num_
     float p = e.p[i] * (1.f - lr * wd);
-    const float m = beta1 * e.m[i] + (1.f - beta1) * g;
-    const float v = beta2 * e.v[i] + (1.f - beta2) * g * g;
-    p -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
+    const float m0 = e.m[i];
+    const float m = m0 + omb1 * (g - m0);            // exp_avg.lerp_(grad, 1 - beta1)
+    const float v = beta2 * e.v[i] + omb2 * g * g;   // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    p -= step_size * (m / (sqrtf(v) / bc2_sqrt + eps));   // addcdiv_(m, sqrt(v)/sqrt(bc2) + eps, value=-step_size)
     e.p[i] = p; e.m[i] = m; e.v[i] = v; e.g[i] = g;
   }
 }
 
 __global__ void scalar_add_kernel(float* x, float v) { x[0] += v; }
+
+__global__ void adam_tick_kernel(float* state, double beta1, double beta2) {
+  const float t = state[0] + 1.f;
+  state[0] = t;
+  state[1] = (float)(1.0 - pow(beta1, (double)t));
+  state[2] = (float)sqrt(1.0 - pow(beta2, (double)t));
+}
 }  // namespace
 
 extern "C" int clc_optim_chunk_elems(void) { return kChunk; }
@@ -66,11 +75,18 @@ extern "C" int clc_grad_sqnorm_partials(const clc_param_entry* table_dev, const 
 }
 
 extern "C" int clc_adamw_step(const clc_param_entry* table_dev, const int32_t* chunks_dev, int n_chunks, const float* total_sqnorm_dev,
-                              float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, const float* step_dev,
-                              clc_stream_t stream) {
-  CLC_CHECK(table_dev && chunks_dev && step_dev && n_chunks > 0, "clc_adamw_step: bad args");
+                              float max_norm, const float* lr_dev, double beta1, double beta2, float eps, float weight_decay,
+                              const float* step_dev, clc_stream_t stream) {
+  CLC_CHECK(table_dev && chunks_dev && step_dev && lr_dev && n_chunks > 0, "clc_adamw_step: bad args");
   hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table_dev, (const int2*)chunks_dev, total_sqnorm_dev,
-                     max_norm, lr, beta1, beta2, eps, weight_decay, step_dev);
+                     max_norm, lr_dev, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay, step_dev);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int clc_adam_tick(float* state_dev, double beta1, double beta2, clc_stream_t stream) {
+  CLC_CHECK(state_dev, "clc_adam_tick: null");
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state_dev, beta1, beta2);
   CLC_LAUNCH_CHECK();
   return 0;
 }

@@ -50,14 +50,20 @@ class EntropyModel(nn.Module):
 
     def host_tables(self):
         """int32 numpy views of the CDF tables (one D2H copy per model, not per call as in CLC_run.py:654-656)."""
-        if self._host_tables is None or self._host_tables[3] is not self._quantized_cdf:
+        # stale when the buffer object was replaced (update()) OR rewritten in place (load_state_dict copies into it: _version moves)
+        key = (self._quantized_cdf, self._quantized_cdf._version, self._cdf_length._version, self._offset._version)
+        if self._host_tables is None or self._host_tables[3][0] is not key[0] or self._host_tables[3][1:] != key[1:]:
             if self._quantized_cdf.numel() == 0:
                 raise ValueError("CDF tables are empty: call update() first")
             cdf = np.ascontiguousarray(self._quantized_cdf.detach().cpu().numpy().astype(np.int32))
             ln = np.ascontiguousarray(self._cdf_length.detach().cpu().numpy().astype(np.int32).reshape(-1))
             off = np.ascontiguousarray(self._offset.detach().cpu().numpy().astype(np.int32).reshape(-1))
-            self._host_tables = (cdf, ln, off, self._quantized_cdf)
+            self._host_tables = (cdf, ln, off, key)
         return self._host_tables[:3]
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._host_tables = None   # the tables are about to be overwritten in place
+        return super()._load_from_state_dict(*args, **kwargs)
 
     def quantize(self, inputs, mode, means=None):
         if mode == "noise":

@@ -55,7 +55,7 @@ class ParamEntry(C.Structure):
     _fields_ = [("p", fp), ("g", fp), ("m", fp), ("v", fp), ("n", C.c_long)]
 
 
-_i, _l, _f, _sz = C.c_int, C.c_long, C.c_float, C.c_size_t
+_i, _l, _f, _d, _sz = C.c_int, C.c_long, C.c_float, C.c_double, C.c_size_t
 _pp = C.POINTER(fp)
 
 # name -> (restype, argtypes); every symbol include/clc_hip.h declares must appear here
@@ -124,7 +124,8 @@ SIGNATURES = {
     "clc_avgpool2": (_i, [fp, _i, fp, _i, _i, _i, _i, fp]),
     "clc_optim_chunk_elems": (_i, []),
     "clc_grad_sqnorm_partials": (_i, [fp, fp, _i, fp, fp]),
-    "clc_adamw_step": (_i, [fp, fp, _i, fp, _f, _f, _f, _f, _f, _f, fp, fp]),
+    "clc_adamw_step": (_i, [fp, fp, _i, fp, _f, fp, _d, _d, _f, _f, fp, fp]),
+    "clc_adam_tick": (_i, [fp, _d, _d, fp]),
     "clc_scalar_add": (_i, [fp, _f, fp]),
     "clc_rans_encode_bound": (_l, [_l]),
     "clc_rans_encode": (_l, [fp, fp, _l, fp, _i, fp, fp, fp, _l]),

@@ -1229,6 +1229,11 @@ def ms_ssim(x, y, data_range=1.0, weights=(0.0448, 0.2856, 0.3001, 0.2363, 0.133
     [5, B, C] product of powers is a handful of scalar-sized torch ops."""
     B, Cc = x.shape[0], x.shape[1]
     means = _MsSsimMeansFn.apply(x, y, len(weights), float(data_range)).view(len(weights), B, Cc, 2)
-    vals = torch.cat([torch.relu(means[:-1, :, :, 0]), torch.relu(means[-1:, :, :, 1])], dim=0)
-    w = torch.tensor(weights, device=x.device, dtype=torch.float32).view(-1, 1, 1)
-    return torch.prod(vals ** w, dim=0).mean()
+    # exponents are host scalars: no host->device tensor is built here, so the loss can be captured into a hipGraph
+    # (TrainEngine(loss_type='ms_ssim') = the reference's --type ms-ssim mode)
+    L = len(weights)
+    out = None
+    for s in range(L):
+        v = torch.relu(means[s, :, :, 0 if s + 1 < L else 1]) ** float(weights[s])
+        out = v if out is None else out * v
+    return out.mean()

@@ -164,7 +164,10 @@ class FusedAdamW:
         dev = self.p_arena.flat.device
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.step_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        # optimizer state the kernels read from DEVICE memory, so a captured hipGraph keeps following it:
+        #   step_dev = {t, 1 - beta1^t, sqrt(1 - beta2^t)} (advanced by clc_adam_tick), lr_dev = the current learning rate
+        self.step_dev = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
         self.sqnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         L = _lib.load()
         chunk = L.clc_optim_chunk_elems()
@@ -185,15 +188,28 @@ class FusedAdamW:
     def zero_grad(self):
         self.g_arena.flat.zero_()
 
+    def set_lr(self, lr: float):
+        """Learning-rate schedule hook (MultiStepLR in the reference, train_CLC.py:453,497): the kernels read the rate from
+        device memory, so this also takes effect on an already captured hipGraph."""
+        self.lr = float(lr)
+        self.lr_dev.fill_(self.lr)
+
+    def state_snapshot(self):
+        return [t.clone() for t in (self.p_arena.flat, self.m, self.v, self.step_dev)]
+
+    def state_restore(self, snap):
+        for dst, src in zip((self.p_arena.flat, self.m, self.v, self.step_dev), snap):
+            dst.copy_(src)
+
     def step(self):
         L, st = _lib.load(), ops._stream()
-        _lib.check(L.clc_scalar_add(self.step_dev.data_ptr(), 1.0, st), "clc_scalar_add")
+        _lib.check(L.clc_adam_tick(self.step_dev.data_ptr(), float(self.betas[0]), float(self.betas[1]), st), "clc_adam_tick")
         sq = None
         if self.max_norm > 0:
             _lib.check(L.clc_grad_sqnorm_partials(self.table.data_ptr(), self.chunks.data_ptr(), self.n_chunks, self.partials.data_ptr(), st), "clc_grad_sqnorm_partials")
             _lib.check(L.clc_sum_partials(self.partials.data_ptr(), self.n_chunks, 1.0, self.sqnorm.data_ptr(), 0, st), "clc_sum_partials")
             sq = self.sqnorm.data_ptr()
-        _lib.check(L.clc_adamw_step(self.table.data_ptr(), self.chunks.data_ptr(), self.n_chunks, sq, float(self.max_norm), float(self.lr),
+        _lib.check(L.clc_adamw_step(self.table.data_ptr(), self.chunks.data_ptr(), self.n_chunks, sq, float(self.max_norm), self.lr_dev.data_ptr(),
                                     float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), self.step_dev.data_ptr(), st), "clc_adamw_step")
 
 
@@ -301,24 +317,58 @@ class TrainEngine:
         out = self._opt_steps(out)
         return self._finish(out)
 
+    def set_lr(self, lr: float = None, aux_lr: float = None):
+        """Learning-rate schedule hook (the reference steps a MultiStepLR once per epoch, train_CLC.py:453,497).  The rates live
+        in device memory, so the change also reaches an already captured hipGraph."""
+        if lr is not None:
+            self.lr = float(lr)
+            if self.opt is not None:
+                self.opt.set_lr(lr)
+        if aux_lr is not None:
+            self.aux_lr = float(aux_lr)
+            if self.aux_opt is not None:
+                self.aux_opt.set_lr(aux_lr)
+
+    @staticmethod
+    def _signature(x, refs):
+        return (tuple(x.shape), None if refs is None else tuple(tuple(r.shape) for r in refs))
+
     def step(self, x, refs=None):
         refs = list(refs) if refs is not None else None
         if self.opt is None:
             self._discover(x, refs)
+            self._live_refs = refs is not None
+        if (refs is not None) != self._live_refs:
+            # the set of parameters that receive gradients (and with it the flat arenas / DDP buckets) depends on whether
+            # references are given (CLC_run.py:550-580 picks the ref_* or the plain slice nets)
+            raise ValueError("TrainEngine was set up %s reference frames; build a second engine for the other mode"
+                             % ("with" if self._live_refs else "without"))
         # CLC_FORCE_SPLIT_GRAPHS=1 exercises the multi-GPU structure (graph A | exchange | graph B) on one GPU
         single = self.sync.world == 1 and os.environ.get("CLC_FORCE_SPLIT_GRAPHS", "0") != "1"
         if not self.use_graph:
             return self._eager_step(x, refs)
+        sig = self._signature(x, refs)
+        if self.graph is not None and sig != self._static_sig:
+            # a batch of another shape (the reference's DataLoader has no drop_last, train_CLC.py:428-434: the last batch of an
+            # epoch is short): run it eagerly — same arithmetic, launch overhead for this one step only
+            return self._eager_step(x, refs)
         if self.graph is None:
-            # warm up on a side stream (allocator + lazy kernel attributes), then capture
+            # warm up on a side stream (allocator + lazy kernel attributes), then capture.  The warm-up steps must not count as
+            # training steps: parameters, Adam moments and step counters are restored afterwards, so the FIRST replay is the
+            # first optimizer update (the reference applies exactly one per batch, train_CLC.py:137-183)
             self._static = (x.clone(), [r.clone() for r in refs] if refs is not None else None)
+            self._static_sig = sig
+            snap = (self.opt.state_snapshot(), self.aux_opt.state_snapshot())
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 for _ in range(2):
                     self._eager_step(*self._static)
+                self.opt.state_restore(snap[0])
+                self.aux_opt.state_restore(snap[1])
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
+            del snap
             if single:
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph):

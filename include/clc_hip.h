@@ -330,11 +330,15 @@ typedef struct { float* p; float* g; float* m; float* v; long n; } clc_param_ent
 int clc_optim_chunk_elems(void);
 int clc_grad_sqnorm_partials(const clc_param_entry* table_dev, const int32_t* chunks_dev, int n_chunks, float* partials,
                              clc_stream_t stream);
-/* g <- nan_to_num(g * min(1, max_norm/(sqrt(*total_sqnorm_dev)+1e-6))) ; AdamW update with the
- * step count read from *step_dev (device float, >= 1) so the launch is graph-replayable. */
+/* state_dev[3] = {t, 1 - beta1^t, sqrt(1 - beta2^t)}: t += 1 and the two bias corrections of torch.optim.AdamW, evaluated in
+ * double on the device (one thread) so the optimizer step stays graph-replayable. */
+int clc_adam_tick(float* state_dev, double beta1, double beta2, clc_stream_t stream);
+/* g <- nan_to_num(g * min(1, max_norm/(sqrt(*total_sqnorm_dev)+1e-6))) ; AdamW update with the step state
+ * read from step_dev[3] (clc_adam_tick) and the learning rate from *lr_dev (device float) so a
+ * captured launch is graph-replayable AND follows the MultiStepLR schedule (train_CLC.py:453,497). */
 int clc_adamw_step(const clc_param_entry* table_dev, const int32_t* chunks_dev, int n_chunks, const float* total_sqnorm_dev,
-                   float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, const float* step_dev,
-                   clc_stream_t stream);
+                   float max_norm, const float* lr_dev, double beta1, double beta2, float eps, float weight_decay,
+                   const float* step_dev, clc_stream_t stream);
 int clc_scalar_add(float* x_dev, float v, clc_stream_t stream);
 
 /* ---- entropy coder (HOST, bit-exact) --------------------------------------------------- *

@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle is the checker: a GPU box reports every host core but grants a 16-CPU share per GPU, and an intra-op pool
+    # sized to the reported count is an order of magnitude slower than one sized to the share
+    import torch
+
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(16, usable)))
 
 
 @pytest.fixture(scope="session")

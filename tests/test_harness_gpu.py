@@ -1,0 +1,300 @@
+"""GPU parity of the harness arithmetic that runs inside every timed step:
+the fused clip_grad_norm_ + nan_to_num_ + AdamW step, the aux (quantiles) step, the hipGraph-captured engine against the
+reference training loop (/root/reference/train_CLC.py:137-183) written with torch.optim.AdamW, the learning-rate hook on a
+captured graph, and clc_amd.eval's pad / crop / PSNR / bitrate (/root/reference/eval_CLC.py:133-166, 324-338).
+"""
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CL = torch.channels_last
+
+
+def _make_params(dev, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(64, 32, 3, 3), (17,), (128, 64), (5, 3, 1, 1), (4097,), (224, 128, 3, 3), (1, 1), (320, 320)]
+    cpu = [torch.randn(s, generator=g) * 0.1 for s in shapes]
+    cpu = [t.contiguous(memory_format=CL) if t.dim() == 4 else t for t in cpu]
+    return cpu
+
+
+def _grads(cpu_params, seed, scale):
+    g = torch.Generator().manual_seed(1000 + seed)
+    return [torch.randn(p.shape, generator=g) * scale for p in cpu_params]
+
+
+@pytest.mark.parametrize("max_norm", [1.0, 0.0])
+def test_fused_adamw_matches_torch(dev, max_norm):
+    """6 steps of clip_grad_norm_(max_norm) + nan_to_num_ + torch.optim.AdamW (train_CLC.py:164-179) on CPU vs clc_adamw_step:
+    clip active (step 1), clip inactive (2), a NaN gradient (3: the norm is NaN, every gradient becomes 0), an Inf gradient
+    (4: coefficient 0, inf*0 = NaN -> 0), ordinary steps after the non-finite ones (5-6: moments must have stayed finite)."""
+    from clc_amd.train import FusedAdamW
+
+    cpu = _make_params(dev)
+    ref = [torch.nn.Parameter(p.clone()) for p in cpu]
+    prm = [torch.nn.Parameter(p.clone().to(dev)) for p in cpu]
+    prm = [torch.nn.Parameter(p.data.contiguous(memory_format=CL)) if p.dim() == 4 else p for p in prm]
+    opt_ref = torch.optim.AdamW(ref, lr=1e-3, foreach=False)
+    opt = FusedAdamW(prm, lr=1e-3, max_norm=max_norm)
+    for step, scale in enumerate([1.0, 1e-4, 1.0, 1.0, 0.5, 1e-3], start=1):
+        gs = _grads(cpu, step, scale)
+        if step == 3:
+            gs[2][5, 7] = float("nan")
+        if step == 4:
+            gs[0][1, 2, 0, 1] = float("inf")
+            gs[5][3, 3, 1, 1] = float("-inf")
+        old = [p.detach().clone() for p in ref]
+        for p, g in zip(ref, gs):
+            p.grad = g.clone()
+        if max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(ref, max_norm)
+        for p in ref:
+            p.grad.nan_to_num_()
+        opt_ref.step()
+        opt.zero_grad()
+        for p, g in zip(prm, gs):
+            p.grad.copy_(g.to(dev))   # the persistent gradient views of the arena
+        opt.step()
+        torch.cuda.synchronize()
+        for i, (a, b, o) in enumerate(zip(prm, ref, old)):
+            upd_ref = (b.detach() - o).double()
+            scale_u = max(upd_ref.abs().max().item(), 1e-12)
+            err = (a.detach().cpu().double() - b.detach().double()).abs()
+            # both sides round the new parameter to fp32 (1 ulp of |p|); beyond that the update itself must agree to 1e-5 of its
+            # size — a wrong bias correction, clip coefficient or step count is an error of 10 % .. 10x of the update
+            allowed = 2.0 ** -23 * b.detach().abs().double() + 1e-5 * scale_u
+            assert bool((err <= allowed).all()), f"step {step} tensor {i}: max excess {(err - allowed).max().item():.3e} (update scale {scale_u:.3e})"
+            st = opt_ref.state[b]
+            off = opt.p_arena.offsets[i]
+            m = opt.m[off: off + b.numel()].cpu()
+            v = opt.v[off: off + b.numel()].cpu()
+            phys = (lambda t: t.permute(0, 2, 3, 1).reshape(-1)) if b.dim() == 4 else (lambda t: t.reshape(-1))
+            if max_norm > 0:   # clipping turns every non-finite gradient into 0 before it reaches the moments
+                assert torch.isfinite(m).all() and torch.isfinite(v).all()
+            torch.testing.assert_close(m, phys(st["exp_avg"]), rtol=2e-6, atol=1e-30, msg=lambda s_: f"step {step} tensor {i} exp_avg: {s_}")
+            torch.testing.assert_close(v, phys(st["exp_avg_sq"]), rtol=2e-6, atol=1e-30, msg=lambda s_: f"step {step} tensor {i} exp_avg_sq: {s_}")
+            # the gradient the optimizer saw (clipped, nan_to_num'ed) is left in place, like p.grad in the reference loop
+            torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=2e-6, atol=1e-30, msg=lambda s_: f"step {step} tensor {i} grad: {s_}")
+
+
+def test_adamw_inf_without_clip_saturates(dev):
+    """nan_to_num_ maps +-inf to +-FLT_MAX when no clipping multiplies it by 0 first (train_CLC.py:176-178 with clip_max_norm=0)."""
+    from clc_amd.train import FusedAdamW
+
+    p_ref = torch.nn.Parameter(torch.linspace(-1, 1, 300))
+    p = torch.nn.Parameter(p_ref.detach().clone().to(dev))
+    o_ref, o = torch.optim.AdamW([p_ref], lr=1e-3, foreach=False), FusedAdamW([p], lr=1e-3, max_norm=0.0)
+    g = torch.linspace(-2, 2, 300)
+    g[10], g[20], g[30] = float("inf"), float("-inf"), float("nan")
+    for _ in range(2):
+        p_ref.grad = g.clone()
+        p_ref.grad.nan_to_num_()
+        o_ref.step()
+        o.zero_grad()
+        p.grad.copy_(g.to(dev))
+        o.step()
+    torch.cuda.synchronize()
+    assert torch.allclose(p.detach().cpu(), p_ref.detach(), rtol=1e-6, atol=1e-9)
+
+
+def test_aux_loss_and_aux_step(dev):
+    """EntropyBottleneck.loss() (aux loss, train_CLC.py:181) and its quantiles gradient vs the oracle leaf, then three aux-optimizer
+    steps (AdamW on *.quantiles, lr 1e-3, train_CLC.py:100-104,182-183) vs torch.optim.AdamW."""
+    from clc_amd.entropy_models import EntropyBottleneck
+    from clc_amd.recipe import apply_weight_recipe
+    from clc_amd.train import FusedAdamW
+    from oracle import leaves
+
+    o = leaves.EntropyBottleneck(192)
+    apply_weight_recipe(o, 5)
+    p = EntropyBottleneck(192)
+    p.load_state_dict(o.state_dict())
+    p = p.to(dev)
+    opt_ref = torch.optim.AdamW([o.quantiles], lr=1e-3, foreach=False)
+    opt = FusedAdamW([p.quantiles], lr=1e-3, max_norm=0.0)
+    for step in range(3):
+        opt_ref.zero_grad()
+        lo = o.loss()
+        lo.backward()
+        opt.zero_grad()
+        lp = p.loss()
+        lp.backward()
+        assert abs(lo.item() - lp.item()) <= 2e-5 * abs(lo.item()), (step, lo.item(), lp.item())
+        gq, gr = p.quantiles.grad.cpu(), o.quantiles.grad
+        assert (gq - gr).abs().max().item() <= 1e-4 * gr.abs().max().item(), step
+        for prm in (p._matrix0, p._bias2, p._factor1):   # the aux loss detaches the density parameters (CompressAI loss())
+            assert prm.grad is None
+        old = o.quantiles.detach().clone()
+        opt_ref.step()
+        opt.step()
+        upd_ref, upd = o.quantiles.detach() - old, p.quantiles.detach().cpu() - old
+        assert (upd - upd_ref).abs().max().item() <= 2e-4 * upd_ref.abs().max().item(), step
+
+
+def _reference_loop(model, x, refs, steps, lmbda, lr, aux_lr, clip, loss_type="mse"):
+    """train_CLC.py:137-183 verbatim in behaviour: zero_grad, forward, loss.backward, clip_grad_norm_, nan_to_num_, AdamW, aux."""
+    from clc_amd.train import RateDistortionLoss
+
+    params = [p for n, p in model.named_parameters() if not n.endswith(".quantiles")]
+    aux = [p for n, p in model.named_parameters() if n.endswith(".quantiles")]
+    opt, aux_opt = torch.optim.AdamW(params, lr=lr), torch.optim.AdamW(aux, lr=aux_lr)
+    crit = RateDistortionLoss(lmbda, loss_type)
+    seq = []
+    for _ in range(steps):
+        opt.zero_grad()
+        aux_opt.zero_grad()
+        out = crit(model(x, refs), x)
+        out["loss"].backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+        for p in model.parameters():
+            if p.grad is not None:
+                p.grad.nan_to_num_()
+        opt.step()
+        aux_loss = model.aux_loss()
+        aux_loss.backward()
+        aux_opt.step()
+        seq.append((out["loss"].item(), out["bpp_loss"].item(), aux_loss.item()))
+    return seq
+
+
+def _model(dev, R=1, seed=0):
+    from clc_amd import models as pm
+    from clc_amd.recipe import apply_weight_recipe
+
+    m = pm.CLC(N=64, num_ref_frames=R)
+    apply_weight_recipe(m, seed)
+    return m.to(dev)
+
+
+def _inputs(dev, B, R, size=256):
+    from clc_amd.recipe import synthetic_image
+
+    return synthetic_image(B, size, size, 100, smooth=True).to(dev), [synthetic_image(B, size, size, 101 + i, smooth=True).to(dev) for i in range(R)]
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_engine_equals_reference_training_loop(dev, use_graph):
+    """TrainEngine (flat arenas, fused optimizer, hipGraph) against the reference loop driven by torch.optim.AdamW on the same
+    product model: 4 steps, the loss / bpp / aux-loss sequences and the final parameters.  Also pins that the captured path
+    applies exactly ONE update per call (the graph warm-up must not train)."""
+    from clc_amd.train import TrainEngine
+
+    x, refs = _inputs(dev, 2, 1)
+    m_ref = _model(dev).eval()          # eval-mode rounding: deterministic (the noise proxy would need shared RNG streams)
+    ref_seq = _reference_loop(m_ref, x, refs, 4, 0.0067, 1e-4, 1e-3, 1.0)
+    m = _model(dev)
+    eng = TrainEngine(m, lmbda=0.0067, lr=1e-4, aux_lr=1e-3, clip_max_norm=1.0, use_graph=use_graph, train_mode=False)
+    seq = []
+    for _ in range(4):
+        out = eng.step(x, refs)
+        seq.append((out["loss"].item(), out["bpp_loss"].item(), out["aux_loss"].item()))
+    for i, (a, b) in enumerate(zip(seq, ref_seq)):
+        for u, v, name in zip(a, b, ("loss", "bpp", "aux")):
+            assert abs(u - v) <= 3e-4 * max(1.0, abs(v)), f"step {i} {name}: engine {u} vs reference loop {v}"
+    assert ref_seq[3][0] < ref_seq[0][0]
+    assert float(eng.opt.step_dev[0].item()) == 4.0 and float(eng.aux_opt.step_dev[0].item()) == 4.0
+    pr = dict(m_ref.named_parameters())
+    worst = 0.0
+    for n, p in m.named_parameters():
+        d = (p.detach() - pr[n].detach()).abs().max().item()
+        worst = max(worst, d / max(pr[n].detach().abs().max().item(), 1e-6))
+    # 4 Adam steps of lr 1e-4: every element moved by up to ~4e-4; agreement to a few % of one step's movement
+    assert worst < 2e-5, worst
+
+
+def test_set_lr_reaches_captured_graph(dev):
+    """MultiStepLR (train_CLC.py:453,497) changes lr between epochs: the captured step must follow."""
+    from clc_amd.train import TrainEngine
+
+    x, refs = _inputs(dev, 2, 1)
+    m = _model(dev)
+    eng = TrainEngine(m, lmbda=0.0067, lr=1e-4, aux_lr=1e-3, use_graph=True, train_mode=False)
+    eng.step(x, refs)
+    w = m.g_a[0].conv1.weight
+    q = m.entropy_bottleneck.quantiles
+    before, qb = w.detach().clone(), q.detach().clone()
+    eng.set_lr(0.0, 0.0)
+    eng.step(x, refs)
+    assert torch.equal(w.detach(), before) and torch.equal(q.detach(), qb), "lr = 0 must freeze the parameters (update and weight decay scale with lr)"
+    eng.set_lr(1e-4, 1e-3)
+    eng.step(x, refs)
+    d1 = (w.detach() - before).abs().max().item()
+    assert 1e-6 < d1 < 5e-4, d1
+    before2 = w.detach().clone()
+    eng.set_lr(1e-5)
+    eng.step(x, refs)
+    d2 = (w.detach() - before2).abs().max().item()
+    assert d2 < 0.25 * d1, (d1, d2)
+
+
+def test_ms_ssim_engine_graph_and_shape_change(dev):
+    """--type ms-ssim (train_CLC.py:56-57) under hipGraph capture == eager, bit for bit; a batch of another shape (the last,
+    short batch of an epoch: the reference DataLoader has no drop_last) falls back to an eager step instead of failing."""
+    from clc_amd.train import TrainEngine
+
+    x, refs = _inputs(dev, 2, 1)
+    seqs = {}
+    for use_graph in (False, True):
+        eng = TrainEngine(_model(dev), lmbda=0.05, loss_type="ms_ssim", use_graph=use_graph, train_mode=False)
+        seqs[use_graph] = [eng.step(x, refs)["loss"].item() for _ in range(3)]
+        assert "ms_ssim_loss" in eng.step(x, refs)
+    assert seqs[False] == seqs[True], seqs
+    out = eng.step(x[:1], [refs[0][:1]])   # short batch on the captured engine
+    assert math.isfinite(out["loss"].item())
+    with pytest.raises(ValueError):
+        eng.step(x, None)
+
+
+def test_force_split_graphs_is_bit_identical(dev, monkeypatch):
+    """The multi-GPU step structure (graph A = fwd+bwd | gradient exchange | graph B = optimizer + aux) forced on one GPU gives
+    the same loss sequence, bit for bit, as the single-graph path."""
+    from clc_amd.train import TrainEngine
+
+    x, refs = _inputs(dev, 2, 1)
+    seqs = []
+    for split in ("0", "1"):
+        monkeypatch.setenv("CLC_FORCE_SPLIT_GRAPHS", split)
+        eng = TrainEngine(_model(dev), lmbda=0.0067, use_graph=True, train_mode=False)
+        seqs.append([eng.step(x, refs)["loss"].item() for _ in range(4)])
+    assert seqs[0] == seqs[1], seqs
+
+
+# ------------------------------------------------------------------------------------------------- eval helpers (row 16)
+
+
+def test_eval_pad_crop_psnr_bitrate(dev):
+    """clc_amd.eval on a 200x300 image (not a multiple of 128): pad / crop geometry and values == the oracle's (eval_CLC.py:133-166),
+    PSNR from the HIP squared-error reduction == the oracle's formula, evaluate() rows == bitrate / PSNR recomputed by hand
+    from compress()/decompress() (eval_CLC.py:324-338)."""
+    from clc_amd import eval as pe
+    from clc_amd.recipe import synthetic_image
+    from oracle import loss as ol
+
+    x = synthetic_image(1, 200, 300, 7, smooth=True)
+    xp_o, pad_o = ol.pad(x, 128)
+    xp, pad_p = pe.pad(x.to(dev), 128)
+    assert pad_p == pad_o == (42, 42, 28, 28) and tuple(xp.shape) == (1, 3, 256, 384)
+    assert torch.equal(xp.cpu(), xp_o)
+    assert torch.equal(pe.crop(xp, pad_p).cpu(), x) and torch.equal(ol.crop(xp_o, pad_o), x)
+    noisy = (x + 0.01 * torch.randn(x.shape, generator=torch.Generator().manual_seed(3))).clamp(0, 1)
+    assert abs(pe.compute_psnr(x.to(dev), noisy.to(dev)) - ol.compute_psnr(x, noisy)) <= 1e-4
+    m = _model(dev).eval()
+    r = synthetic_image(1, 200, 300, 8, smooth=True)
+    res = pe.evaluate(m, [(x[0], [r[0]])], p=128, device=dev)
+    # by hand, eval_CLC.py:324-338
+    enc = m.compress(xp, [pe.pad(r.to(dev), 128)[0]])
+    dec = m.decompress(enc["strings"], enc["shape"], [pe.pad(r.to(dev), 128)[0]])
+    x_hat = ol.crop(dec["x_hat"].cpu(), pad_o)
+    bitrate = sum(len(s[0]) for s in enc["strings"]) * 8.0 / (200 * 300)
+    assert res["rows"][0]["bpp"] == bitrate
+    assert abs(res["rows"][0]["psnr"] - ol.compute_psnr(x, x_hat)) <= 1e-3
+    assert res["avg_bpp"] == bitrate and res["avg_time_s"] > 0
+    # likelihood-based bpp helper (eval_CLC.py:158-166 compute_bpp)
+    with torch.no_grad():
+        out = m(xp, [pe.pad(r.to(dev), 128)[0]])
+    cpu_out = {"x_hat": out["x_hat"].cpu(), "likelihoods": {k: v.cpu() for k, v in out["likelihoods"].items()}}
+    assert abs(pe.compute_bpp(out) - ol.compute_bpp(cpu_out)) <= 1e-5
