@@ -266,11 +266,15 @@ class _SliceCodec(CompressionModel):
             sym_parts.append(sym)
             idx_parts.append(idx)
             y_hat_slices.append(self._refine(i, mean_support, y_hat_slice, ref_features))
-        # ONE D2H copy for all slices; element order inside a slice is the reference's NCHW reshape(-1)
+        return {"strings": [self._encode_y(sym_parts, idx_parts), z_strings], "shape": z.size()[-2:]}
+
+    def _encode_y(self, sym_parts, idx_parts):
+        """Per-slice int32 symbol / index tensors (logical NCHW) -> [one y stream]: slices concatenated in order, element order
+        inside a slice = the reference's NCHW reshape(-1) (CLC_run.py:695-696, 712-714); ONE D2H copy for all slices."""
+        cdf, cdf_len, off = self.gaussian_conditional.host_tables()
         sym_all = torch.stack([s.contiguous() for s in sym_parts]).cpu().numpy().reshape(-1)
         idx_all = torch.stack([s.contiguous() for s in idx_parts]).cpu().numpy().reshape(-1)
-        y_string = ans.encode(sym_all, idx_all, cdf, cdf_len, off)
-        return {"strings": [[y_string], z_strings], "shape": z.size()[-2:]}
+        return [ans.encode(sym_all, idx_all, cdf, cdf_len, off)]
 
     @torch.no_grad()
     def decompress(self, strings, shape, ref_frames=None):

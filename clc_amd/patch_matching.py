@@ -63,13 +63,20 @@ def _topk(cross_corr, k):
 
 
 def SI_Wraper(cross_corr, patch_h, patch_w, patchs_num, y, k=1, temperature=15, is_stack=False):
-    """softmax(top-k value * temperature)-weighted gather of the k best patches of ``y`` per query patch, re-tiled."""
-    if is_stack:
-        raise NotImplementedError("is_stack=True (k stacked candidates) is not built; the weighted sum is")
+    """softmax(top-k value * temperature)-weighted gather of the k best patches of ``y`` per query patch, re-tiled
+    ([1, C, H, W]); is_stack=True: the k candidates unweighted, stacked along the channels ([1, k*C, H, W], candidate-major —
+    Patch_Matching.py:235-236)."""
     y = _chk(y, "SI_Wraper")
     _, C, H, W = y.shape
     assert patchs_num == (H // patch_h) * (W // patch_w) == cross_corr.shape[1]
     val, idx = _topk(cross_corr, k)
+    if is_stack:
+        out = torch.empty((1, k * C, H, W), device=y.device, dtype=torch.float32)
+        for j in range(k):   # candidate j of every query patch, copied as it is (k = 1 gather without weights)
+            idx_j = idx[:, j].contiguous()
+            _lib.check(_L().clc_pm_gather(y.data_ptr(), C, H, W, patch_h, patch_w, None, idx_j.data_ptr(), 1, -1.0,
+                                          out[:, j * C:(j + 1) * C].data_ptr(), _stream()), "clc_pm_gather")
+        return out
     out = torch.empty((1, C, H, W), device=y.device, dtype=torch.float32)
     _lib.check(_L().clc_pm_gather(y.data_ptr(), C, H, W, patch_h, patch_w, val.data_ptr(), idx.data_ptr(), k, float(temperature), out.data_ptr(), _stream()), "clc_pm_gather")
     return out

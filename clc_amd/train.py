@@ -269,6 +269,7 @@ class TrainEngine:
 
     # -- discovery: which parameters does this (model, inputs) combination actually train?
     def _discover(self, x, refs):
+        self._live_refs = refs is not None
         self.model.train(self.train_mode)
         for p in self.model.parameters():
             p.grad = None
@@ -337,7 +338,6 @@ class TrainEngine:
         refs = list(refs) if refs is not None else None
         if self.opt is None:
             self._discover(x, refs)
-            self._live_refs = refs is not None
         if (refs is not None) != self._live_refs:
             # the set of parameters that receive gradients (and with it the flat arenas / DDP buckets) depends on whether
             # references are given (CLC_run.py:550-580 picks the ref_* or the plain slice nets)

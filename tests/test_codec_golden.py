@@ -1,0 +1,112 @@
+"""Codec wiring pinned by the reference's OWN compress() / decompress().
+
+tests/golden/codec_{clc_r1,clc_r3,tcm}.npz were produced by tools/make_golden.py running
+/root/reference/models/CLC_run.py:629-716, 738-814 (and tcm.py's twins) through tools/ref_shim.py on seeded inputs: the y / z
+stream bytes, `shape`, the tensors the coder saw (y, z, means, scales) and a digest of the decoded x_hat.  Checked here:
+  * CPU: the oracle model's compress() reproduces both streams byte for byte and its decompress() the x_hat digest;
+         from the stored tensors, the oracle's quantise / build_indexes + all three coders (pure Python, plain C, the product's
+         C++ coder through the C ABI — host code, no GPU) reproduce the y stream; the product coder decodes it back.
+  * GPU: the HIP quantise/build_indexes kernel on the stored tensors + the product coder, in the order the product's
+         compress() concatenates them, reproduce the y stream; EntropyBottleneck.compress on the stored z reproduces the z
+         stream; end to end the HIP compress() emits the same container layout with sizes within 1 % (rounding flips only).
+So symbol order, slice concatenation and the strings layout come from reference code, not from a reading of it.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CASES = [("clc_r1", 1), ("clc_r3", 3), ("tcm", 0)]
+
+
+def _load(name):
+    g = np.load(os.path.join(GOLD, f"codec_{name}.npz"))
+    return g, bytes(g["y_stream"].tobytes()), bytes(g["z_stream"].tobytes())
+
+
+def _oracle(name, R):
+    from clc_amd.recipe import apply_weight_recipe, synthetic_image
+    from oracle import graph
+
+    torch.manual_seed(0)
+    m = (graph.CLC(N=64, num_ref_frames=R) if R else graph.TCM(N=64)).eval()
+    apply_weight_recipe(m, 0)
+    m.update(force=True)
+    x = synthetic_image(1, 256, 256, 100, smooth=True)
+    refs = [synthetic_image(1, 256, 256, 101 + i, smooth=True) for i in range(R)]
+    return m, x, refs
+
+
+@pytest.mark.parametrize("name,R", CASES)
+def test_oracle_compress_reproduces_reference_streams(name, R):
+    g, ys, zs = _load(name)
+    m, x, refs = _oracle(name, R)
+    with torch.no_grad():
+        enc = m.compress(x, refs) if R else m.compress(x)
+        assert enc["strings"][0][0] == ys and enc["strings"][1][0] == zs and list(enc["shape"]) == g["shape"].tolist()
+        dec = m.decompress([[ys], [zs]], torch.Size(g["shape"].tolist()), refs) if R else m.decompress([[ys], [zs]], torch.Size(g["shape"].tolist()))
+    assert hashlib.sha256(dec["x_hat"].numpy().tobytes()).hexdigest() == str(g["x_hat_sha256"])
+    assert abs(8.0 * (len(ys) + len(zs)) / 65536 - float(g["bpp"])) == 0.0
+
+
+@pytest.mark.parametrize("name,R", CASES)
+def test_three_coders_reproduce_reference_y_stream_from_stored_tensors(name, R):
+    """symbols = round(y - mu) per slice in NCHW order, slices concatenated, ONE stream (CLC_run.py:689-713)."""
+    from clc_amd import ans
+    from oracle import leaves, rans_c, rans_py
+
+    g, ys, zs = _load(name)
+    gc = leaves.GaussianConditional(None)
+    gc.update_scale_table(leaves.get_scale_table())
+    y, mu, sc = (torch.from_numpy(g[k]) for k in ("y", "means", "scales"))
+    sym = torch.cat([gc.quantize(a, "symbols", m).reshape(-1) for a, m in zip(y.chunk(5, 1), mu.chunk(5, 1))]).numpy().astype(np.int32)
+    idx = torch.cat([gc.build_indexes(s).reshape(-1) for s in sc.chunk(5, 1)]).numpy().astype(np.int32)
+    cdf = np.ascontiguousarray(gc.quantized_cdf.numpy().astype(np.int32))
+    ln, off = gc.cdf_length.numpy().astype(np.int32), gc.offset.numpy().astype(np.int32)
+    assert rans_c.encode(sym, idx, cdf, ln, off) == ys
+    assert ans.encode(sym, idx, cdf, ln, off) == ys                                   # product C++ coder (host)
+    assert rans_py.RansEncoder().encode_with_indexes(sym.tolist(), idx.tolist(), cdf.tolist(), ln.tolist(), off.tolist()) == ys
+    assert np.array_equal(ans.decode(ys, idx, cdf, ln, off), sym)
+    # the reference API shape: BufferedRansEncoder fed slice by slice == one call (compressai.ans surface)
+    enc = ans.BufferedRansEncoder()
+    for k in range(5):
+        n = sym.size // 5
+        enc.encode_with_indexes(sym[k * n:(k + 1) * n].tolist(), idx[k * n:(k + 1) * n].tolist(), cdf.tolist(), ln.tolist(), off.tolist())
+    assert enc.flush() == ys
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,R", CASES)
+def test_hip_codec_reproduces_reference_streams(dev, name, R):
+    from clc_amd import models as pm
+    from clc_amd.recipe import apply_weight_recipe, synthetic_image
+
+    g, ys, zs = _load(name)
+    torch.manual_seed(0)
+    p = pm.CLC(N=64, num_ref_frames=R) if R else pm.TCM(N=64)
+    apply_weight_recipe(p, 0)
+    p = p.to(dev).eval()
+    p.update(force=True)
+    CL = torch.channels_last
+    y, mu, sc, z = (torch.from_numpy(g[k]).to(dev).contiguous(memory_format=CL) for k in ("y", "means", "scales", "z"))
+    # (1) integer path of compress() on identical tensors: HIP quantise/build_indexes kernel + product coder, product order
+    parts = [p.gaussian_conditional.quantize_and_index(a, m, s) for a, m, s in zip(y.chunk(5, 1), mu.chunk(5, 1), sc.chunk(5, 1))]
+    assert p._encode_y([q[0] for q in parts], [q[1] for q in parts]) == [ys]
+    for (sym, idx, y_hat), a, m in zip(parts, y.chunk(5, 1), mu.chunk(5, 1)):
+        assert torch.equal(y_hat, torch.round(a - m) + m)
+    # (2) z stream from the stored z
+    assert p.entropy_bottleneck.compress(z) == [zs]
+    # (3) decoding the GOLDEN strings with the HIP transforms is deliberately NOT asserted: the context model is float, and one
+    #     scale landing on the other side of a table threshold (|d scale| ~ 1e-6 between a CPU and a GPU summation order)
+    #     de-synchronises an arithmetic decoder — the reference has the same property across devices.  The decoder's integer path
+    #     is pinned on the CPU (ans.decode of the golden stream == the reference's symbols) and its agreement with the product's
+    #     own encoder by test_codec_roundtrip_and_bitstream / test_config4_*.
+    x = synthetic_image(1, 256, 256, 100, smooth=True).to(dev)
+    refs = [synthetic_image(1, 256, 256, 101 + i, smooth=True).to(dev) for i in range(R)]
+    # (4) end to end on the HIP transforms: same container layout, size within 1 % of the reference's (float rounding flips only)
+    enc = p.compress(x, refs) if R else p.compress(x)
+    assert list(enc["shape"]) == g["shape"].tolist() and len(enc["strings"][0]) == 1 and len(enc["strings"][1]) == 1
+    assert abs(len(enc["strings"][0][0]) - len(ys)) <= 0.01 * len(ys) and abs(len(enc["strings"][1][0]) - len(zs)) <= 0.02 * len(zs) + 8

