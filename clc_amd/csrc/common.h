@@ -10,6 +10,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void clc_set_error(const char* fmt, ...);
 
+// Process-wide tuning switches (clc_set_tuning): A/B knobs that select between kernel variants computing the SAME bits.
+enum { CLC_TUNE_DMA_LOOP = 0 /* 1: conv_igemm_dma_kernel, 2: conv_igemm_dma2_kernel (re-timed K loop) */, CLC_TUNE_WGRAD_STREAMK = 1, CLC_TUNE_COUNT = 16 };
+extern int clc_tuning[CLC_TUNE_COUNT];
+
 #define CLC_CHECK(cond, ...)            \
   do {                                  \
     if (!(cond)) {                      \

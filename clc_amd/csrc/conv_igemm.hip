@@ -490,6 +490,195 @@ void conv_igemm_dma_kernel(const ConvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv_igemm_dma_kernel with the K loop re-timed (same tiles, same K order, same MFMA sequence -> same bits):
+//   * the gather address of a row is (origin + tap delta): origin byte offset and a 9-bit tap-validity mask are computed
+//     once per row, the tap delta is a scalar -> ~4 VALU instructions per DMA piece instead of ~12 with two v_mul_lo_u32;
+//   * the next tile's DMA pieces are issued BETWEEN the MFMA groups of the current tile (their address VALU executes in
+//     the shadow of the MFMA that was just issued) instead of in a block of their own at the top of the iteration, and
+//     without a branch around them (the last iteration deposits zeros in the idle buffer);
+//   * group 0's fragments of the next tile are read right after the barrier, two fragment register sets are offered to the
+//     scheduler (hipcc still sinks most reads to just before their first MFMA; pinning the order with sched_group_barrier
+//     did not change that).
+template <int BM, int BN, int WM, int WN, bool TR>
+__global__ __launch_bounds__(64 * WM * WN, (64 * WM * WN) >= 512 ? 4 : ((64 * WM * WN) >= 256 ? 2 : 4))
+void conv_igemm_dma2_kernel(const ConvParams p) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_P = BM * 8 / NT, B_P = BN * 8 / NT;
+  static_assert(TM >= 1 && TN >= 1 && A_P * NT == BM * 8 && B_P * NT == BN * 8, "tile");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                    // [2][BM][BK], slot-swizzled
+  float* Bs = smem + 2 * BM * BK;      // [2][BN][BK]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int cls = blockIdx.z, ph = cls >> 1, pw = cls & 1;
+  const bool half = p.transposed && p.stride == 2;
+  const int DH = half ? p.OH / 2 : p.OH, DW = half ? p.OW / 2 : p.OW;
+  const TapGrid tg = make_taps(p, ph, pw);
+
+  const bool second = p.w2 != nullptr && m0 >= p.group_rows;
+  const float* wsel = second ? p.w2 : p.w;
+  const float* bsel = second ? p.bias2 : p.bias;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wsel), 0, p.w_bytes, 0x00020000);
+
+  // Row r of the tile at tap-grid index (j, i) reads source pixel origin + sgn * (j * W + i): forward taps walk up/right from
+  // (y0, x0); a data gradient walks down/left from (y0 - kh0, x0 - kw0) (>> 1 for stride 2: the tap grid has the class's parity).
+  constexpr int sgn = TR ? -1 : 1;
+  unsigned a_base[A_P], a_mask[A_P], b_base[B_P];
+  int a_c4[A_P], b_c4[B_P];
+  bool b_ok[B_P];
+#pragma unroll
+  for (int i = 0; i < A_P; ++i) {
+    const int r = (tid + i * NT) >> 3;
+    const RowState rs = make_row<TR>(p, m0 + r, DH, DW, ph, pw);
+    a_c4[i] = ((tid & 7) ^ ((r >> 1) & 7)) * 4;
+    int oy, ox;
+    if (TR) { const int sh = p.stride - 1; oy = (rs.y0 - tg.kh0) >> sh; ox = (rs.x0 - tg.kw0) >> sh; }
+    else { oy = rs.y0 + tg.kh0; ox = rs.x0 + tg.kw0; }
+    unsigned mask = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int iy = oy + sgn * j, ix = ox + sgn * q;
+        const bool ok = rs.ok && j < tg.nkh && q < tg.nkw && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        mask |= ok ? (1u << (j * 3 + q)) : 0u;
+      }
+    a_mask[i] = mask;
+    a_base[i] = ((unsigned)(rs.base + oy * p.W + ox) * (unsigned)p.ldx + (unsigned)a_c4[i]) * 4u;   // (wraps harmlessly when invalid: never used then)
+  }
+#pragma unroll
+  for (int i = 0; i < B_P; ++i) {
+    const int r = (tid + i * NT) >> 3;
+    const int co = n0 + r;
+    b_ok[i] = co < p.Cout;
+    b_c4[i] = ((tid & 7) ^ ((r >> 1) & 7)) * 4;
+    b_base[i] = ((unsigned)co * (unsigned)p.ldw + (unsigned)b_c4[i]) * 4u;
+  }
+  const int wave_row = wave * 8;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int total = tg.nkh * tg.nkw * p.kc_tiles;
+  int tj = 0, ti = 0, kc = 0;
+  auto advance = [&]() {   // branch-free: the loop body stays ONE scheduling region
+    const int kc1 = kc + 1;
+    const bool w1 = kc1 == p.kc_tiles;
+    kc = w1 ? 0 : kc1;
+    const int ti1 = ti + (w1 ? 1 : 0);
+    const bool w2 = ti1 == tg.nkw;
+    ti = w2 ? 0 : ti1;
+    tj += w2 ? 1 : 0;
+  };
+  // scalar state of the tile being fetched
+  unsigned s_bit, s_adelta, s_bdelta; int s_cleft; bool s_en;
+  auto set_fetch = [&](bool en) {
+    s_en = en;
+    s_bit = 1u << (tj * 3 + ti);
+    s_cleft = p.Cin - kc * BK;
+    s_adelta = (unsigned)(sgn * (tj * p.W + ti) * p.ldx + kc * BK) * 4u;
+    const int kh = tg.kh0 + tg.step * tj, kw = tg.kw0 + tg.step * ti;
+    s_bdelta = (unsigned)((kh * p.ks + kw) * p.Cin + kc * BK) * 4u;
+  };
+  auto dma_a = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) {
+      const bool ok = s_en && (a_mask[i] & s_bit) != 0u && a_c4[i] < s_cleft;
+      dma16(xr, As + (buf * BM + wave_row + i * (NT / 8)) * BK, ok ? a_base[i] + s_adelta : kOOB);
+    }
+  };
+  auto dma_b = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < B_P; ++i) {
+      const bool ok = s_en && b_ok[i] && b_c4[i] < s_cleft;
+      dma16(wr, Bs + (buf * BN + wave_row + i * (NT / 8)) * BK, ok ? b_base[i] + s_bdelta : kOOB);
+    }
+  };
+  set_fetch(true);
+  dma_a(0);
+  dma_b(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int lr = lane & 31, hh = lane >> 5, sw = (lr >> 1) & 7;
+  int fo[4];
+#pragma unroll
+  for (int t8 = 0; t8 < 4; ++t8) fo[t8] = ((2 * t8 + hh) ^ sw) * 4;
+  f32x4 af[2][TM], bf[2][TN];
+  auto read_frag = [&](int buf, int t8, f32x4 (&a)[TM], f32x4 (&b)[TN]) {
+    const float* Ab = As + (buf * BM + wm * (BM / WM) + lr) * BK + fo[t8];
+    const float* Bb = Bs + (buf * BN + wn * (BN / WN) + lr) * BK + fo[t8];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * BK);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * BK);
+  };
+  auto mfma_group = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) {
+#pragma unroll
+    for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][ss], b[j][ss], acc[i][j], 0, 0, 0);
+  };
+  read_frag(0, 0, af[0], bf[0]);
+  for (int it = 0; it < total; ++it) {
+    const int buf = it & 1;
+    advance();
+    set_fetch(it + 1 < total);
+    read_frag(buf, 1, af[1], bf[1]);
+    mfma_group(af[0], bf[0]);
+    dma_a(buf ^ 1);
+    read_frag(buf, 2, af[0], bf[0]);
+    mfma_group(af[1], bf[1]);
+    dma_b(buf ^ 1);
+    read_frag(buf, 3, af[1], bf[1]);
+    mfma_group(af[0], bf[0]);
+    mfma_group(af[1], bf[1]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's DMA pieces have landed
+    __syncthreads();
+    read_frag(buf ^ 1, 0, af[0], bf[0]);                // (after the last tile: a harmless read of the zero-filled buffer)
+  }
+
+  constexpr int LDC = BN + 4;
+  float* Cs = smem;   // [BM][LDC]
+  __syncthreads();    // every wave's trailing fragment read is done before the tile is overwritten
+  {
+    const int col = lane & 31, rhalf = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          Cs[(wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf) * LDC + wn * (BN / WN) + j * 32 + col] = acc[i][j][r];
+  }
+  __syncthreads();
+  if (p.vec_epi) {   // block-uniform
+    for (int e = tid; e < BM * BN / 4; e += NT) {
+      const int row = e / (BN / 4), cc = (e - row * (BN / 4)) * 4;
+      const int m = m0 + row, co = n0 + cc;
+      if (m < p.M && co < p.Cout) epilogue_store4(p, bsel, *reinterpret_cast<const f32x4*>(Cs + row * LDC + cc), m, co, DH, DW, ph, pw);
+    }
+    return;
+  }
+  for (int e = tid; e < BM * BN; e += NT) {
+    const int row = e / BN, cc = e - row * BN;
+    const int m = m0 + row, co = n0 + cc;
+    if (m < p.M && co < p.Cout) epilogue_store(p, Cs[row * LDC + cc], bsel ? bsel[co] : 0.f, m, co, DH, DW, ph, pw);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Small maps (<= 16x16 per image): latency, not MFMA rate, is what matters (a 64->64 3x3 at 8x16x16 is 0.15 GFLOP).
 // One 32 x BN output tile per workgroup of KW = 8 waves; wave w owns K-tiles w, w+8, ... and loads its MFMA fragments
 // STRAIGHT from global memory into registers in operand layout (lane (i,h) needs 4 consecutive k of its own row i:
@@ -642,10 +831,26 @@ int launch_dma_t(const ConvParams& p, int classes, hipStream_t st) {
   CLC_LAUNCH_CHECK();
   return (2 << 20) | (WM << 16) | (WN << 12) | (BM << 3) | (BN >> 5);  // family 2 = conv_igemm_dma_kernel<BM,BN,WM,WN>
 }
+template <int BM, int BN, int WM, int WN, bool TR>
+int launch_dma2_t(const ConvParams& p, int classes, hipStream_t st) {
+  dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, classes);
+  constexpr size_t lds_ab = (size_t)2 * (BM + BN) * BK * sizeof(float), lds_c = (size_t)BM * (BN + 4) * sizeof(float);
+  constexpr size_t lds = lds_ab > lds_c ? lds_ab : lds_c;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma2_kernel<BM, BN, WM, WN, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_dma2_kernel<BM, BN, WM, WN, TR>), grid, dim3(64 * WM * WN), lds, st, p);
+  CLC_LAUNCH_CHECK();
+  return (4 << 20) | (WM << 16) | (WN << 12) | (BM << 3) | (BN >> 5);  // family 4 = conv_igemm_dma2_kernel<BM,BN,WM,WN>
+}
 template <int BM, int BN, int WM, int WN>
 int launch(const ConvParams& p, int classes, hipStream_t st) {
   static const int use_dma = getenv("CLC_DMA") ? atoi(getenv("CLC_DMA")) : 1;   // CLC_DMA=0: register staging everywhere (A/B knob)
   static const int dma_small = getenv("CLC_DMA_SMALL") ? atoi(getenv("CLC_DMA_SMALL")) : 1;
+  if (use_dma && p.in_op == CLC_IN_NONE && p.xs == nullptr && (BM >= 128 || dma_small) && clc_tuning[CLC_TUNE_DMA_LOOP] == 2)
+    return p.transposed ? launch_dma2_t<BM, BN, WM, WN, true>(p, classes, st) : launch_dma2_t<BM, BN, WM, WN, false>(p, classes, st);
   if (use_dma && p.in_op == CLC_IN_NONE && p.xs == nullptr && (BM >= 128 || dma_small))   // no input prologue -> the tiles can go straight to LDS
     return p.transposed ? launch_dma_t<BM, BN, WM, WN, true>(p, classes, st) : launch_dma_t<BM, BN, WM, WN, false>(p, classes, st);
   return p.transposed ? launch_t<BM, BN, WM, WN, true>(p, classes, st) : launch_t<BM, BN, WM, WN, false>(p, classes, st);

@@ -37,8 +37,12 @@ struct WgradParams {
   int nci;          // ci tiles
 };
 
+// Where a workgroup's result goes.  mode 0: global [Cout][T][Cin] layout, plain store (a split's slab or the gradient itself);
+// mode 1: same layout, accumulate (single writer per element); mode 2: compact tile image (stream-K partial slot).
+struct OutSpec { float* w; float* b; int mode; };
+
 template <int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, const int by, const int bz) {
+__device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, const int by, const int k_begin, const int k_end, const OutSpec o) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_P = (BK * BM / 4 + NT - 1) / NT, B_P = (BK * BN / 4 + NT - 1) / NT;
@@ -52,11 +56,8 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
   const int tap = bx / p.nci, ci0 = (bx % p.nci) * BN;
   const int kh = tap / p.ks, kw = tap - kh * p.ks;
   const int co0 = by * BM;
-  const int split = bz;
-  const int k_begin = split * p.k_per_split;
-  const int k_end = min(p.K, k_begin + p.k_per_split);
   const int ntiles = (k_end - k_begin + BK - 1) / BK;
-  const bool do_bias = (p.bias_partial != nullptr) && (bx == 0);
+  const bool do_bias = (o.b != nullptr) && (bx == 0);
 
   f32x4 a_reg[A_P], b_reg[B_P], bias_acc[A_P], s_reg[A_P];
 #pragma unroll
@@ -149,22 +150,23 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
     __syncthreads();
   }
 
-  // partial slab [split][Cout][T][Cin]
+  // result: [Cout][T][Cin] (slab / gradient) or the compact [BM][BN] image of a stream-K partial
   const int T = p.ks * p.ks;
-  float* slab = p.partial + (size_t)split * p.Cout * T * p.Cin;
   const int rhalf = 4 * (lane >> 5);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int ci = ci0 + wn * (BN / WN) + j * 32 + li;
-    if (ci >= p.Cin) continue;
+    const int cil = wn * (BN / WN) + j * 32 + li, ci = ci0 + cil;
+    if (o.mode != 2 && ci >= p.Cin) continue;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
-        if (co < p.Cout) {
-          float* dst = slab + ((size_t)co * T + tap) * p.Cin + ci;
-          *dst = p.rmw ? *dst + acc[i][j][r] : acc[i][j][r];
+        const int col = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf, co = co0 + col;
+        if (o.mode == 2) {
+          o.w[col * BN + cil] = acc[i][j][r];
+        } else if (co < p.Cout) {
+          float* dst = o.w + ((size_t)co * T + tap) * p.Cin + ci;
+          *dst = o.mode == 1 ? *dst + acc[i][j][r] : acc[i][j][r];
         }
       }
   }
@@ -181,9 +183,11 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
     for (int c = tid; c < BM; c += NT) {
       float s = 0.f;
       for (int r = 0; r < BK; ++r) s += red[r * BM + c];
-      if (co0 + c < p.Cout) {
-        float* dst = p.bias_partial + (size_t)split * p.Cout + co0 + c;
-        *dst = p.rmw ? *dst + s : s;
+      if (o.mode == 2) {
+        o.b[c] = s;
+      } else if (co0 + c < p.Cout) {
+        float* dst = o.b + co0 + c;
+        *dst = o.mode == 1 ? *dst + s : s;
       }
     }
   }
@@ -197,7 +201,7 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
 // 64 co x (9 taps x 64 ci) outputs per workgroup, wave (wm, wn) = 32 co x 32 ci x 9 taps = 9 MFMA blocks (144 acc
 // registers), 10 ds_read_b32 per 9 MFMAs.  Same slab layout / fixed-order reduce as above.
 template <int TW>
-__device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int bx, const int by, const int bz) {
+__device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int bx, const int by, const int t_begin, const int t_end, const OutSpec o) {
   constexpr int TH = 32 / TW, XW = TW + 2, XH = TH + 2, XP = XH * XW;
   constexpr int LTW = TW == 32 ? 5 : (TW == 16 ? 4 : 3);
   constexpr int X_P = (XP * 16 + 255) / 256;
@@ -207,11 +211,9 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int ci0 = bx * 64, co0 = by * 64, split = bz;
-  const int t_begin = split * (p.k_per_split >> 5);
-  const int t_end = min(p.K >> 5, t_begin + (p.k_per_split >> 5));
+  const int ci0 = bx * 64, co0 = by * 64;
   const int ntiles = t_end - t_begin;
-  const bool do_bias = (p.bias_partial != nullptr) && (bx == 0);
+  const bool do_bias = (o.b != nullptr) && (bx == 0);
   const int lcols = p.ow_shift - LTW;                       // log2(tile columns per image row)
   const int lrows = (p.img_shift - p.ow_shift) - (5 - LTW); // log2(tile rows per image)
 
@@ -292,18 +294,19 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int 
     __syncthreads();
   }
 
-  // partial slab [split][Cout][9][Cin]
-  float* slab = p.partial + (size_t)split * p.Cout * 9 * p.Cin;
-  const int ci = ci0 + wn * 32 + li;
-  if (ci < p.Cin) {
+  // result: [Cout][9][Cin] (slab / gradient) or the compact [64][9][64] image of a stream-K partial
+  const int cil = wn * 32 + li, ci = ci0 + cil;
+  if (o.mode == 2 || ci < p.Cin) {
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        if (co < p.Cout) {
-          float* dst = slab + ((size_t)co * 9 + t) * p.Cin + ci;
-          *dst = p.rmw ? *dst + acc[t][r] : acc[t][r];
+        const int col = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf, co = co0 + col;
+        if (o.mode == 2) {
+          o.w[(col * 9 + t) * 64 + cil] = acc[t][r];
+        } else if (co < p.Cout) {
+          float* dst = o.w + ((size_t)co * 9 + t) * p.Cin + ci;
+          *dst = o.mode == 1 ? *dst + acc[t][r] : acc[t][r];
         }
       }
   }
@@ -317,24 +320,38 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int 
     if (tid < 64) {
       float sum = 0.f;
       for (int r = 0; r < 32; ++r) sum += red[r * 64 + tid];
-      if (co0 + tid < p.Cout) {
-        float* dst = p.bias_partial + (size_t)split * p.Cout + co0 + tid;
-        *dst = p.rmw ? *dst + sum : sum;
+      if (o.mode == 2) {
+        o.b[tid] = sum;
+      } else if (co0 + tid < p.Cout) {
+        float* dst = o.b + co0 + tid;
+        *dst = o.mode == 1 ? *dst + sum : sum;
       }
     }
   }
 }
 
+// split-K form: split z of a problem covers K-range z * k_per_split .. and writes slab z (or, single split, the gradient itself)
+__device__ __forceinline__ OutSpec split_out(const WgradParams& p, int split) {
+  OutSpec o;
+  o.w = p.partial + (size_t)split * p.Cout * p.ks * p.ks * p.Cin;
+  o.b = p.bias_partial ? p.bias_partial + (size_t)split * p.Cout : nullptr;
+  o.mode = p.rmw ? 1 : 0;
+  return o;
+}
+__device__ __forceinline__ int taps_range_begin(const WgradParams& p, int split) { return split * (p.k_per_split >> 5); }
+__device__ __forceinline__ int taps_range_end(const WgradParams& p, int split) { return min(p.K >> 5, (split + 1) * (p.k_per_split >> 5)); }
+
 template <int TW>
 __global__ __launch_bounds__(256, 2)
 void conv_wgrad_taps_kernel(const WgradParams p) {
-  wgrad_taps_body<TW>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+  wgrad_taps_body<TW>(p, blockIdx.x, blockIdx.y, taps_range_begin(p, blockIdx.z), taps_range_end(p, blockIdx.z), split_out(p, blockIdx.z));
 }
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN, 2)
 void conv_wgrad_kernel(const WgradParams p) {
-  wgrad_body<BM, BN, WM, WN>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+  const int kb = blockIdx.z * p.k_per_split;
+  wgrad_body<BM, BN, WM, WN>(p, blockIdx.x, blockIdx.y, kb, min(p.K, kb + p.k_per_split), split_out(p, blockIdx.z));
 }
 
 // Grouped launch: up to kMaxGroup independent filter-gradient problems of one tile shape in ONE grid (descriptors in the
@@ -357,7 +374,9 @@ void conv_wgrad_grouped_kernel(const WgradGroup g) {
   const int l = b - (idx ? g.wg_end[idx - 1] : 0);
   const int gx = g.gx[idx], gy = g.gy[idx];
   const int bx = l % gx, t = l / gx;
-  wgrad_body<BM, BN, WM, WN>(g.p[idx], bx, t % gy, t / gy);
+  const WgradParams& p = g.p[idx];
+  const int kb = (t / gy) * p.k_per_split;
+  wgrad_body<BM, BN, WM, WN>(p, bx, t % gy, kb, min(p.K, kb + p.k_per_split), split_out(p, t / gy));
 }
 
 template <int TW>
@@ -369,7 +388,138 @@ void conv_wgrad_taps_grouped_kernel(const WgradGroup g) {
   const int l = b - (idx ? g.wg_end[idx - 1] : 0);
   const int gx = g.gx[idx], gy = g.gy[idx];
   const int bx = l % gx, t = l / gx;
-  wgrad_taps_body<TW>(g.p[idx], bx, t % gy, t / gy);
+  const WgradParams& p = g.p[idx];
+  wgrad_taps_body<TW>(p, bx, t % gy, taps_range_begin(p, t / gy), taps_range_end(p, t / gy), split_out(p, t / gy));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stream-K form of the grouped launch.  The split-K form above sizes every problem as if it had the chip to itself (~256-512
+// workgroups each), so a 64-problem group writes and re-reads thousands of partial slabs (8.5 GB per training step, r1 PMC
+// profile).  Here ONE grid of G <= 512 workgroups (two per CU) covers the group: the K-units (32 output pixels) of all
+// (problem, tile) pairs are laid end to end and workgroup w takes the contiguous range [w*U/G, (w+1)*U/G).  It keeps
+// accumulating in registers while it stays inside a tile and writes
+//   * straight into the gradient when it covers a tile's whole K range,
+//   * else a compact partial image into slot 0 (it CONTINUES a tile begun by workgroup w-1) or slot 1 (it BEGINS a tile that
+//     workgroup w+1 continues) of its own slot pair -> at most two partials per workgroup, ~G x |tile| bytes per launch.
+// wgrad_sk_fixup_kernel then adds the partials of every split tile in workgroup order (fixed order -> run-to-run reproducible;
+// the ranges depend only on the group's shapes, never on timing).
+struct SKGroup {
+  int count, G, slot_floats;
+  long total;                    // K-units of the whole group
+  long unit_end[kMaxGroup];      // exclusive prefix of K-units per problem
+  int T[kMaxGroup];              // K-units per tile
+  int gx[kMaxGroup], gy[kMaxGroup];
+  float* slots;                  // [G][2][slot_floats]
+  WgradParams p[kMaxGroup];      // partial = the gradient itself, bias_partial = the bias gradient (or null), rmw = accumulate
+};
+
+struct SKSeg { int idx, tile, k0, k1; };
+__device__ __forceinline__ SKSeg sk_locate(const SKGroup& g, long u, long end, int& idx) {
+  while (u >= g.unit_end[idx]) ++idx;
+  const long base = idx ? g.unit_end[idx - 1] : 0;
+  const int T = g.T[idx];
+  const long local = u - base;
+  SKSeg sgm;
+  sgm.idx = idx;
+  sgm.tile = (int)(local / T);
+  sgm.k0 = (int)(local - (long)sgm.tile * T);
+  const long k1 = (long)sgm.k0 + (end - u);
+  sgm.k1 = k1 < T ? (int)k1 : T;
+  return sgm;
+}
+__device__ __forceinline__ OutSpec sk_out(const SKGroup& g, const WgradParams& p, const SKSeg& sgm, int T, int w, int tile_floats) {
+  OutSpec o;
+  if (sgm.k0 == 0 && sgm.k1 == T) {
+    o.w = p.partial; o.b = p.bias_partial; o.mode = p.rmw ? 1 : 0;
+  } else {
+    float* slot = g.slots + ((size_t)w * 2 + (sgm.k0 > 0 ? 0 : 1)) * g.slot_floats;
+    o.w = slot; o.b = p.bias_partial ? slot + tile_floats : nullptr; o.mode = 2;
+  }
+  return o;
+}
+
+template <int TW>
+__global__ __launch_bounds__(256, 2)
+void conv_wgrad_taps_sk_kernel(const SKGroup g) {
+  const int w = blockIdx.x;
+  long u = (long)w * g.total / g.G;
+  const long end = (long)(w + 1) * g.total / g.G;
+  int idx = 0;
+  bool first = true;
+  while (u < end) {
+    const SKSeg sgm = sk_locate(g, u, end, idx);
+    const WgradParams& p = g.p[sgm.idx];
+    const int gx = g.gx[sgm.idx];
+    if (!first) __syncthreads();   // the previous segment's LDS tiles / bias reduction are done with
+    wgrad_taps_body<TW>(p, sgm.tile % gx, sgm.tile / gx, sgm.k0, sgm.k1, sk_out(g, p, sgm, g.T[sgm.idx], w, 64 * 9 * 64));
+    first = false;
+    u += sgm.k1 - sgm.k0;
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2)
+void conv_wgrad_sk_kernel(const SKGroup g) {
+  const int w = blockIdx.x;
+  long u = (long)w * g.total / g.G;
+  const long end = (long)(w + 1) * g.total / g.G;
+  int idx = 0;
+  bool first = true;
+  while (u < end) {
+    const SKSeg sgm = sk_locate(g, u, end, idx);
+    const WgradParams& p = g.p[sgm.idx];
+    const int gx = g.gx[sgm.idx];
+    if (!first) __syncthreads();
+    const int ke = sgm.k1 * BK;
+    wgrad_body<BM, BN, WM, WN>(p, sgm.tile % gx, sgm.tile / gx, sgm.k0 * BK, ke < p.K ? ke : p.K, sk_out(g, p, sgm, g.T[sgm.idx], w, BM * BN));
+    first = false;
+    u += sgm.k1 - sgm.k0;
+  }
+}
+
+// grid (G - 1 boundaries, chunks of 1024 tile elements).  Block (b, c) acts iff the boundary between workgroups b and b+1 is
+// the LAST one inside some tile; it then sums that tile's partials in workgroup order for its chunk of the tile image.
+// TAPS = 9: tile image [64][9][64] (+64 bias sums); TAPS = 1: [BM][BN] of one tap (+BM bias sums).
+template <int BM, int BN, int TAPS>
+__global__ __launch_bounds__(256) void wgrad_sk_fixup_kernel(const SKGroup g) {
+  constexpr int TILE = BM * TAPS * BN;
+  const int b = blockIdx.x;
+  const long ub = (long)(b + 1) * g.total / g.G;   // first K-unit of workgroup b+1
+  int idx = 0;
+  while (ub >= g.unit_end[idx]) ++idx;
+  const long base = idx ? g.unit_end[idx - 1] : 0;
+  const int T = g.T[idx];
+  const int tile = (int)((ub - base) / T);
+  const long ts = base + (long)tile * T, te = ts + T;
+  if (ub == ts) return;                                   // the boundary sits on a tile edge
+  if ((long)(b + 2) * g.total / g.G < te) return;         // a later boundary is still inside this tile: that block sums it
+  long wf = ts * g.G / g.total;                           // first workgroup of the tile: the largest w with w*U/G <= ts
+  while ((wf + 1) * g.total / g.G <= ts) ++wf;
+  while (wf * g.total / g.G > ts) --wf;
+  const WgradParams& p = g.p[idx];
+  const int gx = g.gx[idx];
+  const int bx = tile % gx, by = tile / gx;
+  const int e = (blockIdx.y * 256 + threadIdx.x) * 4;     // element of the tile image (+ bias tail)
+  if (e >= TILE + BM) return;
+  const bool is_bias = e >= TILE;
+  if (is_bias && !(p.bias_partial && bx == 0)) return;
+  f32x4 s = *reinterpret_cast<const f32x4*>(g.slots + ((size_t)wf * 2 + 1) * g.slot_floats + e);
+  for (long w = wf + 1; w <= b + 1; ++w) s += *reinterpret_cast<const f32x4*>(g.slots + (size_t)w * 2 * g.slot_floats + e);
+  const int co0 = by * BM;
+  if (is_bias) {
+    const int c = e - TILE;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (co0 + c + q < p.Cout) { float* dst = p.bias_partial + co0 + c + q; *dst = (p.rmw ? *dst : 0.f) + s[q]; }
+    return;
+  }
+  int col, tap, cil, ci0, T9;
+  if (TAPS == 9) { col = e / (9 * BN); const int r = e - col * 9 * BN; tap = r / BN; cil = r - tap * BN; ci0 = bx * BN; T9 = 9; }
+  else { col = e / BN; cil = e - col * BN; tap = bx / p.nci; ci0 = (bx - tap * p.nci) * BN; T9 = p.ks * p.ks; }
+  const int co = co0 + col, ci = ci0 + cil;
+  if (co >= p.Cout || ci >= p.Cin) return;                // (Cin % 4 == 0 on this path: a float4 is inside or outside as a whole)
+  f32x4* dst = reinterpret_cast<f32x4*>(p.partial + ((size_t)co * T9 + tap) * p.Cin + ci);
+  *dst = p.rmw ? *dst + s : s;
 }
 
 // out[i] (+)= sum_k partial[k][i], fixed order: 4 interleaved groups (k mod 4) summed ascending, then ((g0+g1)+(g2+g3)).
@@ -713,6 +863,126 @@ int flush(Pending* pend, int& n, hipStream_t st) {
   return 0;
 }
 
+// ---- stream-K launches ---------------------------------------------------------------------------
+constexpr int kSKMaxG = 512;
+constexpr size_t sk_slot_floats(int tile_floats, int bm) { return (size_t)((tile_floats + bm + 255) / 256 * 256); }
+// workspace regions, one per kernel family (they run back to back, their fix-ups afterwards)
+constexpr size_t kSKRegion[7] = {
+    (size_t)kSKMaxG * 2 * sk_slot_floats(128 * 128, 128), (size_t)kSKMaxG * 2 * sk_slot_floats(128 * 64, 128),
+    (size_t)kSKMaxG * 2 * sk_slot_floats(64 * 128, 64),   (size_t)kSKMaxG * 2 * sk_slot_floats(64 * 64, 64),
+    (size_t)kSKMaxG * 2 * sk_slot_floats(64 * 9 * 64, 64), (size_t)kSKMaxG * 2 * sk_slot_floats(64 * 9 * 64, 64),
+    (size_t)kSKMaxG * 2 * sk_slot_floats(64 * 9 * 64, 64)};
+constexpr size_t sk_total_floats() { size_t t = 0; for (int i = 0; i < 7; ++i) t += kSKRegion[i]; return t; }
+
+// fills the group of one family; returns false when no problem of the family is pending
+template <typename Pred, typename Geo>
+bool sk_collect(const Pending* pend, int n, SKGroup& g, float* region, int slot_floats, Pred pred, Geo geo) {
+  g.count = 0; g.total = 0; g.slots = region; g.slot_floats = slot_floats;
+  for (int i = 0; i < n; ++i) {
+    const Pending& e = pend[i];
+    if (e.pl.small || !pred(e)) continue;
+    int gx, gy, T;
+    geo(e, gx, gy, T);
+    g.gx[g.count] = gx; g.gy[g.count] = gy; g.T[g.count] = T;
+    g.total += (long)gx * gy * T;
+    g.unit_end[g.count] = g.total;
+    g.p[g.count] = e.p;
+    g.p[g.count].partial = e.d->dw;                 // full tiles and the fix-up write the gradient itself
+    g.p[g.count].bias_partial = e.d->dbias;
+    g.p[g.count].rmw = e.d->accumulate;
+    ++g.count;
+  }
+  if (g.count == 0) return false;
+  long G = g.total / 2;                             // at least two K-units per workgroup
+  g.G = (int)(G < 1 ? 1 : (G > kSKMaxG ? kSKMaxG : G));
+  return true;
+}
+
+template <int BM, int BN>
+int launch_variant_sk(const Pending* pend, int n, float* region, hipStream_t st) {
+  static SKGroup g;   // (host staging of the kernel argument; launches are issued by one host thread per process)
+  constexpr int slot = (int)sk_slot_floats(BM * BN, BM);
+  if (!sk_collect(pend, n, g, region, slot, [](const Pending& e) { return !e.pl.taps && e.pl.bm == BM && e.pl.bn == BN; },
+                  [](const Pending& e, int& gx, int& gy, int& T) {
+                    gx = e.pl.nci * e.d->ks * e.d->ks; gy = (e.d->Cout + BM - 1) / BM; T = (e.p.K + BK - 1) / BK;
+                  })) return 0;
+  const size_t lds = (size_t)2 * BK * (BM + BN) * sizeof(float);
+  hipLaunchKernelGGL((conv_wgrad_sk_kernel<BM, BN, 2, 2>), dim3(g.G), dim3(256), lds, st, g);
+  CLC_LAUNCH_CHECK();
+  if (g.G > 1) {
+    hipLaunchKernelGGL((wgrad_sk_fixup_kernel<BM, BN, 1>), dim3(g.G - 1, (BM * BN + BM + 1023) / 1024), dim3(256), 0, st, g);
+    CLC_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+template <int TW>
+int launch_taps_sk(const Pending* pend, int n, float* region, hipStream_t st) {
+  static SKGroup g;
+  constexpr int slot = (int)sk_slot_floats(64 * 9 * 64, 64);
+  if (!sk_collect(pend, n, g, region, slot, [](const Pending& e) { return e.pl.taps == TW; },
+                  [](const Pending& e, int& gx, int& gy, int& T) { gx = e.pl.nci; gy = (e.d->Cout + 63) / 64; T = e.p.K >> 5; })) return 0;
+  constexpr int XP = (32 / TW + 2) * (TW + 2);
+  const size_t lds = (size_t)2 * (32 * 64 + XP * 64) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_taps_sk_kernel<TW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_wgrad_taps_sk_kernel<TW>), dim3(g.G), dim3(256), lds, st, g);
+  CLC_LAUNCH_CHECK();
+  if (g.G > 1) {
+    hipLaunchKernelGGL((wgrad_sk_fixup_kernel<64, 64, 9>), dim3(g.G - 1, (64 * 9 * 64 + 64 + 1023) / 1024), dim3(256), 0, st, g);
+    CLC_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// stream-K flush: the RGB-head problems keep the split form (their own workspaces), everything else one grid per family
+int flush_sk(Pending* pend, int& n, float* ws, hipStream_t st) {
+  if (n == 0) return 0;
+  SlabGroup sg;
+  sg.count = 0;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i)
+    if (pend[i].pl.small) {
+      const Pending& e = pend[i];
+      hipLaunchKernelGGL(wgrad_small_kernel, dim3(e.pl.splits, (e.d->Cout + 127) / 128), dim3(256), 0, st, e.p, e.pl.splits);
+      CLC_LAUNCH_CHECK();
+      if (e.pl.splits == 1) continue;
+      const long wsz = (long)e.d->Cout * e.d->ks * e.d->ks * e.d->Cin;
+      blocks += (int)((wsz + 255) / 256);
+      sg.e[sg.count] = SlabSet{e.p.partial, e.d->dw, wsz, e.pl.splits, e.d->accumulate};
+      sg.blk_end[sg.count++] = blocks;
+      if (e.d->dbias) {
+        blocks += (e.d->Cout + 255) / 256;
+        sg.e[sg.count] = SlabSet{e.p.bias_partial, e.d->dbias, (long)e.d->Cout, e.pl.splits, e.d->accumulate};
+        sg.blk_end[sg.count++] = blocks;
+      }
+    }
+  if (sg.count) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, sg);
+    CLC_LAUNCH_CHECK();
+  }
+  int rc;
+  float* r = ws;
+  if ((rc = launch_variant_sk<128, 128>(pend, n, r, st)) < 0) return rc;
+  r += kSKRegion[0];
+  if ((rc = launch_variant_sk<128, 64>(pend, n, r, st)) < 0) return rc;
+  r += kSKRegion[1];
+  if ((rc = launch_variant_sk<64, 128>(pend, n, r, st)) < 0) return rc;
+  r += kSKRegion[2];
+  if ((rc = launch_variant_sk<64, 64>(pend, n, r, st)) < 0) return rc;
+  r += kSKRegion[3];
+  if ((rc = launch_taps_sk<32>(pend, n, r, st)) < 0) return rc;
+  r += kSKRegion[4];
+  if ((rc = launch_taps_sk<16>(pend, n, r, st)) < 0) return rc;
+  r += kSKRegion[5];
+  if ((rc = launch_taps_sk<8>(pend, n, r, st)) < 0) return rc;
+  n = 0;
+  return 0;
+}
+
 int variant_id(const Plan& pl) { return pl.small ? 1 : (pl.taps ? 64900 + pl.taps : pl.bm * 1000 + pl.bn); }
 
 }  // namespace
@@ -743,4 +1013,28 @@ extern "C" int clc_conv2d_wgrad_batched(const clc_wgrad_desc* descs, int count, 
     ++n;
   }
   return flush(pend, n, (hipStream_t)stream);
+}
+
+extern "C" size_t clc_conv2d_wgrad_group_workspace_bytes(void) { return sk_total_floats() * sizeof(float); }
+
+extern "C" int clc_conv2d_wgrad_batched_sk(const clc_wgrad_desc* descs, int count, void* group_workspace, size_t group_workspace_bytes,
+                                          clc_stream_t stream) {
+  CLC_CHECK(descs && count >= 0, "clc_conv2d_wgrad_batched_sk: bad arguments");
+  CLC_CHECK(group_workspace && group_workspace_bytes >= clc_conv2d_wgrad_group_workspace_bytes() && aligned16(group_workspace),
+            "clc_conv2d_wgrad_batched_sk: group workspace too small / unaligned");
+  if (!clc_tuning[CLC_TUNE_WGRAD_STREAMK]) return clc_conv2d_wgrad_batched(descs, count, stream);
+  Pending pend[kMaxGroup];
+  int n = 0, rc;
+  for (int i = 0; i < count; ++i) {
+    const clc_wgrad_desc* d = descs + i;
+    // two problems that write the same gradient buffer (a filter applied twice) must not share a launch
+    bool clash = n == kMaxGroup;
+    for (int j = 0; j < n && !clash; ++j)
+      clash = pend[j].d->dw == d->dw || (d->dbias && pend[j].d->dbias == d->dbias) || pend[j].d->workspace == d->workspace;
+    if (clash && (rc = flush_sk(pend, n, (float*)group_workspace, (hipStream_t)stream)) < 0) return rc;
+    pend[n].d = d;
+    if ((rc = prepare(d, pend[n].pl, pend[n].p)) < 0) return rc;
+    ++n;
+  }
+  return flush_sk(pend, n, (float*)group_workspace, (hipStream_t)stream);
 }

@@ -62,10 +62,13 @@ _pp = C.POINTER(fp)
 SIGNATURES = {
     "clc_last_error": (C.c_char_p, []),
     "clc_version": (_i, []),
+    "clc_set_tuning": (_i, [_i, _i]),
     "clc_conv2d": (_i, [C.POINTER(ConvDesc), fp]),
     "clc_conv2d_wgrad_workspace_bytes": (_sz, [C.POINTER(WgradDesc)]),
     "clc_conv2d_wgrad": (_i, [C.POINTER(WgradDesc), fp]),
     "clc_conv2d_wgrad_batched": (_i, [C.POINTER(WgradDesc), _i, fp]),
+    "clc_conv2d_wgrad_group_workspace_bytes": (_sz, []),
+    "clc_conv2d_wgrad_batched_sk": (_i, [C.POINTER(WgradDesc), _i, fp, _sz, fp]),
     "clc_filter_transpose": (_i, [fp, fp, _i, _i, _i, fp]),
     "clc_filter_transpose_batched": (_i, [fp, _i, _i, fp]),
     "clc_partial_reduce_batched": (_i, [C.POINTER(ReduceEntry), _i, fp]),
@@ -156,6 +159,10 @@ def load():
         fn = getattr(L, name)  # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    # CLC_TUNING="key:value,..." -> clc_set_tuning (A/B switches between kernel variants that compute the same results)
+    for item in filter(None, os.environ.get("CLC_TUNING", "").split(",")):
+        k, v = item.split(":")
+        L.clc_set_tuning(int(k), int(v))
     _lib = L
     return L
 

@@ -53,6 +53,24 @@ _PENDING_STREAMS = {}   # streams that queued a problem since the last flush (th
 _PENDING_POST = []      # callables run right after the grouped launch, on its stream (consumers of deferred temporaries)
 
 
+_GROUP_WS = {}   # stream id -> persistent partial-tile workspace of the stream-K grouped filter-gradient launches
+
+
+def _group_ws():
+    """(ptr, bytes) of this stream's stream-K workspace (launches on one stream are ordered, so one buffer serves them all)."""
+    key = (torch.cuda.current_device(), _stream())
+    ws = _GROUP_WS.get(key)
+    if ws is None:
+        nbytes = _L().clc_conv2d_wgrad_group_workspace_bytes()
+        ws = _GROUP_WS[key] = torch.empty((nbytes + 3) // 4, device="cuda", dtype=torch.float32)
+    return ws.data_ptr(), ws.numel() * 4
+
+
+def _launch_wgrad_group(arr, n):
+    wp, wb = _group_ws()
+    _lib.check(_L().clc_conv2d_wgrad_batched_sk(arr, n, wp, wb, _stream()), "clc_conv2d_wgrad_batched_sk")
+
+
 def flush_wgrads():
     if not _PENDING:
         return
@@ -65,11 +83,11 @@ def flush_wgrads():
     _PENDING_STREAMS.clear()
     with torch.cuda.stream(target):
         if PROFILE is None:
-            _lib.check(_L().clc_conv2d_wgrad_batched(arr, len(_PENDING), _stream()), "clc_conv2d_wgrad_batched")
+            _launch_wgrad_group(arr, len(_PENDING))
         else:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            _lib.check(_L().clc_conv2d_wgrad_batched(arr, len(_PENDING), _stream()), "clc_conv2d_wgrad_batched")
+            _launch_wgrad_group(arr, len(_PENDING))
             e1.record()
             PROFILE.append(("conv_wgrad_grouped", 0, _PENDING_FLOP[0], e0, e1, f"{len(_PENDING)} problems"))
         for fn in _PENDING_POST:
@@ -365,7 +383,7 @@ def wgrad_batched(problems):
     for kw in problems:
         queued.append(wgrad_raw(**kw, _collect=True))
     arr = (_lib.WgradDesc * len(queued))(*[d for d, _ in queued])
-    _lib.check(_L().clc_conv2d_wgrad_batched(arr, len(queued), _stream()), "clc_conv2d_wgrad_batched")
+    _launch_wgrad_group(arr, len(queued))
     return [k for _, k in queued]   # operands / workspaces: keep until the stream has run the launches
 
 

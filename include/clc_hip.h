@@ -36,6 +36,9 @@ typedef void* clc_stream_t; /* hipStream_t */
 
 const char* clc_last_error(void);
 int clc_version(void);
+/* A/B switch between kernel variants that compute the same bits (key 0: K-loop timing of the LDS-DMA convolution, 1 or 2;
+ * key 1: stream-K filter gradients, 0 or 1); returns the previous value.  Benchmark tooling only. */
+int clc_set_tuning(int key, int value);
 
 /* ---- activation / epilogue codes ---------------------------------------------------- */
 enum { CLC_ACT_NONE = 0, CLC_ACT_LRELU = 1, CLC_ACT_RELU = 2, CLC_ACT_GELU = 3, CLC_ACT_HALFTANH = 4 /* 0.5*tanh(v), LRP head */,
@@ -116,6 +119,14 @@ int clc_conv2d_wgrad(const clc_wgrad_desc* d, clc_stream_t stream);
  * the same dw / dbias (a filter applied twice, e.g. the reference encoder over several reference frames) are kept in
  * separate launches, in order. */
 int clc_conv2d_wgrad_batched(const clc_wgrad_desc* descs, int count, clc_stream_t stream);
+/* Stream-K form of the grouped launch: ONE grid of <= 512 workgroups per tile shape walks the K-units of all problems laid end
+ * to end; a workgroup accumulates in registers while it stays inside an output tile and leaves at most two partial tile
+ * images in `group_workspace` (clc_conv2d_wgrad_group_workspace_bytes(), caller-owned, reusable across calls on one stream),
+ * which a fix-up launch adds in workgroup order.  Same results as clc_conv2d_wgrad_batched up to summation order; run-to-run
+ * reproducible (the ranges depend only on the group's shapes). */
+size_t clc_conv2d_wgrad_group_workspace_bytes(void);
+int clc_conv2d_wgrad_batched_sk(const clc_wgrad_desc* descs, int count, void* group_workspace, size_t group_workspace_bytes,
+                                clc_stream_t stream);
 
 /* [Cout][T][Cin] -> [Cin][T][Cout]  (T = ks*ks) */
 int clc_filter_transpose(const float* w, float* wt, int Cout, int T, int Cin, clc_stream_t stream);

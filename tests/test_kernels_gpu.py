@@ -92,16 +92,36 @@ def test_wgrad_batched_matches_single_launches(dev):
                 out.append((torch.full((n,), 0.25, device=dev), torch.full((kw["Cout"],), -0.5, device=dev)))
         return out
 
+    from clc_amd import lib as _lib
+
     single = buffers()
     for kw, (dw, db) in zip(probs, single):
         ops.wgrad_raw(**kw, dw_out=dw, db_out=db)
-    batched = buffers()
-    keep = ops.wgrad_batched([dict(kw, dw_out=dw, db_out=db) for kw, (dw, db) in zip(probs, batched)])
-    torch.cuda.synchronize()
-    del keep
+
+    def run_batched():
+        out = buffers()
+        keep = ops.wgrad_batched([dict(kw, dw_out=dw, db_out=db) for kw, (dw, db) in zip(probs, out)])
+        torch.cuda.synchronize()
+        del keep
+        return out
+
+    # (a) split-K grouped form (tuning key 1 = 0): the same launches as the single calls, bit for bit
+    prev = _lib.load().clc_set_tuning(1, 0)
+    try:
+        batched = run_batched()
+    finally:
+        _lib.load().clc_set_tuning(1, prev)
     for i, ((dw1, db1), (dw2, db2)) in enumerate(zip(single, batched)):
         assert torch.equal(dw1, dw2), f"problem {i}: dW differs"
         assert torch.equal(db1, db2), f"problem {i}: dbias differs"
+    # (b) stream-K grouped form (default): another split of the K range -> equal up to fp32 summation order, and run-to-run
+    #     reproducible bit for bit (the ranges are a function of the group's shapes only)
+    sk1, sk2 = run_batched(), run_batched()
+    for i, ((dw1, db1), (dw2, db2), (dw3, db3)) in enumerate(zip(single, sk1, sk2)):
+        assert torch.equal(dw2, dw3) and torch.equal(db2, db3), f"problem {i}: stream-K result is not reproducible"
+        _close(dw2, dw1, 1e-5, f"problem {i}: stream-K dW vs split-K")
+        _close(db2, db1, 1e-5, f"problem {i}: stream-K dbias vs split-K")
+    batched = sk1
     # and against the fp32 reference for one grouped problem
     kw = probs[0]
     wref = torch.zeros(64, 64, 3, 3, requires_grad=True)

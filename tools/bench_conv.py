@@ -50,7 +50,13 @@ for name, N, Cin, H, W, Cout, ks, s in SHAPES:
     def dgrad(): ops.conv_raw(dy, wt.view(Cin, -1), None, ks=ks, stride=s, pad=ks // 2, transposed=True, out_hw=(H, W))
     def wgrad(): ops.wgrad_raw(x, dy, ks=ks, stride=s, pad=ks // 2, Cout=Cout, Cin=Cin, want_bias=True)
     res = []
-    for fn in (fwd, dgrad, wgrad):
+    from clc_amd import lib as _lib
+    variants = [(fwd, "fwd", 2), (dgrad, "dgrad", 2), (wgrad, "wgrad", None)]
+    if os.environ.get("AB", "0") == "1":   # A/B of the DMA K-loop variants in ONE process (tuning key 0)
+        variants = [(fwd, "fwd.v1", 1), (fwd, "fwd.v2", 2), (dgrad, "dgrad.v1", 1), (dgrad, "dgrad.v2", 2), (wgrad, "wgrad", None)]
+    for fn, label, tune in variants:
+        if tune is not None:
+            _lib.load().clc_set_tuning(0, tune)
         for _ in range(3): fn()
         torch.cuda.synchronize()
         # capture the launches in a hipGraph so the number is GPU time, not Python/ctypes launch overhead
@@ -63,5 +69,5 @@ for name, N, Cin, H, W, Cout, ks, s in SHAPES:
         g_.replay()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / reps * 1e3
-        res.append(f"{fn.__name__} {us:8.1f} us {flops / us / 1e6:6.1f} TF")
+        res.append(f"{label} {us:8.1f} us {flops / us / 1e6:6.1f} TF")
     print(f"{name:20s} {flops/1e9:7.2f} GF | " + " | ".join(res), flush=True)
