@@ -58,6 +58,7 @@ struct ConvParams {
   const float* w2; const float* bias2; int group_rows;   // rows >= group_rows (second half of the batch) use w2 / bias2
   int pre_deriv;               // y_pre <- act'(v) instead of v
   const float* res_gate; int ldg, rg_act, rg_pre;   // residual term *= act'(res_gate)
+  int dma_place;               // conv_igemm_dma2_kernel: 1 = next tile's DMA pieces at the top of the iteration, 0 = between the MFMA groups
 };
 
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
@@ -635,12 +636,16 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
     const int buf = it & 1;
     advance();
     set_fetch(it + 1 < total);
+    // Where the next tile's DMA pieces are issued (block-uniform): at the top they have the whole iteration to land — what
+    // counts inside the training step, where operands come from HBM / Infinity Cache; between the MFMA groups their address
+    // VALU hides in the MFMA shadow — faster only when the operands are L2-resident (single-layer micro-benchmark).
+    if (p.dma_place) { dma_a(buf ^ 1); dma_b(buf ^ 1); }
     read_frag(buf, 1, af[1], bf[1]);
     mfma_group(af[0], bf[0]);
-    dma_a(buf ^ 1);
+    if (!p.dma_place) dma_a(buf ^ 1);
     read_frag(buf, 2, af[0], bf[0]);
     mfma_group(af[1], bf[1]);
-    dma_b(buf ^ 1);
+    if (!p.dma_place) dma_b(buf ^ 1);
     read_frag(buf, 3, af[1], bf[1]);
     mfma_group(af[0], bf[0]);
     mfma_group(af[1], bf[1]);
@@ -1016,6 +1021,7 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   p.M = d->N * d->OH * d->OW;
   if (d->transposed && d->stride == 2) { classes = 4; p.M = d->N * (d->OH / 2) * (d->OW / 2); }
   p.w2 = d->w2; p.bias2 = d->bias2; p.group_rows = 0; p.pre_deriv = d->pre_deriv;
+  p.dma_place = clc_tuning[CLC_TUNE_DMA_PLACE];
   p.res_gate = d->res ? d->res_gate : nullptr; p.ldg = d->ldg; p.rg_act = d->res_gate_act; p.rg_pre = d->res_gate_pre;
   if (d->w2) {   // second half of the batch on a second filter set; rows are image-major, so the halves split at M/2
     CLC_CHECK(d->N % 2 == 0, "clc_conv2d: w2 needs an even batch (got N=%d)", d->N);

@@ -42,7 +42,7 @@ struct WgradParams {
 struct OutSpec { float* w; float* b; int mode; };
 
 template <int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, const int by, const int k_begin, const int k_end, const OutSpec o) {
+__device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, const int by, const int k_begin, const int k_end, const OutSpec o, const int tid) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_P = (BK * BM / 4 + NT - 1) / NT, B_P = (BK * BN / 4 + NT - 1) / NT;
@@ -51,7 +51,7 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
   float* As = smem;                 // [2][BK][BM]
   float* Bs = smem + 2 * BK * BM;   // [2][BK][BN]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int tap = bx / p.nci, ci0 = (bx % p.nci) * BN;
   const int kh = tap / p.ks, kw = tap - kh * p.ks;
@@ -201,7 +201,7 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
 // 64 co x (9 taps x 64 ci) outputs per workgroup, wave (wm, wn) = 32 co x 32 ci x 9 taps = 9 MFMA blocks (144 acc
 // registers), 10 ds_read_b32 per 9 MFMAs.  Same slab layout / fixed-order reduce as above.
 template <int TW>
-__device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int bx, const int by, const int t_begin, const int t_end, const OutSpec o) {
+__device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int bx, const int by, const int t_begin, const int t_end, const OutSpec o, const int tid) {
   constexpr int TH = 32 / TW, XW = TW + 2, XH = TH + 2, XP = XH * XW;
   constexpr int LTW = TW == 32 ? 5 : (TW == 16 ? 4 : 3);
   constexpr int X_P = (XP * 16 + 255) / 256;
@@ -209,7 +209,7 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int 
   float* As = smem;                  // [2][32][64]   dY tile, [k][co]
   float* Xs = smem + 2 * 32 * 64;    // [2][XP][64]   input window, [pixel][ci]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int ci0 = bx * 64, co0 = by * 64;
   const int ntiles = t_end - t_begin;
@@ -344,14 +344,14 @@ __device__ __forceinline__ int taps_range_end(const WgradParams& p, int split) {
 template <int TW>
 __global__ __launch_bounds__(256, 2)
 void conv_wgrad_taps_kernel(const WgradParams p) {
-  wgrad_taps_body<TW>(p, blockIdx.x, blockIdx.y, taps_range_begin(p, blockIdx.z), taps_range_end(p, blockIdx.z), split_out(p, blockIdx.z));
+  wgrad_taps_body<TW>(p, blockIdx.x, blockIdx.y, taps_range_begin(p, blockIdx.z), taps_range_end(p, blockIdx.z), split_out(p, blockIdx.z), threadIdx.x);
 }
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN, 2)
 void conv_wgrad_kernel(const WgradParams p) {
   const int kb = blockIdx.z * p.k_per_split;
-  wgrad_body<BM, BN, WM, WN>(p, blockIdx.x, blockIdx.y, kb, min(p.K, kb + p.k_per_split), split_out(p, blockIdx.z));
+  wgrad_body<BM, BN, WM, WN>(p, blockIdx.x, blockIdx.y, kb, min(p.K, kb + p.k_per_split), split_out(p, blockIdx.z), threadIdx.x);
 }
 
 // Grouped launch: up to kMaxGroup independent filter-gradient problems of one tile shape in ONE grid (descriptors in the
@@ -376,7 +376,7 @@ void conv_wgrad_grouped_kernel(const WgradGroup g) {
   const int bx = l % gx, t = l / gx;
   const WgradParams& p = g.p[idx];
   const int kb = (t / gy) * p.k_per_split;
-  wgrad_body<BM, BN, WM, WN>(p, bx, t % gy, kb, min(p.K, kb + p.k_per_split), split_out(p, t / gy));
+  wgrad_body<BM, BN, WM, WN>(p, bx, t % gy, kb, min(p.K, kb + p.k_per_split), split_out(p, t / gy), threadIdx.x);
 }
 
 template <int TW>
@@ -389,7 +389,7 @@ void conv_wgrad_taps_grouped_kernel(const WgradGroup g) {
   const int gx = g.gx[idx], gy = g.gy[idx];
   const int bx = l % gx, t = l / gx;
   const WgradParams& p = g.p[idx];
-  wgrad_taps_body<TW>(p, bx, t % gy, taps_range_begin(p, t / gy), taps_range_end(p, t / gy), split_out(p, t / gy));
+  wgrad_taps_body<TW>(p, bx, t % gy, taps_range_begin(p, t / gy), taps_range_end(p, t / gy), split_out(p, t / gy), threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -410,12 +410,28 @@ struct SKGroup {
   int T[kMaxGroup];              // K-units per tile
   int gx[kMaxGroup], gy[kMaxGroup];
   float* slots;                  // [G][2][slot_floats]
+  int* plan;                     // [G][4]: {problem, tile, first workgroup of the tile, 1} when workgroup w contributes a tile's LAST partial, else zeros
   WgradParams p[kMaxGroup];      // partial = the gradient itself, bias_partial = the bias gradient (or null), rmw = accumulate
 };
 
 struct SKSeg { int idx, tile, k0, k1; };
+// threadIdx.x behind an opaque move: the per-thread index arithmetic of a tile body then cannot be hoisted out of the segment
+// loop, where it would stay live in VGPRs across the whole K loop of every segment (measured: +50..120 VGPRs, spills)
+__device__ __forceinline__ int sk_tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+__device__ __forceinline__ int sk_find(const SKGroup& g, long u, int lo) {   // smallest idx >= lo with u < unit_end[idx]
+  int hi = g.count - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (u >= g.unit_end[mid]) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
 __device__ __forceinline__ SKSeg sk_locate(const SKGroup& g, long u, long end, int& idx) {
-  while (u >= g.unit_end[idx]) ++idx;
+  idx = sk_find(g, u, idx);
   const long base = idx ? g.unit_end[idx - 1] : 0;
   const int T = g.T[idx];
   const long local = u - base;
@@ -427,6 +443,23 @@ __device__ __forceinline__ SKSeg sk_locate(const SKGroup& g, long u, long end, i
   sgm.k1 = k1 < T ? (int)k1 : T;
   return sgm;
 }
+// workgroup w's plan entry: its first segment continues a tile (k0 > 0) and ends it (k1 == T) -> w is the tile's last contributor
+__device__ __forceinline__ void sk_write_plan(const SKGroup& g, int w, long u0, long end) {
+  if (threadIdx.x != 0) return;
+  int idx = 0;
+  const SKSeg sgm = sk_locate(g, u0, end, idx);
+  int e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+  if (sgm.k0 > 0 && sgm.k1 == g.T[sgm.idx]) {
+    const long ts = u0 - sgm.k0;                         // first K-unit of the tile
+    long wf = ts * g.G / g.total;                        // its first workgroup: the largest w' with w' * U / G <= ts
+    while ((wf + 1) * g.total / g.G <= ts) ++wf;
+    while (wf * g.total / g.G > ts) --wf;
+    e0 = sgm.idx; e1 = sgm.tile; e2 = (int)wf; e3 = 1;
+  }
+  int* dst = g.plan + 4 * w;
+  dst[0] = e0; dst[1] = e1; dst[2] = e2; dst[3] = e3;
+}
+
 __device__ __forceinline__ OutSpec sk_out(const SKGroup& g, const WgradParams& p, const SKSeg& sgm, int T, int w, int tile_floats) {
   OutSpec o;
   if (sgm.k0 == 0 && sgm.k1 == T) {
@@ -444,82 +477,122 @@ void conv_wgrad_taps_sk_kernel(const SKGroup g) {
   const int w = blockIdx.x;
   long u = (long)w * g.total / g.G;
   const long end = (long)(w + 1) * g.total / g.G;
+  sk_write_plan(g, w, u, end);
   int idx = 0;
   bool first = true;
+#pragma clang loop unroll(disable)
   while (u < end) {
     const SKSeg sgm = sk_locate(g, u, end, idx);
     const WgradParams& p = g.p[sgm.idx];
     const int gx = g.gx[sgm.idx];
     if (!first) __syncthreads();   // the previous segment's LDS tiles / bias reduction are done with
-    wgrad_taps_body<TW>(p, sgm.tile % gx, sgm.tile / gx, sgm.k0, sgm.k1, sk_out(g, p, sgm, g.T[sgm.idx], w, 64 * 9 * 64));
+    wgrad_taps_body<TW>(p, sgm.tile % gx, sgm.tile / gx, sgm.k0, sgm.k1, sk_out(g, p, sgm, g.T[sgm.idx], w, 64 * 9 * 64), sk_tid());
     first = false;
     u += sgm.k1 - sgm.k0;
   }
 }
 
+// resident workgroups per CU the register / LDS budget of each tile shape allows (= the split-K kernels' occupancy)
+constexpr int sk_wg_per_cu(int bm, int bn) { return bm * bn >= 128 * 128 ? 2 : (bm * bn >= 128 * 64 ? 3 : 5); }
+
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, 2)
+__global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 128 * 128 ? 2 : (BM * BN >= 128 * 64 ? 4 : 6)))
 void conv_wgrad_sk_kernel(const SKGroup g) {
   const int w = blockIdx.x;
   long u = (long)w * g.total / g.G;
   const long end = (long)(w + 1) * g.total / g.G;
+  sk_write_plan(g, w, u, end);
   int idx = 0;
   bool first = true;
+#pragma clang loop unroll(disable)
   while (u < end) {
     const SKSeg sgm = sk_locate(g, u, end, idx);
     const WgradParams& p = g.p[sgm.idx];
     const int gx = g.gx[sgm.idx];
     if (!first) __syncthreads();
     const int ke = sgm.k1 * BK;
-    wgrad_body<BM, BN, WM, WN>(p, sgm.tile % gx, sgm.tile / gx, sgm.k0 * BK, ke < p.K ? ke : p.K, sk_out(g, p, sgm, g.T[sgm.idx], w, BM * BN));
+    wgrad_body<BM, BN, WM, WN>(p, sgm.tile % gx, sgm.tile / gx, sgm.k0 * BK, ke < p.K ? ke : p.K, sk_out(g, p, sgm, g.T[sgm.idx], w, BM * BN), sk_tid());
     first = false;
     u += sgm.k1 - sgm.k0;
   }
 }
 
-// grid (G - 1 boundaries, chunks of 1024 tile elements).  Block (b, c) acts iff the boundary between workgroups b and b+1 is
-// the LAST one inside some tile; it then sums that tile's partials in workgroup order for its chunk of the tile image.
+// Fix-up: adds the partials of every split tile in workgroup order.  grid (256-element chunks of the tile image, kFixY).
+// wgrad_sk_compact_kernel first packs the plan (one entry per workgroup, written by the stream-K kernel) into a list of the
+// split tiles' last contributors, in workgroup order; block (x, y) of the fix-up takes list entries y, y + kFixY, ...
+// Per entry the block is 64 float4 columns x 4 groups: group q sums partials q, q+4, ... (4 loads in flight), the groups are
+// combined as (g0+g1)+(g2+g3): a fixed order -> run-to-run reproducible.
 // TAPS = 9: tile image [64][9][64] (+64 bias sums); TAPS = 1: [BM][BN] of one tap (+BM bias sums).
+constexpr int kFixY = 64;
+// one block: the plan's live entries (last-contributor workgroups), ascending, into list[1..], their count into list[0]
+__global__ __launch_bounds__(1024) void wgrad_sk_compact_kernel(const int* __restrict__ plan, int G, int* __restrict__ list) {
+  __shared__ int wave_cnt[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int n_list = 0;
+  for (int base = 0; base < G; base += 1024) {
+    const int w = base + tid;
+    const bool on = w < G && plan[4 * w + 3] != 0;
+    const unsigned long long m = __ballot(on);
+    if (lane == 0) wave_cnt[wv] = __popcll(m);
+    __syncthreads();
+    int off = n_list, tot = 0;
+    for (int q = 0; q < 16; ++q) { if (q < wv) off += wave_cnt[q]; tot += wave_cnt[q]; }
+    if (on) list[1 + off + __popcll(m & ((1ull << lane) - 1ull))] = w;
+    n_list += tot;
+    __syncthreads();
+  }
+  if (tid == 0) list[0] = n_list;
+}
+
 template <int BM, int BN, int TAPS>
 __global__ __launch_bounds__(256) void wgrad_sk_fixup_kernel(const SKGroup g) {
   constexpr int TILE = BM * TAPS * BN;
-  const int b = blockIdx.x;
-  const long ub = (long)(b + 1) * g.total / g.G;   // first K-unit of workgroup b+1
-  int idx = 0;
-  while (ub >= g.unit_end[idx]) ++idx;
-  const long base = idx ? g.unit_end[idx - 1] : 0;
-  const int T = g.T[idx];
-  const int tile = (int)((ub - base) / T);
-  const long ts = base + (long)tile * T, te = ts + T;
-  if (ub == ts) return;                                   // the boundary sits on a tile edge
-  if ((long)(b + 2) * g.total / g.G < te) return;         // a later boundary is still inside this tile: that block sums it
-  long wf = ts * g.G / g.total;                           // first workgroup of the tile: the largest w with w*U/G <= ts
-  while ((wf + 1) * g.total / g.G <= ts) ++wf;
-  while (wf * g.total / g.G > ts) --wf;
-  const WgradParams& p = g.p[idx];
-  const int gx = g.gx[idx];
-  const int bx = tile % gx, by = tile / gx;
-  const int e = (blockIdx.y * 256 + threadIdx.x) * 4;     // element of the tile image (+ bias tail)
-  if (e >= TILE + BM) return;
-  const bool is_bias = e >= TILE;
-  if (is_bias && !(p.bias_partial && bx == 0)) return;
-  f32x4 s = *reinterpret_cast<const f32x4*>(g.slots + ((size_t)wf * 2 + 1) * g.slot_floats + e);
-  for (long w = wf + 1; w <= b + 1; ++w) s += *reinterpret_cast<const f32x4*>(g.slots + (size_t)w * 2 * g.slot_floats + e);
-  const int co0 = by * BM;
-  if (is_bias) {
-    const int c = e - TILE;
+  __shared__ f32x4 sm[4][64];
+  const int tid = threadIdx.x;
+  const int* list = g.plan + 4 * 1280;
+  const int n_list = list[0];
+  const int col = tid & 63, grp = tid >> 6;
+  const int e = (blockIdx.x * 64 + col) * 4;              // element of the tile image (+ bias tail)
+  for (int li = blockIdx.y; li < n_list; li += kFixY) {
+    const int wl = list[1 + li];
+    const int idx = g.plan[4 * wl], tile = g.plan[4 * wl + 1], wf = g.plan[4 * wl + 2];
+    const WgradParams& p = g.p[idx];
+    const int gx = g.gx[idx];
+    const int bx = tile % gx, by = tile / gx;
+    const bool is_bias = e >= TILE;
+    const bool live = e < TILE + BM && !(is_bias && !(p.bias_partial && bx == 0));
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      const int n = wl - wf + 1;                            // partial i: slot 1 of workgroup wf (i = 0), slot 0 of workgroup wf + i
+      auto src = [&](int i) { return reinterpret_cast<const f32x4*>(g.slots + ((size_t)(wf + i) * 2 + (i == 0 ? 1 : 0)) * g.slot_floats + e); };
+      int i = grp;
+      for (; i + 12 < n; i += 16) {
+        const f32x4 a0 = *src(i), a1 = *src(i + 4), a2 = *src(i + 8), a3 = *src(i + 12);
+        s += a0; s += a1; s += a2; s += a3;
+      }
+      for (; i < n; i += 4) s += *src(i);
+    }
+    __syncthreads();                                        // (previous entry's combine has read sm)
+    sm[grp][col] = s;
+    __syncthreads();
+    if (grp != 0 || !live) continue;
+    s = (sm[0][col] + sm[1][col]) + (sm[2][col] + sm[3][col]);
+    const int co0 = by * BM;
+    if (is_bias) {
+      const int c = e - TILE;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (co0 + c + q < p.Cout) { float* dst = p.bias_partial + co0 + c + q; *dst = (p.rmw ? *dst : 0.f) + s[q]; }
-    return;
+      for (int q = 0; q < 4; ++q)
+        if (co0 + c + q < p.Cout) { float* dst = p.bias_partial + co0 + c + q; *dst = (p.rmw ? *dst : 0.f) + s[q]; }
+      continue;
+    }
+    int cl, tap, cil, ci0, T9;
+    if (TAPS == 9) { cl = e / (9 * BN); const int r = e - cl * 9 * BN; tap = r / BN; cil = r - tap * BN; ci0 = bx * BN; T9 = 9; }
+    else { cl = e / BN; cil = e - cl * BN; tap = bx / p.nci; ci0 = (bx - tap * p.nci) * BN; T9 = p.ks * p.ks; }
+    const int co = co0 + cl, ci = ci0 + cil;
+    if (co >= p.Cout || ci >= p.Cin) continue;              // (Cin % 4 == 0 on this path: a float4 is inside or outside as a whole)
+    f32x4* dst = reinterpret_cast<f32x4*>(p.partial + ((size_t)co * T9 + tap) * p.Cin + ci);
+    *dst = p.rmw ? *dst + s : s;
   }
-  int col, tap, cil, ci0, T9;
-  if (TAPS == 9) { col = e / (9 * BN); const int r = e - col * 9 * BN; tap = r / BN; cil = r - tap * BN; ci0 = bx * BN; T9 = 9; }
-  else { col = e / BN; cil = e - col * BN; tap = bx / p.nci; ci0 = (bx - tap * p.nci) * BN; T9 = p.ks * p.ks; }
-  const int co = co0 + col, ci = ci0 + cil;
-  if (co >= p.Cout || ci >= p.Cin) return;                // (Cin % 4 == 0 on this path: a float4 is inside or outside as a whole)
-  f32x4* dst = reinterpret_cast<f32x4*>(p.partial + ((size_t)co * T9 + tap) * p.Cin + ci);
-  *dst = p.rmw ? *dst + s : s;
 }
 
 // out[i] (+)= sum_k partial[k][i], fixed order: 4 interleaved groups (k mod 4) summed ascending, then ((g0+g1)+(g2+g3)).
@@ -864,20 +937,22 @@ int flush(Pending* pend, int& n, hipStream_t st) {
 }
 
 // ---- stream-K launches ---------------------------------------------------------------------------
-constexpr int kSKMaxG = 512;
+constexpr int kCUs = 256;
 constexpr size_t sk_slot_floats(int tile_floats, int bm) { return (size_t)((tile_floats + bm + 255) / 256 * 256); }
-// workspace regions, one per kernel family (they run back to back, their fix-ups afterwards)
+constexpr size_t kSKPlanFloats = 4 * 1280 + 1536;   // plan entries + compact list (ints) in front of every family's slots
+// grid = the workgroups that are resident at once (per tile shape) -> every workgroup starts immediately and runs the same number
+// of K-units; workspace regions, one per kernel family (the families' launches and fix-ups run back to back)
 constexpr size_t kSKRegion[7] = {
-    (size_t)kSKMaxG * 2 * sk_slot_floats(128 * 128, 128), (size_t)kSKMaxG * 2 * sk_slot_floats(128 * 64, 128),
-    (size_t)kSKMaxG * 2 * sk_slot_floats(64 * 128, 64),   (size_t)kSKMaxG * 2 * sk_slot_floats(64 * 64, 64),
-    (size_t)kSKMaxG * 2 * sk_slot_floats(64 * 9 * 64, 64), (size_t)kSKMaxG * 2 * sk_slot_floats(64 * 9 * 64, 64),
-    (size_t)kSKMaxG * 2 * sk_slot_floats(64 * 9 * 64, 64)};
-constexpr size_t sk_total_floats() { size_t t = 0; for (int i = 0; i < 7; ++i) t += kSKRegion[i]; return t; }
+    (size_t)kCUs * sk_wg_per_cu(128, 128) * 2 * sk_slot_floats(128 * 128, 128), (size_t)kCUs * sk_wg_per_cu(128, 64) * 2 * sk_slot_floats(128 * 64, 128),
+    (size_t)kCUs * sk_wg_per_cu(64, 128) * 2 * sk_slot_floats(64 * 128, 64),    (size_t)kCUs * sk_wg_per_cu(64, 64) * 2 * sk_slot_floats(64 * 64, 64),
+    (size_t)kCUs * 2 * 2 * sk_slot_floats(64 * 9 * 64, 64), (size_t)kCUs * 2 * 2 * sk_slot_floats(64 * 9 * 64, 64),
+    (size_t)kCUs * 2 * 2 * sk_slot_floats(64 * 9 * 64, 64)};
+constexpr size_t sk_total_floats() { size_t t = 0; for (int i = 0; i < 7; ++i) t += kSKRegion[i] + kSKPlanFloats; return t; }
 
 // fills the group of one family; returns false when no problem of the family is pending
 template <typename Pred, typename Geo>
-bool sk_collect(const Pending* pend, int n, SKGroup& g, float* region, int slot_floats, Pred pred, Geo geo) {
-  g.count = 0; g.total = 0; g.slots = region; g.slot_floats = slot_floats;
+bool sk_collect(const Pending* pend, int n, SKGroup& g, float* region, int slot_floats, int max_g, int min_units, Pred pred, Geo geo) {
+  g.count = 0; g.total = 0; g.plan = reinterpret_cast<int*>(region); g.slots = region + kSKPlanFloats; g.slot_floats = slot_floats;
   for (int i = 0; i < n; ++i) {
     const Pending& e = pend[i];
     if (e.pl.small || !pred(e)) continue;
@@ -893,8 +968,8 @@ bool sk_collect(const Pending* pend, int n, SKGroup& g, float* region, int slot_
     ++g.count;
   }
   if (g.count == 0) return false;
-  long G = g.total / 2;                             // at least two K-units per workgroup
-  g.G = (int)(G < 1 ? 1 : (G > kSKMaxG ? kSKMaxG : G));
+  long G = g.total / min_units;                     // a workgroup's chain of MFMAs must amortise its prologue / partial-tile write
+  g.G = (int)(G < 1 ? 1 : (G > max_g ? max_g : G));
   return true;
 }
 
@@ -902,7 +977,7 @@ template <int BM, int BN>
 int launch_variant_sk(const Pending* pend, int n, float* region, hipStream_t st) {
   static SKGroup g;   // (host staging of the kernel argument; launches are issued by one host thread per process)
   constexpr int slot = (int)sk_slot_floats(BM * BN, BM);
-  if (!sk_collect(pend, n, g, region, slot, [](const Pending& e) { return !e.pl.taps && e.pl.bm == BM && e.pl.bn == BN; },
+  if (!sk_collect(pend, n, g, region, slot, kCUs * sk_wg_per_cu(BM, BN), 16, [](const Pending& e) { return !e.pl.taps && e.pl.bm == BM && e.pl.bn == BN; },
                   [](const Pending& e, int& gx, int& gy, int& T) {
                     gx = e.pl.nci * e.d->ks * e.d->ks; gy = (e.d->Cout + BM - 1) / BM; T = (e.p.K + BK - 1) / BK;
                   })) return 0;
@@ -910,7 +985,9 @@ int launch_variant_sk(const Pending* pend, int n, float* region, hipStream_t st)
   hipLaunchKernelGGL((conv_wgrad_sk_kernel<BM, BN, 2, 2>), dim3(g.G), dim3(256), lds, st, g);
   CLC_LAUNCH_CHECK();
   if (g.G > 1) {
-    hipLaunchKernelGGL((wgrad_sk_fixup_kernel<BM, BN, 1>), dim3(g.G - 1, (BM * BN + BM + 1023) / 1024), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(wgrad_sk_compact_kernel, dim3(1), dim3(1024), 0, st, g.plan, g.G, g.plan + 4 * 1280);
+    CLC_LAUNCH_CHECK();
+    hipLaunchKernelGGL((wgrad_sk_fixup_kernel<BM, BN, 1>), dim3((BM * BN + BM + 255) / 256, kFixY), dim3(256), 0, st, g);
     CLC_LAUNCH_CHECK();
   }
   return 0;
@@ -920,7 +997,7 @@ template <int TW>
 int launch_taps_sk(const Pending* pend, int n, float* region, hipStream_t st) {
   static SKGroup g;
   constexpr int slot = (int)sk_slot_floats(64 * 9 * 64, 64);
-  if (!sk_collect(pend, n, g, region, slot, [](const Pending& e) { return e.pl.taps == TW; },
+  if (!sk_collect(pend, n, g, region, slot, kCUs * 2, 4, [](const Pending& e) { return e.pl.taps == TW; },
                   [](const Pending& e, int& gx, int& gy, int& T) { gx = e.pl.nci; gy = (e.d->Cout + 63) / 64; T = e.p.K >> 5; })) return 0;
   constexpr int XP = (32 / TW + 2) * (TW + 2);
   const size_t lds = (size_t)2 * (32 * 64 + XP * 64) * sizeof(float);
@@ -932,7 +1009,9 @@ int launch_taps_sk(const Pending* pend, int n, float* region, hipStream_t st) {
   hipLaunchKernelGGL((conv_wgrad_taps_sk_kernel<TW>), dim3(g.G), dim3(256), lds, st, g);
   CLC_LAUNCH_CHECK();
   if (g.G > 1) {
-    hipLaunchKernelGGL((wgrad_sk_fixup_kernel<64, 64, 9>), dim3(g.G - 1, (64 * 9 * 64 + 64 + 1023) / 1024), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(wgrad_sk_compact_kernel, dim3(1), dim3(1024), 0, st, g.plan, g.G, g.plan + 4 * 1280);
+    CLC_LAUNCH_CHECK();
+    hipLaunchKernelGGL((wgrad_sk_fixup_kernel<64, 64, 9>), dim3((64 * 9 * 64 + 64 + 255) / 256, kFixY), dim3(256), 0, st, g);
     CLC_LAUNCH_CHECK();
   }
   return 0;
@@ -967,17 +1046,17 @@ int flush_sk(Pending* pend, int& n, float* ws, hipStream_t st) {
   int rc;
   float* r = ws;
   if ((rc = launch_variant_sk<128, 128>(pend, n, r, st)) < 0) return rc;
-  r += kSKRegion[0];
+  r += kSKRegion[0] + kSKPlanFloats;
   if ((rc = launch_variant_sk<128, 64>(pend, n, r, st)) < 0) return rc;
-  r += kSKRegion[1];
+  r += kSKRegion[1] + kSKPlanFloats;
   if ((rc = launch_variant_sk<64, 128>(pend, n, r, st)) < 0) return rc;
-  r += kSKRegion[2];
+  r += kSKRegion[2] + kSKPlanFloats;
   if ((rc = launch_variant_sk<64, 64>(pend, n, r, st)) < 0) return rc;
-  r += kSKRegion[3];
+  r += kSKRegion[3] + kSKPlanFloats;
   if ((rc = launch_taps_sk<32>(pend, n, r, st)) < 0) return rc;
-  r += kSKRegion[4];
+  r += kSKRegion[4] + kSKPlanFloats;
   if ((rc = launch_taps_sk<16>(pend, n, r, st)) < 0) return rc;
-  r += kSKRegion[5];
+  r += kSKRegion[5] + kSKPlanFloats;
   if ((rc = launch_taps_sk<8>(pend, n, r, st)) < 0) return rc;
   n = 0;
   return 0;

@@ -64,9 +64,9 @@ def test_fused_adamw_matches_torch(dev, max_norm):
             upd_ref = (b.detach() - o).double()
             scale_u = max(upd_ref.abs().max().item(), 1e-12)
             err = (a.detach().cpu().double() - b.detach().double()).abs()
-            # both sides round the new parameter to fp32 (1 ulp of |p|); beyond that the update itself must agree to 1e-5 of its
+            # both sides round the new parameter to fp32 (up to 1 ulp of |p| each); beyond that the update itself must agree to 1e-5 of its
             # size — a wrong bias correction, clip coefficient or step count is an error of 10 % .. 10x of the update
-            allowed = 2.0 ** -23 * b.detach().abs().double() + 1e-5 * scale_u
+            allowed = 2.0 ** -22 * b.detach().abs().double() + 1e-5 * scale_u
             assert bool((err <= allowed).all()), f"step {step} tensor {i}: max excess {(err - allowed).max().item():.3e} (update scale {scale_u:.3e})"
             st = opt_ref.state[b]
             off = opt.p_arena.offsets[i]
