@@ -39,18 +39,26 @@ def synthetic_batch(batch, size, seed, device):
     return x.to(device)
 
 
-def cpu_baseline(n_refs: int, sample_batch: int, size: int):
-    """Oracle fwd + RD loss + bwd on the host cores (checker used as the reported baseline, never as the product)."""
+def _host_threads():
+    """threads this process may actually use: the affinity mask (os.cpu_count() over-reports inside a cpuset) capped at the
+    16-CPU share a one-GPU box grants — an intra-op pool sized to the reported 128 cores oversubscribes the share and is slower"""
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(usable, int(os.environ.get("CLC_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(n_refs: int, sample_batch: int, size: int, timed_steps: int = 3):
+    """the oracle (plain-PyTorch CPU restatement of the reference graph; the reference itself cannot be imported
+    where this runs) — forward + RD loss + backward at the GPU run's batch, 1 warm-up + `timed_steps` timed iterations, median.
+    The checker is used here as the reported baseline, never as the product."""
+    import statistics
+
     import torch
 
+    from clc_amd.recipe import apply_weight_recipe
     from oracle import graph as og
     from oracle.loss import RateDistortionLoss
-    from oracle.recipe import apply_weight_recipe
 
-    # threads actually usable by this process (affinity mask; os.cpu_count() over-reports inside a cpuset) and what
-    # torch's intra-op pool was sized to — never oversubscribe, that makes the "baseline" arbitrarily slow
-    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(usable, torch.get_num_threads()))
+    cores = _host_threads()
     torch.set_num_threads(cores)
     m = og.CLC(N=64, num_ref_frames=n_refs).train()
     apply_weight_recipe(m, 0)
@@ -61,16 +69,97 @@ def cpu_baseline(n_refs: int, sample_batch: int, size: int):
     def one():
         for p in m.parameters():
             p.grad = None
+        t0 = time.perf_counter()
         out = crit(m(x, refs), x)
         out["loss"].backward()
+        return time.perf_counter() - t0
 
     one()  # warm-up (first iteration pays allocator / thread-pool start-up)
-    t0 = time.perf_counter()
-    one()
-    dt = time.perf_counter() - t0
+    ts = [one() for _ in range(timed_steps)]
+    dt = statistics.median(ts)
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in fh if l.startswith("model name")), "")
+    except OSError:
+        pass
     return {"value": sample_batch / dt, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle (plain PyTorch CPU restatement of the reference graph) fwd+RD-loss+bwd, 1 warm-up + 1 timed step at batch {sample_batch} "
-                      f"({size}x{size}, n_refs={n_refs}), {cores} torch threads, fp32; {dt:.2f} s"}
+            "sample": f"oracle (plain PyTorch CPU restatement of the reference graph) fwd+RD-loss+bwd at batch {sample_batch} ({size}x{size}, "
+                      f"n_refs={n_refs}), 1 warm-up + {timed_steps} timed steps, median {dt:.2f} s/step (all: {', '.join(f'{t:.2f}' for t in ts)}); "
+                      f"{cores} torch threads of {os.cpu_count()} reported cores, torch {torch.__version__}, fp32; CPU: {cpu_model}"}
+
+
+def parity_and_codec(dev):
+    """BASELINE.md §3 parity columns + codec timing on one seeded 256x256 image (eval mode):
+    |d bpp|, |d PSNR| of the HIP forward vs the oracle; y/z streams of the HIP compress() identical across the product's C++ coder,
+    the plain-C oracle coder and the pure-Python oracle coder (on the product's symbols); decoder == encoder-side reconstruction;
+    compress / decompress wall time per image on the GPU path and on the CPU oracle (CPU transforms + pure-Python rANS)."""
+    import math
+
+    import torch
+
+    from clc_amd import models as pm
+    from clc_amd.recipe import apply_weight_recipe, synthetic_image
+    from oracle import graph as og
+    from oracle import rans_c, rans_py
+    from oracle.loss import compute_bpp
+
+    torch.set_num_threads(_host_threads())
+    o = og.CLC(N=64, num_ref_frames=1).eval()
+    apply_weight_recipe(o, 0)
+    p = pm.CLC(N=64, num_ref_frames=1)
+    p.load_state_dict(o.state_dict())
+    p = p.to(dev).eval()
+    o.update(force=True)
+    p.update(force=True)
+    x, r = synthetic_image(1, 256, 256, 100, smooth=True), [synthetic_image(1, 256, 256, 101, smooth=True)]
+    xd, rd = x.to(dev), [r[0].to(dev)]
+    with torch.no_grad():
+        a = o(x, r)
+        b = p(xd, rd)
+    bpp_o = compute_bpp(a)
+    bpp_p = compute_bpp({"x_hat": b["x_hat"].cpu(), "likelihoods": {k: v.cpu() for k, v in b["likelihoods"].items()}})
+    psnr = lambda t: -10 * math.log10(torch.mean((t.double().cpu() - x.double()) ** 2).item())
+    # codec: GPU path
+    for _ in range(2):
+        enc = p.compress(xd, rd)
+        dec = p.decompress(enc["strings"], enc["shape"], rd)
+    torch.cuda.synchronize()
+    n = 5
+    t0 = time.perf_counter()
+    for _ in range(n):
+        enc = p.compress(xd, rd)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(n):
+        dec = p.decompress(enc["strings"], enc["shape"], rd)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    gc = p.gaussian_conditional
+    cdf, ln, off = gc.host_tables()
+    sc, mu, y = b["para"]["scales"], b["para"]["means"], b["para"]["y"]
+    idx = torch.cat([gc.build_indexes(s).contiguous().reshape(-1) for s in sc.chunk(5, 1)]).cpu().numpy()
+    sym = torch.cat([torch.round(u - m).int().contiguous().reshape(-1) for u, m in zip(y.chunk(5, 1), mu.chunk(5, 1))]).cpu().numpy()
+    ys = enc["strings"][0][0]
+    identical = (rans_c.encode(sym, idx, cdf, ln, off) == ys
+                 and rans_py.RansEncoder().encode_with_indexes(sym.tolist(), idx.tolist(), cdf.tolist(), ln.tolist(), off.tolist()) == ys
+                 and bool(torch.equal(dec["x_hat"], b["x_hat"].clamp(0, 1))))
+    # codec: CPU oracle (one image, one pass each)
+    with torch.no_grad():
+        c0 = time.perf_counter()
+        enc_o = o.compress(x, r)
+        c1 = time.perf_counter()
+        o.decompress(enc_o["strings"], enc_o["shape"], r)
+        c2 = time.perf_counter()
+    parity = {"dbpp": abs(bpp_o - bpp_p), "dpsnr_db": abs(psnr(a["x_hat"]) - psnr(b["x_hat"])), "bitstream_identical": bool(identical),
+              "bpp_oracle": bpp_o, "bpp_hip": bpp_p, "bars": "dbpp <= 1e-4, dpsnr <= 0.01 dB, y/z streams byte-identical across the C++ / C / Python coders and "
+              "decoder output == encoder-side reconstruction", "sample": "CLC N=64 n_refs=1, one seeded smooth 256x256 image, eval mode, recipe weights"}
+    codec = {"gpu_compress_ms_per_image": (t1 - t0) / n * 1e3, "gpu_decompress_ms_per_image": (t2 - t1) / n * 1e3,
+             "cpu_compress_ms_per_image": (c1 - c0) * 1e3, "cpu_decompress_ms_per_image": (c2 - c1) * 1e3,
+             "y_bytes": len(ys), "z_bytes": len(enc["strings"][1][0]),
+             "note": "GPU: HIP transforms + one D2H copy + host C++ rANS, batch 1, 256x256; CPU: oracle transforms + pure-Python rANS (the stand-in for "
+                     "CompressAI's coder), one pass"}
+    return parity, codec
 
 
 def roofline_leg(engine, x, refs):
@@ -96,13 +185,19 @@ def roofline_leg(engine, x, refs):
         ops.PROFILE = None
     def kernel_name(fam, variant, shape):
         """the name rocprofv3 --kernel-trace reports for this launch (template arguments from the C ABI's variant id)"""
+        if fam == "conv_wgrad_group":   # one kernel family of a grouped stream-K filter-gradient call (+ its compact / fix-up launches)
+            if variant == 1:
+                return "wgrad_small_kernel"
+            if variant >= 64900:
+                return f"conv_wgrad_taps_sk_kernel<{variant - 64900}>"
+            return f"conv_wgrad_sk_kernel<{variant // 1000}, {variant % 1000}, 2, 2>"
         if fam != "conv_igemm" or variant < (1 << 20):
-            return fam   # conv_direct_small / wgrad calls (a grouped wgrad call is several kernels + a slab reduce)
+            return fam   # conv_direct_small / single (non-deferred) wgrad calls
         tr = "true" if str(shape).startswith("dgrad") else "false"
         f, bm, bn = variant >> 20, (variant >> 3) & 0x1FF, (variant & 7) << 5
         if f == 3:
             return f"conv_igemm_splitk_kernel<{bn}, {tr}, {(variant >> 16) & 15}>"
-        return f"conv_igemm{'_dma' if f == 2 else ''}_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}>"
+        return f"conv_igemm{ {1: '', 2: '_dma', 4: '_dma2'}[f]}_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}>"
 
     agg = {}
     for fam, variant, flops, e0, e1, *_shape in rec:
@@ -113,8 +208,8 @@ def roofline_leg(engine, x, refs):
         a[2] += 1
     total_t = sum(a[1] for a in agg.values())
     total_f = sum(a[0] for a in agg.values())
-    # the dominant KERNEL: calls that launch several kernels (grouped filter gradients + slab reduce) are listed in per_kernel
-    # but cannot be matched against one rocprofv3 row, so they do not compete
+    # the dominant KERNEL by summed time; a stream-K filter-gradient family competes with its algorithmic FLOPs over the time of its
+    # main kernel + compact + fix-up launches (the bracket cannot separate them; the fix-up is ~1-3 % of it)
     single = {k: v for k, v in agg.items() if "_kernel<" in k}
     dom = max((single or agg).items(), key=lambda kv: kv[1][1])
     name, (f, t, n) = dom
@@ -124,7 +219,7 @@ def roofline_leg(engine, x, refs):
     # file does not list the kernel
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as fh:
             k = json.load(fh)["kernels"].get(name)
         if k and k["launches_per_step"]:
             traffic = round((k["fetch_bytes_per_step"] + k["write_bytes_per_step"]) / k["launches_per_step"])
@@ -153,7 +248,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=2)
+    ap.add_argument("--cpu-sample-batch", type=int, default=0, help="CPU-baseline batch (default: the GPU batch, BASELINE.md §3)")
+    ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -216,14 +312,17 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"CLC N=64 lambda={args.lmbda} MSE, {args.size}x{args.size} bs{args.batch}/GPU, n_refs={args.n_refs}: "
                                "fwd + RD loss + bwd + clip_grad_norm + AdamW + aux step (configs[1])",
-                   "global_batch": world * args.batch, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
-                   "final_loss": loss},
+                   "global_batch": world * args.batch, "parallelism": f"dp{world}", "ranks_seen": (dist.get_world_size() if world > 1 else 1),
+                   "collective": ("RCCL all-reduce of the flat fp32 gradient arena (64 MiB buckets), overlapped with the analysis-transform backward"
+                                  if world > 1 else "none"), "hip_graph": not args.no_graph, "final_loss": loss},
     }
     if not args.no_roofline:  # every rank runs it (the eager step contains the gradient all-reduce); rank 0 reports
         result["roofline"] = roofline_leg(engine, x, refs)
     if rank == 0:
+        if world == 1 and not args.no_parity:
+            result["parity"], result["codec"] = parity_and_codec(dev)
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args.n_refs, args.cpu_sample_batch, args.size)
+            result["cpu_baseline"] = cpu_baseline(args.n_refs, args.cpu_sample_batch or args.batch, args.size)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -1094,6 +1094,11 @@ extern "C" int clc_conv2d_wgrad_batched(const clc_wgrad_desc* descs, int count, 
   return flush(pend, n, (hipStream_t)stream);
 }
 
+extern "C" int clc_conv2d_wgrad_variant(const clc_wgrad_desc* d) {
+  if (!d) return -1;
+  return variant_id(make_plan(d));
+}
+
 extern "C" size_t clc_conv2d_wgrad_group_workspace_bytes(void) { return sk_total_floats() * sizeof(float); }
 
 extern "C" int clc_conv2d_wgrad_batched_sk(const clc_wgrad_desc* descs, int count, void* group_workspace, size_t group_workspace_bytes,

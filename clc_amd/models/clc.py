@@ -125,6 +125,9 @@ class CompressionModel(nn.Module):
 class _SliceCodec(CompressionModel):
     """Shared backbone + channel-slice entropy model of TCM and CLC."""
 
+    _boundary_ok = True   # forward() can expose (y, ref_features) for the two-phase backward of clc_amd.train.TrainEngine
+    _boundary = None
+
     def _build_backbone(self, N, M, head_dim):
         ws = self.window_size
         self.g_a = nn.Sequential(
@@ -224,6 +227,10 @@ class _SliceCodec(CompressionModel):
         x = self._prep(x)
         ref_features = self._ref(ref_frames)
         y = self.g_a(x)
+        if getattr(self, "_keep_boundary", False):
+            # outputs of the analysis transform / reference branch: where clc_amd.train.TrainEngine cuts the backward pass in two
+            # so that the gradient exchange of everything downstream overlaps the backward of these two encoders
+            self._boundary = (y, ref_features)
         y_shape = y.shape[2:]
         z = self.h_a(y)
         z_likelihoods, z_hat = self.entropy_bottleneck.likelihood_and_ste(z)

@@ -85,11 +85,19 @@ def flush_wgrads():
         if PROFILE is None:
             _launch_wgrad_group(arr, len(_PENDING))
         else:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            _launch_wgrad_group(arr, len(_PENDING))
-            e1.record()
-            PROFILE.append(("conv_wgrad_grouped", 0, _PENDING_FLOP[0], e0, e1, f"{len(_PENDING)} problems"))
+            # one call per kernel family (the families are separate grids inside the grouped call anyway: same kernels, same
+            # work split), each bracketed by events and credited with its problems' algorithmic FLOPs
+            fams = {}
+            for d, _k in _PENDING:
+                fams.setdefault(_L().clc_conv2d_wgrad_variant(C.byref(d)), []).append(d)
+            for vid, ds in fams.items():
+                sub = (_lib.WgradDesc * len(ds))(*ds)
+                fl = sum(2.0 * d.N * d.OH * d.OW * d.ks * d.ks * d.Cin * d.Cout for d in ds)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _launch_wgrad_group(sub, len(ds))
+                e1.record()
+                PROFILE.append(("conv_wgrad_group", vid, fl, e0, e1, f"{len(ds)} problems"))
         for fn in _PENDING_POST:
             fn()
     _PENDING_POST.clear()

@@ -103,20 +103,26 @@ class GradSync:
     only add latency — default bucket = 64 MiB.  ``start()`` launches asynchronously, ``finish()`` waits and scales.
     """
 
-    def __init__(self, flat: torch.Tensor, bucket_bytes: int = 64 << 20, group=None):
+    def __init__(self, flat: torch.Tensor, bucket_bytes: int = 64 << 20, group=None, phases=None):
+        """phases: list of (begin, end) element ranges of `flat` that become ready at different times (reverse-graph order: the
+        gradients of the layers nearest the loss first); start(k) launches phase k's buckets.  Default: one phase = everything."""
         import torch.distributed as dist
 
         self.dist = dist
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         n = max(1, bucket_bytes // 4)
-        self.buckets = [flat[i: i + n] for i in range(0, flat.numel(), n)]
+        self.phases = []
+        for a, b in (phases or [(0, flat.numel())]):
+            self.phases.append([flat[i: min(i + n, b)] for i in range(a, b, n)])
+        self.buckets = [bk for ph in self.phases for bk in ph]
         self.pending = []
 
-    def start(self):
+    def start(self, phase=None):
         if self.world == 1:
             return
-        self.pending = [self.dist.all_reduce(b, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets]
+        bks = self.buckets if phase is None else self.phases[phase]
+        self.pending += [self.dist.all_reduce(b, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True) for b in bks]
 
     def finish(self):
         if self.world == 1:
@@ -253,9 +259,15 @@ class TrainEngine:
     out = engine.step(x, refs)      # dict of device scalars: loss, bpp_loss, mse_loss, aux_loss
     """
 
+    LATE_PREFIXES = ("g_a.", "ref_encoder.", "ref_feature_adapter.")   # modules whose backward runs last (they feed everything else)
+
     def __init__(self, model: nn.Module, lmbda: float, loss_type: str = "mse", lr: float = 1e-4, aux_lr: float = 1e-3,
-                 clip_max_norm: float = 1.0, use_graph: bool = True, with_optimizer: bool = True, train_mode: bool = True, side_stream: bool = True):
-        self.model, self.criterion = model, RateDistortionLoss(lmbda, loss_type)
+                 clip_max_norm: float = 1.0, use_graph: bool = True, with_optimizer: bool = True, train_mode: bool = True, side_stream: bool = True,
+                 criterion=None, optimizer_factory=None):
+        """criterion / optimizer_factory: replaceable parts (defaults: the reference's RD loss and the fused HIP AdamW) — the
+        multi-process CPU test drives the step structure with plain-torch stand-ins."""
+        self.model, self.criterion = model, (criterion or RateDistortionLoss(lmbda, loss_type))
+        self._make_opt = optimizer_factory or (lambda params, lr, max_norm: FusedAdamW(params, lr=lr, max_norm=max_norm))
         self.lr, self.aux_lr, self.clip = lr, aux_lr, clip_max_norm
         self.use_graph, self.with_optimizer = use_graph, with_optimizer
         self.train_mode = train_mode   # False: deterministic rounding instead of noise (tests)
@@ -275,16 +287,26 @@ class TrainEngine:
             p.grad = None
         out = self.criterion(self.model(x, refs), x)
         out["loss"].backward()
-        live = [p for n, p in self.model.named_parameters() if p.grad is not None and not n.endswith(".quantiles")]
+        named = [(n, p) for n, p in self.model.named_parameters() if p.grad is not None and not n.endswith(".quantiles")]
+        # arena order = [encoders | everything downstream]: the backward pass reaches the analysis transform and the reference
+        # branch LAST, so their gradients are the second (small) exchange phase and everything else can go on the wire while
+        # their backward still runs (overlap in reverse-graph order)
+        late = [p for n, p in named if n.startswith(self.LATE_PREFIXES)]
+        early = [p for n, p in named if not n.startswith(self.LATE_PREFIXES)]
+        live = late + early
         aux = [p for n, p in self.model.named_parameters() if n.endswith(".quantiles")]
         if self.side_stream:
             ops.enable_wgrad_stream(True)
             ops.enable_branch_streams(True)
         ops.enable_deferred_reductions(True)
-        self.opt = FusedAdamW(live, lr=self.lr, max_norm=self.clip)
-        self.aux_opt = FusedAdamW(aux, lr=self.aux_lr, max_norm=0.0)
+        self.opt = self._make_opt(live, self.lr, self.clip)
+        self.aux_opt = self._make_opt(aux, self.aux_lr, 0.0)
         self.transposer = FilterTransposer(live)
-        self.sync = GradSync(self.opt.grad_flat)
+        cut = self.opt.p_arena.offsets[len(late)] if (late and early) else 0
+        n_el = self.opt.grad_flat.numel()
+        self.early_params = early
+        self.sync = GradSync(self.opt.grad_flat, phases=([(cut, n_el), (0, cut)] if cut else None))
+        self.two_phase = bool(cut) and hasattr(self.model, "_boundary_ok")
         self.aux_sync = GradSync(self.aux_opt.grad_flat)
 
     def _fwd_bwd(self, x, refs):
@@ -295,6 +317,32 @@ class TrainEngine:
         out["loss"].backward()
         ops.join_side_streams()   # filter gradients computed on the side stream are complete from here on
         return out
+
+    # -- the same pass cut in two at the outputs of the analysis transform / reference branch (multi-GPU overlap)
+    def _fwd_bwd_early(self, x, refs):
+        """forward + loss + backward of everything DOWNSTREAM of (y, ref_features); their gradients are parked on the boundary."""
+        self.opt.zero_grad()
+        self.aux_opt.zero_grad()
+        self.transposer.refresh()
+        self.model._keep_boundary = True
+        try:
+            out = self.criterion(self.model(x, refs), x)
+        finally:
+            self.model._keep_boundary = False
+        self._bt = [t for t in self.model._boundary if t is not None and t.requires_grad]
+        self.model._boundary = None
+        for t in self._bt:
+            t.grad = None
+        # (retain_graph: the engine would otherwise also release the saved tensors of the boundary's producers, which stage 2 needs)
+        torch.autograd.backward([out["loss"]], inputs=list(self.early_params) + self._bt, retain_graph=True)
+        ops.join_side_streams()
+        return out
+
+    def _bwd_late(self):
+        """backward of the analysis transform and the reference branch from the parked boundary gradients."""
+        torch.autograd.backward(self._bt, [t.grad for t in self._bt])
+        ops.join_side_streams()
+        self._bt = None
 
     def _opt_steps(self, out):
         if self.with_optimizer:
@@ -311,9 +359,15 @@ class TrainEngine:
             self.aux_opt.step()
         return {k: v.detach() for k, v in out.items()}
 
-    def _eager_step(self, x, refs):
-        out = self._fwd_bwd(x, refs)
-        self.sync.start()
+    def _eager_step(self, x, refs, split=False):
+        if split and self.two_phase:
+            out = self._fwd_bwd_early(x, refs)
+            self.sync.start(0)        # everything downstream of the encoders goes on the wire ...
+            self._bwd_late()          # ... while the encoders' backward runs
+            self.sync.start(1)
+        else:
+            out = self._fwd_bwd(x, refs)
+            self.sync.start()
         self.sync.finish()
         out = self._opt_steps(out)
         return self._finish(out)
@@ -346,12 +400,12 @@ class TrainEngine:
         # CLC_FORCE_SPLIT_GRAPHS=1 exercises the multi-GPU structure (graph A | exchange | graph B) on one GPU
         single = self.sync.world == 1 and os.environ.get("CLC_FORCE_SPLIT_GRAPHS", "0") != "1"
         if not self.use_graph:
-            return self._eager_step(x, refs)
+            return self._eager_step(x, refs, split=not single)
         sig = self._signature(x, refs)
         if self.graph is not None and sig != self._static_sig:
             # a batch of another shape (the reference's DataLoader has no drop_last, train_CLC.py:428-434: the last batch of an
             # epoch is short): run it eagerly — same arithmetic, launch overhead for this one step only
-            return self._eager_step(x, refs)
+            return self._eager_step(x, refs, split=not single)
         if self.graph is None:
             # warm up on a side stream (allocator + lazy kernel attributes), then capture.  The warm-up steps must not count as
             # training steps: parameters, Adam moments and step counters are restored afterwards, so the FIRST replay is the
@@ -363,7 +417,7 @@ class TrainEngine:
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 for _ in range(2):
-                    self._eager_step(*self._static)
+                    self._eager_step(*self._static, split=not single)
                 self.opt.state_restore(snap[0])
                 self.aux_opt.state_restore(snap[1])
             torch.cuda.current_stream().wait_stream(s)
@@ -373,6 +427,16 @@ class TrainEngine:
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph):
                     self._out = self._eager_step(*self._static)
+            elif self.two_phase:
+                # collectives stay outside the graphs: A1 = forward + backward down to the encoders' outputs | exchange of those
+                # gradients starts | A2 = the encoders' backward (overlaps the exchange) | rest of the exchange | B = optimizer + aux
+                self.graph = (torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph())
+                with torch.cuda.graph(self.graph[0]):
+                    self._mid = self._fwd_bwd_early(*self._static)
+                with torch.cuda.graph(self.graph[1], pool=self.graph[0].pool()):
+                    self._bwd_late()
+                with torch.cuda.graph(self.graph[2], pool=self.graph[0].pool()):
+                    self._out2 = self._opt_steps(dict(self._mid))
             else:
                 # collectives stay outside the graphs: graph A = fwd+bwd, exchange, graph B = optimizer + aux
                 self.graph = (torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph())
@@ -389,7 +453,12 @@ class TrainEngine:
             self.graph.replay()
             return self._out
         self.graph[0].replay()
-        self.sync.start()
+        if len(self.graph) == 3:
+            self.sync.start(0)
+            self.graph[1].replay()
+            self.sync.start(1)
+        else:
+            self.sync.start()
         self.sync.finish()
-        self.graph[1].replay()
+        self.graph[-1].replay()
         return self._finish(dict(self._out2))

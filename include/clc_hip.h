@@ -125,6 +125,9 @@ int clc_conv2d_wgrad_batched(const clc_wgrad_desc* descs, int count, clc_stream_
  * which a fix-up launch adds in workgroup order.  Same results as clc_conv2d_wgrad_batched up to summation order; run-to-run
  * reproducible (the ranges depend only on the group's shapes). */
 size_t clc_conv2d_wgrad_group_workspace_bytes(void);
+/* kernel family a problem is planned on: 1 = small-Cin VALU kernel, 64900 + TW = all-taps 3x3 kernel (TW = 32 | 16 | 8),
+ * BM * 1000 + BN = tap-per-workgroup kernel (same ids clc_conv2d_wgrad returns).  Benchmark tooling: FLOP accounting per kernel. */
+int clc_conv2d_wgrad_variant(const clc_wgrad_desc* d);
 int clc_conv2d_wgrad_batched_sk(const clc_wgrad_desc* descs, int count, void* group_workspace, size_t group_workspace_bytes,
                                 clc_stream_t stream);
 

@@ -258,9 +258,11 @@ def test_ms_ssim_engine_graph_and_shape_change(dev):
         eng.step(x, None)
 
 
-def test_force_split_graphs_is_bit_identical(dev, monkeypatch):
-    """The multi-GPU step structure (graph A = fwd+bwd | gradient exchange | graph B = optimizer + aux) forced on one GPU gives
-    the same loss sequence, bit for bit, as the single-graph path."""
+def test_force_split_graphs_matches_single_graph(dev, monkeypatch):
+    """The multi-GPU step structure (graph A1 = forward + backward down to the encoders' outputs | first exchange phase | graph A2 =
+    the encoders' backward | second phase | graph B = optimizer + aux) forced on one GPU gives the single-graph path's loss sequence.
+    Not bit for bit: the filter gradients are flushed in two groups instead of one, and the stream-K split of a group's K range
+    depends on what else is in the group (fp32 summation order only); each path by itself is run-to-run reproducible."""
     from clc_amd.train import TrainEngine
 
     x, refs = _inputs(dev, 2, 1)
@@ -269,7 +271,12 @@ def test_force_split_graphs_is_bit_identical(dev, monkeypatch):
         monkeypatch.setenv("CLC_FORCE_SPLIT_GRAPHS", split)
         eng = TrainEngine(_model(dev), lmbda=0.0067, use_graph=True, train_mode=False)
         seqs.append([eng.step(x, refs)["loss"].item() for _ in range(4)])
-    assert seqs[0] == seqs[1], seqs
+        if split == "1":
+            assert isinstance(eng.graph, tuple) and len(eng.graph) == 3, "two-phase backward structure not taken"
+            eng2 = TrainEngine(_model(dev), lmbda=0.0067, use_graph=True, train_mode=False)
+            assert [eng2.step(x, refs)["loss"].item() for _ in range(4)] == seqs[1], "split path is not reproducible"
+    for a, b in zip(*seqs):
+        assert abs(a - b) <= 2e-5 * abs(a), seqs
 
 
 # ------------------------------------------------------------------------------------------------- eval helpers (row 16)
