@@ -1,0 +1,293 @@
+"""Batched, hipGraph-captured encoder / decoder service around the CLC / TCM models.
+
+The reference codec (/root/reference/models/CLC_run.py:629-716, 738-814; eval loop /root/reference/eval_CLC.py:324-338) runs
+~550 eager launches per 256x256 image, marshals symbols through Python lists, codes one image at a time and never writes a
+file.  Same bitstreams, re-staged for the MI355X:
+
+  compress    ONE captured graph per (batch, size, refs) signature: analysis + hyper transforms, the five slice steps and the
+              integer quantise / index kernels -> packed int32 symbols + CDF indexes of every image, ONE device->host copy,
+              then one rANS stream per image on host threads (the C++ coder runs outside the GIL).
+              z_hat = round(z - median) + median is taken on the device — identical to decoding the z stream just written,
+              which is what the reference does (CLC_run.py:643-644) — so nothing waits for the host coder.
+  decompress  the slice loop is autoregressive THROUGH the arithmetic decoder (slice i's CDF indexes depend on the decoded
+              slices < i), so a host decoder forces one device->host->device hop per slice; everything between two hops is one
+              captured graph (6 graphs per signature), the hops use pinned buffers, and the images of a batch are decoded in
+              parallel (one decoder state per image).
+  container   `pack` / `unpack` / `write_file` / `read_file`: a self-describing byte layout around {"strings", "shape"}
+              (the reference only counts len(strings[k][0]), eval_CLC.py:337).
+
+Streams are byte-identical to model.compress() per image (tests/test_codec_service_gpu.py), which in turn is pinned to the
+reference's own compress() by tests/golden/codec_*.npz.
+"""
+from __future__ import annotations
+
+import struct
+from concurrent.futures import ThreadPoolExecutor
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import ans, ops
+from .ops import CL
+
+MAGIC = b"CLC1"
+
+
+# ------------------------------------------------------------------------------------------------ container
+
+
+def pack(strings, shape, image_hw, n_refs: int = 0, model_id: int = 0) -> bytes:
+    """One image: header + z stream + y stream.
+    header (little endian): magic 'CLC1' | u8 version=1 | u8 model_id | u8 n_refs | u8 reserved | u16 H | u16 W (original image) |
+    u16 zh | u16 zw (hyper-latent shape = `shape`) | u32 len(y) | u32 len(z)."""
+    y, z = strings[0][0], strings[1][0]
+    return MAGIC + struct.pack("<BBBBHHHHII", 1, model_id, n_refs, 0, image_hw[0], image_hw[1], int(shape[0]), int(shape[1]), len(y), len(z)) + z + y
+
+
+def unpack(blob: bytes):
+    """-> (strings, shape, meta) as decompress() takes them."""
+    if blob[:4] != MAGIC:
+        raise ValueError("not a CLC1 container")
+    ver, model_id, n_refs, _r, H, W, zh, zw, ny, nz = struct.unpack("<BBBBHHHHII", blob[4:24])
+    if ver != 1:
+        raise ValueError(f"unsupported container version {ver}")
+    if len(blob) != 24 + ny + nz:
+        raise ValueError("truncated / oversized container")
+    z, y = blob[24:24 + nz], blob[24 + nz:24 + nz + ny]
+    return [[y], [z]], torch.Size([zh, zw]), {"image_hw": (H, W), "n_refs": n_refs, "model_id": model_id}
+
+
+def write_file(path, strings, shape, image_hw, n_refs=0, model_id=0):
+    blob = pack(strings, shape, image_hw, n_refs, model_id)
+    with open(path, "wb") as f:
+        f.write(blob)
+    return len(blob)
+
+
+def read_file(path):
+    with open(path, "rb") as f:
+        return unpack(f.read())
+
+
+# --------------------------------------------------------------------------------------------------- engine
+
+
+class _Plan:
+    pass
+
+
+class CodecEngine:
+    """engine = CodecEngine(model); outs = engine.compress(x[B], refs); xs = engine.decompress(outs, refs)."""
+
+    def __init__(self, model, threads: int = 8, use_graph: bool = True):
+        self.model = model.eval()
+        self.use_graph = use_graph
+        self.pool = ThreadPoolExecutor(max_workers=max(1, threads))
+        self._enc = {}
+        self._dec = {}
+        model.update()   # CDF tables (no-op when present)
+
+    # ---------------------------------------------------------------- shared pieces
+    def _sig(self, x, refs):
+        return (tuple(x.shape), None if refs is None else tuple(tuple(r.shape) for r in refs))
+
+    def _capture(self, fn):
+        """run fn() twice eagerly on a side stream (allocator / lazy kernel attributes), then capture it; -> (graph, outputs)."""
+        if not self.use_graph:
+            return None, fn()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fn()
+            fn()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = fn()
+        g.replay()   # capture does not execute: leave valid values behind for the next segment's warm-up passes
+        return g, out
+
+    # ---------------------------------------------------------------- encoder
+    def _build_encoder(self, x, refs):
+        m = self.model
+        pl = _Plan()
+        pl.x = x.clone()
+        pl.refs = [r.clone() for r in refs] if refs is not None else None
+        B = x.shape[0]
+        S = m.num_slices
+
+        @torch.no_grad()
+        def run():
+            xx = m._prep(pl.x)
+            ref_features = m._ref(pl.refs)
+            y = m.g_a(xx)
+            y_shape = y.shape[2:]
+            z = m.h_a(y)
+            eb = m.entropy_bottleneck
+            med = eb._get_medians().reshape(1, -1, 1, 1)
+            z_sym = torch.round(z - med).to(torch.int32)                    # == EntropyBottleneck.compress's symbols
+            z_hat = (z_sym.float() + med).contiguous(memory_format=CL)      # == decompress(compress(z)), CLC_run.py:643-644
+            latent_scales = m.h_scale_s(z_hat)
+            latent_means = m.h_mean_s(z_hat)
+            syms, idxs, y_hat_slices = [], [], []
+            for i, y_slice in enumerate(y.chunk(S, 1)):
+                mean_support, mu, scale = m._slice_params(i, latent_means, latent_scales, y_hat_slices, ref_features, y_shape)
+                sym, idx, y_hat_slice = m.gaussian_conditional.quantize_and_index(y_slice, mu, scale)
+                syms.append(sym.contiguous())
+                idxs.append(idx.contiguous())
+                y_hat_slices.append(m._refine(i, mean_support, y_hat_slice, ref_features))
+            # per image contiguous: [B][slice][C/S][h][w] in the reference's NCHW reshape(-1) order
+            ys = torch.stack(syms, dim=1).reshape(B, -1)
+            yi = torch.stack(idxs, dim=1).reshape(B, -1)
+            zs = z_sym.contiguous().reshape(B, -1)
+            return torch.cat((ys, yi, zs), dim=1), tuple(z.shape[-2:])
+
+        pl.graph, (pl.packed, pl.zshape) = self._capture(run)
+        pl.run = run
+        pl.host = torch.empty(pl.packed.shape, dtype=torch.int32).pin_memory()
+        pl.ny = (pl.packed.shape[1] - 192 * pl.zshape[0] * pl.zshape[1]) // 2
+        C = 192
+        pl.zidx = np.ascontiguousarray(np.broadcast_to(np.arange(C, dtype=np.int32).reshape(C, 1, 1), (C,) + pl.zshape)).reshape(-1)
+        return pl
+
+    @torch.no_grad()
+    def compress(self, x, ref_frames: Optional[Sequence[torch.Tensor]] = None) -> List[dict]:
+        """x [B,3,H,W] (H, W multiples of 128 after eval.pad) -> one {"strings": [[y], [z]], "shape"} per image."""
+        refs = list(ref_frames) if ref_frames else None
+        if not getattr(self.model, "use_ref", True) or not hasattr(self.model, "ref_encoder"):
+            refs = None
+        sig = self._sig(x, refs)
+        pl = self._enc.get(sig)
+        if pl is None:
+            pl = self._enc[sig] = self._build_encoder(x, refs)
+        pl.x.copy_(x, non_blocking=True)
+        if refs is not None:
+            for d, r in zip(pl.refs, refs):
+                d.copy_(r, non_blocking=True)
+        if pl.graph is not None:
+            pl.graph.replay()
+        else:
+            pl.packed, _ = pl.run()
+        pl.host.copy_(pl.packed, non_blocking=True)
+        torch.cuda.current_stream().synchronize()        # the ONE device->host hop of the encoder
+        arr = pl.host.numpy()
+        gcdf, gln, goff = self.model.gaussian_conditional.host_tables()
+        ecdf, eln, eoff = self.model.entropy_bottleneck.host_tables()
+        ny = pl.ny
+
+        def encode_one(b):
+            row = arr[b]
+            return (ans.encode(row[:ny], row[ny:2 * ny], gcdf, gln, goff), ans.encode(row[2 * ny:], pl.zidx, ecdf, eln, eoff))
+
+        streams = list(self.pool.map(encode_one, range(arr.shape[0])))
+        return [{"strings": [[ys], [zs]], "shape": torch.Size(pl.zshape)} for ys, zs in streams]
+
+    # ---------------------------------------------------------------- decoder
+    def _build_decoder(self, B, zshape, refs, dev):
+        m = self.model
+        S = m.num_slices
+        pl = _Plan()
+        pl.refs = [r.clone() for r in refs] if refs is not None else None
+        pl.z_in = torch.zeros((B, 192) + tuple(zshape), dtype=torch.int32, device=dev)
+        yh, yw = zshape[0] * 4, zshape[1] * 4
+        Cs = m.M // S if hasattr(m, "M") else 320 // S
+        pl.rv_in = [torch.zeros((B, Cs, yh, yw), dtype=torch.int32, device=dev) for _ in range(S)]
+        pl.z_host = torch.empty(pl.z_in.shape, dtype=torch.int32).pin_memory()
+        pl.rv_host = [torch.empty(t.shape, dtype=torch.int32).pin_memory() for t in pl.rv_in]
+        pl.idx_host = [torch.empty(t.shape, dtype=torch.int32).pin_memory() for t in pl.rv_in]
+        # per-slice state, indexed by slice: a segment only ever reads entries written by EARLIER segments' captured runs and
+        # writes its own entries, so the eager warm-up passes of one segment cannot disturb what another segment's graph reads
+        st = {"y_hat": [None] * S, "ms": [None] * S, "mu": [None] * S}
+        y_shape = [yh, yw]
+        gc = m.gaussian_conditional
+
+        @torch.no_grad()
+        def params(i):
+            mean_support, mu, scale = m._slice_params(i, st["lm"], st["ls"], st["y_hat"][:i], st["ref"], y_shape)
+            st["ms"][i], st["mu"][i] = mean_support, mu
+            return gc.build_indexes(scale).contiguous()
+
+        @torch.no_grad()
+        def refine(i):
+            rv = pl.rv_in[i].float().contiguous(memory_format=CL)
+            st["y_hat"][i] = m._refine(i, st["ms"][i], rv + st["mu"][i], st["ref"])
+
+        @torch.no_grad()
+        def seg_first():
+            st["ref"] = m._ref(pl.refs)
+            med = m.entropy_bottleneck._get_medians().reshape(1, -1, 1, 1)
+            z_hat = (pl.z_in.float() + med).contiguous(memory_format=CL)
+            st["ls"] = m.h_scale_s(z_hat)
+            st["lm"] = m.h_mean_s(z_hat)
+            return params(0)
+
+        def seg_mid(i):
+            def fn():
+                refine(i - 1)
+                return params(i)
+            return fn
+
+        @torch.no_grad()
+        def seg_last():
+            refine(S - 1)
+            return m.g_s(torch.cat(st["y_hat"], dim=1)).clamp_(0, 1)
+
+        pl.segs = []
+        for fn in [seg_first] + [seg_mid(i) for i in range(1, S)] + [seg_last]:
+            g, out = self._capture(fn)
+            pl.segs.append((g, fn, out))
+        return pl
+
+    @torch.no_grad()
+    def decompress(self, items: Sequence[dict], ref_frames: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+        """items: outputs of compress() (or unpack()ed containers) for B images of one shape -> x_hat [B,3,H,W] clamped to [0,1]."""
+        m = self.model
+        refs = list(ref_frames) if ref_frames else None
+        if not getattr(m, "use_ref", True) or not hasattr(m, "ref_encoder"):
+            refs = None
+        B = len(items)
+        zshape = tuple(int(v) for v in items[0]["shape"])
+        dev = next(m.parameters()).device
+        sig = (B, zshape, None if refs is None else tuple(tuple(r.shape) for r in refs))
+        pl = self._dec.get(sig)
+        if pl is None:
+            pl = self._dec[sig] = self._build_decoder(B, zshape, refs, dev)
+        if refs is not None:
+            for d, r in zip(pl.refs, refs):
+                d.copy_(r, non_blocking=True)
+        gcdf, gln, goff = m.gaussian_conditional.host_tables()
+        ecdf, eln, eoff = m.entropy_bottleneck.host_tables()
+        C = 192
+        zidx = np.ascontiguousarray(np.broadcast_to(np.arange(C, dtype=np.int32).reshape(C, 1, 1), (C,) + zshape)).reshape(-1)
+        zh = pl.z_host.numpy()
+
+        def dec_z(b):
+            zh[b] = ans.decode(items[b]["strings"][1][0], zidx, ecdf, eln, eoff).reshape(zh.shape[1:])
+
+        list(self.pool.map(dec_z, range(B)))
+        pl.z_in.copy_(pl.z_host, non_blocking=True)
+        decoders = [ans._Decoder(items[b]["strings"][0][0]) for b in range(B)]
+        try:
+            S = m.num_slices
+            for i in range(S + 1):
+                g, fn, out = pl.segs[i]
+                if g is not None:
+                    g.replay()
+                else:
+                    out = fn()
+                if i == S:
+                    return out.clone() if g is not None else out
+                pl.idx_host[i].copy_(out, non_blocking=True)
+                torch.cuda.current_stream().synchronize()          # hop i: CDF indexes of slice i for every image
+                ih, rh = pl.idx_host[i].numpy(), pl.rv_host[i].numpy()
+
+                def dec_y(b):
+                    rh[b] = decoders[b].decode(ih[b].reshape(-1), gcdf, gln, goff).reshape(rh.shape[1:])
+
+                list(self.pool.map(dec_y, range(B)))
+                pl.rv_in[i].copy_(pl.rv_host[i], non_blocking=True)
+        finally:
+            for d in decoders:
+                d.close()

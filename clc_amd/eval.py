@@ -41,8 +41,9 @@ def compute_bpp(out_net) -> float:
 
 
 @torch.no_grad()
-def evaluate(net, samples: Iterable[Tuple[torch.Tensor, Sequence[torch.Tensor]]], p: int = 128, device="cuda"):
-    """samples: iterable of (image [3,h,w] in [0,1], [reference images]). Returns per-image rows and averages."""
+def evaluate(net, samples: Iterable[Tuple[torch.Tensor, Sequence[torch.Tensor]]], p: int = 128, device="cuda", engine=None):
+    """samples: iterable of (image [3,h,w] in [0,1], [reference images]). Returns per-image rows and averages.
+    engine: a clc_amd.codec.CodecEngine over `net` (graph-captured codec, same bitstreams); default: net.compress / net.decompress."""
     net.eval()
     net.update()
     rows, t_total = [], 0.0
@@ -54,8 +55,12 @@ def evaluate(net, samples: Iterable[Tuple[torch.Tensor, Sequence[torch.Tensor]]]
         refs_p = [pad(r, p)[0] for r in refs]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        enc = net.compress(x_p, refs_p)
-        dec = net.decompress(enc["strings"], enc["shape"], refs_p)
+        if engine is not None:
+            enc = engine.compress(x_p, refs_p)[0]
+            dec = {"x_hat": engine.decompress([enc], refs_p)}
+        else:
+            enc = net.compress(x_p, refs_p)
+            dec = net.decompress(enc["strings"], enc["shape"], refs_p)
         torch.cuda.synchronize()
         t_total += time.perf_counter() - t0
         x_hat = crop(dec["x_hat"], padding)

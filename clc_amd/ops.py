@@ -483,6 +483,9 @@ class _ConvFn(Function):
     @staticmethod
     def forward(ctx, x, w, b, res, ks, stride, act, res_scale, shuffle, res_first, w2=None, b2=None, fold_in=None, fold_out=None, out_buf=None,
                 grad_slot=None, park_dx=None):
+        if x.dim() != 4 or x.shape[1] != w.shape[1]:
+            # (the kernels take Cin from the activation: a mismatch would walk off the end of the filter buffer)
+            raise _lib.ClcError(f"conv2d: input {tuple(x.shape)} does not match the filter {tuple(w.shape)} (expected {w.shape[1]} input channels)")
         wk = to_kernel_weight(w)
         ctx.park_dx = park_dx   # GradFold that takes this layer's input gradient (a sibling layer on the same input adds it in its epilogue)
         wk2 = to_kernel_weight(w2) if w2 is not None else None

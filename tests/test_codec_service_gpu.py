@@ -1,0 +1,76 @@
+"""Batched, hipGraph-captured codec service (clc_amd.codec) against the reference-surface model methods:
+per-image streams byte-identical to model.compress(), decoded images bit-identical to model.decompress() and to the
+encoder-side reconstruction, graph and eager engines identical, container round trip (also through a file)."""
+import os
+
+import pytest
+import torch
+
+
+def _container_items():
+    return [[b"\x01\x02\x03\x04" * 5], [b"\xff" * 12]], torch.Size([4, 6])
+
+
+def test_container_roundtrip(tmp_path):
+    from clc_amd import codec
+
+    strings, shape = _container_items()
+    blob = codec.pack(strings, shape, (200, 300), n_refs=3, model_id=1)
+    assert len(blob) == 24 + 20 + 12 and blob[:4] == b"CLC1"
+    s2, sh2, meta = codec.unpack(blob)
+    assert s2 == strings and tuple(sh2) == (4, 6) and meta == {"image_hw": (200, 300), "n_refs": 3, "model_id": 1}
+    n = codec.write_file(tmp_path / "a.clc", strings, shape, (200, 300), 3, 1)
+    assert n == len(blob) and os.path.getsize(tmp_path / "a.clc") == n
+    s3, sh3, meta3 = codec.read_file(tmp_path / "a.clc")
+    assert s3 == strings and tuple(sh3) == (4, 6) and meta3 == meta
+    with pytest.raises(ValueError):
+        codec.unpack(b"XXXX" + blob[4:])
+    with pytest.raises(ValueError):
+        codec.unpack(blob[:-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,R", [("clc", 1), ("tcm", 0)])
+def test_engine_matches_model_codec(dev, kind, R):
+    from clc_amd import codec
+    from clc_amd import models as pm
+    from clc_amd.recipe import apply_weight_recipe, synthetic_image
+
+    m = pm.CLC(N=64, num_ref_frames=R) if kind == "clc" else pm.TCM(N=64)
+    apply_weight_recipe(m, 0)
+    m = m.to(dev).eval()
+    m.update(force=True)
+    B = 3
+    x = torch.cat([synthetic_image(1, 256, 256, 100 + 7 * i, smooth=True) for i in range(B)]).to(dev)
+    refs = [torch.cat([synthetic_image(1, 256, 256, 200 + 7 * i + j, smooth=True) for i in range(B)]).to(dev) for j in range(R)]
+    want = []
+    for i in range(B):
+        ri = [r[i:i + 1] for r in refs]
+        enc = m.compress(x[i:i + 1], ri) if R else m.compress(x[i:i + 1])
+        dec = m.decompress(enc["strings"], enc["shape"], ri) if R else m.decompress(enc["strings"], enc["shape"])
+        want.append((enc, dec["x_hat"]))
+    results = {}
+    for use_graph in (True, False):
+        eng = codec.CodecEngine(m, threads=4, use_graph=use_graph)
+        outs = eng.compress(x, refs)
+        assert len(outs) == B
+        for i, (o, (enc, _)) in enumerate(zip(outs, want)):
+            assert o["strings"][0][0] == enc["strings"][0][0], f"image {i}: y stream differs from model.compress (graph={use_graph})"
+            assert o["strings"][1][0] == enc["strings"][1][0], f"image {i}: z stream differs"
+            assert tuple(o["shape"]) == tuple(enc["shape"])
+        x_hat = eng.decompress(outs, refs)
+        for i in range(B):
+            assert torch.equal(x_hat[i:i + 1], want[i][1]), f"image {i}: decoded image differs from model.decompress (graph={use_graph})"
+        # a second batch through the SAME captured graphs (other content, other order)
+        perm = [2, 0, 1]
+        outs2 = eng.compress(x[perm], [r[perm] for r in refs])
+        for k, i in enumerate(perm):
+            assert outs2[k]["strings"] == outs[i]["strings"], "an image's streams depend on its position in the batch"
+        x_hat2 = eng.decompress(outs2, [r[perm] for r in refs])
+        assert torch.equal(x_hat2, x_hat[perm])
+        # through the container
+        blobs = [codec.pack(o["strings"], o["shape"], (256, 256), n_refs=R) for o in outs]
+        items = [dict(zip(("strings", "shape"), codec.unpack(b)[:2])) for b in blobs]
+        assert torch.equal(eng.decompress(items, refs), x_hat)
+        results[use_graph] = (outs, x_hat)
+    assert torch.equal(results[True][1], results[False][1])

@@ -258,11 +258,46 @@ def test_ms_ssim_engine_graph_and_shape_change(dev):
         eng.step(x, None)
 
 
+def test_two_phase_backward_equals_single_backward(dev):
+    """The backward pass cut at the encoders' outputs (multi-GPU overlap: clc_amd.train.TrainEngine._fwd_bwd_early / _bwd_late)
+    produces the single-pass gradients: every parameter, to fp32 summation order (the filter gradients are flushed in two
+    stream-K groups instead of one), and the encoders' parameters sit in front of the arena (second exchange phase)."""
+    from clc_amd.train import TrainEngine
+
+    x, refs = _inputs(dev, 2, 1)
+    m = _model(dev)
+    eng = TrainEngine(m, lmbda=0.0067, use_graph=False, train_mode=False)
+    eng._discover(x, refs)
+    assert eng.two_phase and len(eng.sync.phases) == 2
+    names = {id(p): n for n, p in m.named_parameters()}
+    order = [names[id(p)] for p in eng.opt.params]
+    n_late = sum(n.startswith(TrainEngine.LATE_PREFIXES) for n in order)
+    assert 0 < n_late < len(order) and all(n.startswith(TrainEngine.LATE_PREFIXES) for n in order[:n_late])
+    assert not any(n.startswith(TrainEngine.LATE_PREFIXES) for n in order[n_late:])
+    cut = eng.opt.p_arena.offsets[n_late]
+    assert eng.sync.phases[0][0].data_ptr() == eng.opt.grad_flat[cut:].data_ptr() and eng.sync.phases[1][0].data_ptr() == eng.opt.grad_flat.data_ptr()
+    out1 = eng._fwd_bwd(x, refs)
+    g1 = eng.opt.grad_flat.clone()
+    out2 = eng._fwd_bwd_early(x, refs)
+    assert float(eng.opt.grad_flat[:cut].abs().max()) == 0.0, "the encoders' gradients must not exist before the second stage"
+    eng._bwd_late()
+    g2 = eng.opt.grad_flat.clone()
+    assert out1["loss"].item() == out2["loss"].item()
+    worst = 0.0
+    for i, p in enumerate(eng.opt.params):
+        a = g1[eng.opt.p_arena.offsets[i]: eng.opt.p_arena.offsets[i] + p.numel()]
+        b = g2[eng.opt.p_arena.offsets[i]: eng.opt.p_arena.offsets[i] + p.numel()]
+        scale = a.abs().max().item()
+        if scale > 1e-12:
+            worst = max(worst, (a - b).abs().max().item() / scale)
+    assert worst < 2e-5, worst
+
+
 def test_force_split_graphs_matches_single_graph(dev, monkeypatch):
     """The multi-GPU step structure (graph A1 = forward + backward down to the encoders' outputs | first exchange phase | graph A2 =
-    the encoders' backward | second phase | graph B = optimizer + aux) forced on one GPU gives the single-graph path's loss sequence.
-    Not bit for bit: the filter gradients are flushed in two groups instead of one, and the stream-K split of a group's K range
-    depends on what else is in the group (fp32 summation order only); each path by itself is run-to-run reproducible."""
+    the encoders' backward | second phase | graph B = optimizer + aux) forced on one GPU: same first loss, bit for bit (identical
+    forward), the following ones within training noise (the filter gradients are summed in another order and Adam's first step is
+    lr * sign(g), so rounding-boundary flips of the quantiser separate the trajectories), and run-to-run reproducible."""
     from clc_amd.train import TrainEngine
 
     x, refs = _inputs(dev, 2, 1)
@@ -275,8 +310,9 @@ def test_force_split_graphs_matches_single_graph(dev, monkeypatch):
             assert isinstance(eng.graph, tuple) and len(eng.graph) == 3, "two-phase backward structure not taken"
             eng2 = TrainEngine(_model(dev), lmbda=0.0067, use_graph=True, train_mode=False)
             assert [eng2.step(x, refs)["loss"].item() for _ in range(4)] == seqs[1], "split path is not reproducible"
+    assert seqs[0][0] == seqs[1][0]
     for a, b in zip(*seqs):
-        assert abs(a - b) <= 2e-5 * abs(a), seqs
+        assert abs(a - b) <= 1e-2 * abs(a), seqs
 
 
 # ------------------------------------------------------------------------------------------------- eval helpers (row 16)
