@@ -34,13 +34,28 @@ __global__ void pm_prep_kernel(const float* __restrict__ x, float* __restrict__ 
   }
 }
 
-// one workgroup per patch: sums over K = C*ph*pw contiguous floats (fixed-order tree)
-__global__ __launch_bounds__(256) void pm_patch_stats_kernel(const float* __restrict__ q, int K, float* __restrict__ x_sum, float* __restrict__ x_sq) {
+// one workgroup per patch: centre it (x' = x - mean(x), written to qc) and leave sum x' (~0, kept for exactness) and sum x'^2.
+// The correlation's numerator sum x y - mean(y) sum x is then accumulated as sum x' y directly — two O(K) terms that cancel to
+// O(sqrt K) no longer meet in fp32 (the uncentred form lost the 3rd decimal of the map: tests allowed 2e-3) — and
+// den_x = sum x'^2 needs no subtraction at all.  Fixed-order trees -> reproducible.
+__global__ __launch_bounds__(256) void pm_patch_stats_kernel(const float* __restrict__ q, int K, float* __restrict__ qc, float* __restrict__ x_sum,
+                                                         float* __restrict__ x_sq) {
   __shared__ float s1[256], s2[256];
   const float* row = q + (size_t)blockIdx.x * K;
-  float a = 0.f, b = 0.f;
-  for (int k = threadIdx.x; k < K; k += 256) { const float v = row[k]; a += v; b = fmaf(v, v, b); }
-  s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+  float* crow = qc + (size_t)blockIdx.x * K;
+  float a = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) a += row[k];
+  s1[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) s1[threadIdx.x] += s1[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float mean = s1[0] / (float)K;
+  __syncthreads();
+  float c1 = 0.f, c2 = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) { const float v = row[k] - mean; crow[k] = v; c1 += v; c2 = fmaf(v, v, c2); }
+  s1[threadIdx.x] = c1; s2[threadIdx.x] = c2;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (threadIdx.x < o) { s1[threadIdx.x] += s1[threadIdx.x + o]; s2[threadIdx.x] += s2[threadIdx.x + o]; }
@@ -51,18 +66,21 @@ __global__ __launch_bounds__(256) void pm_patch_stats_kernel(const float* __rest
 
 // box sums over the C x ph x pw window at every valid position; one thread per position, rows summed via a
 // horizontal running window held in registers is overkill here: the image is small and L2-resident.
+// S1 = window mean, S2 = sum (y - mean)^2 over the window = sum y^2 - K mean^2, evaluated in double (768-term sums whose
+// difference is the variance: in fp32 the subtraction costs 3-4 digits; this kernel is a few microseconds either way).
 __global__ void pm_box_sums_kernel(const float* __restrict__ y, int C, int H, int W, int ph, int pw, float* __restrict__ S1, float* __restrict__ S2) {
   const int cw = W - pw + 1, chh = H - ph + 1;
   const int pos = blockIdx.x * blockDim.x + threadIdx.x;
   if (pos >= cw * chh) return;
   const int oy = pos / cw, ox = pos - oy * cw;
-  float a = 0.f, b = 0.f;
+  double a = 0.0, b = 0.0;
   for (int c = 0; c < C; ++c)
     for (int dy = 0; dy < ph; ++dy) {
       const float* r = y + ((size_t)c * H + oy + dy) * W + ox;
-      for (int dx = 0; dx < pw; ++dx) { const float v = r[dx]; a += v; b = fmaf(v, v, b); }
+      for (int dx = 0; dx < pw; ++dx) { const double v = (double)r[dx]; a += v; b += v * v; }
     }
-  S1[pos] = a; S2[pos] = b;
+  const double K = (double)C * ph * pw, mean = a / K;
+  S1[pos] = (float)mean; S2[pos] = (float)(b - mean * mean * K);
 }
 
 struct PearsonParams {
@@ -119,13 +137,13 @@ __global__ __launch_bounds__(256, 2) void pm_pearson_kernel(const PearsonParams 
   if (ox >= p.cw) return;
   const int pos = oy * p.cw + ox;
   const float psz = (float)p.K;
-  const float y_mean = p.S1[pos] / psz;
-  const float den_y = p.S2[pos] - y_mean * y_mean * psz;
+  const float y_mean = p.S1[pos];          // window mean
+  const float den_y = p.S2[pos];           // centred sum of squares of the window
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int n = n0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
     if (n >= p.P) continue;
-    const float xs = p.x_sum[n];
+    const float xs = p.x_sum[n];             // sum of the CENTRED patch (~1e-5: rounding of the mean)
     const float den_x = p.x_sq[n] - (xs / psz) * xs;
     float v = (acc[r] - y_mean * xs) / sqrtf(den_y * den_x);
     if (p.mask) v *= p.mask[(size_t)n * p.cw * p.chh + pos];
@@ -235,25 +253,26 @@ extern "C" int clc_pm_gauss_mask(float* out, int img_h, int img_w, int ph, int p
   return 0;
 }
 
-extern "C" size_t clc_pm_pearson_workspace_bytes(int P, int H, int W, int ph, int pw) {
-  return ((size_t)2 * P + (size_t)2 * (H - ph + 1) * (W - pw + 1)) * sizeof(float);
+extern "C" size_t clc_pm_pearson_workspace_bytes(int P, int C, int H, int W, int ph, int pw) {   // statistics + the centred copy of the patches
+  return ((size_t)2 * P + (size_t)2 * (H - ph + 1) * (W - pw + 1) + 64 + (size_t)P * C * ph * pw) * sizeof(float);
 }
 
 extern "C" int clc_pm_pearson(const float* q, int P, const float* y, int C, int H, int W, int ph, int pw, const float* mask, float* out, void* ws,
                               size_t ws_bytes, clc_stream_t stream) {
   CLC_CHECK(q && y && out && P > 0 && C > 0 && H >= ph && W >= pw && ph > 0 && pw > 0, "clc_pm_pearson: bad args");
   CLC_CHECK(pw % 4 == 0 && aligned16(q), "clc_pm_pearson: patch width must be a multiple of 4 and q 16-byte aligned");
-  CLC_CHECK(ws && ws_bytes >= clc_pm_pearson_workspace_bytes(P, H, W, ph, pw), "clc_pm_pearson: workspace too small");
+  CLC_CHECK(ws && ws_bytes >= clc_pm_pearson_workspace_bytes(P, C, H, W, ph, pw) && aligned16(ws), "clc_pm_pearson: workspace too small / unaligned");
   const size_t lds = (size_t)C * ph * (64 + pw - 1) * sizeof(float);
   CLC_CHECK(lds <= 64 * 1024, "clc_pm_pearson: window of %zu bytes exceeds the 64 KiB LDS budget", lds);
   CLC_CHECK((size_t)P * C * ph * pw * 4 < (1ull << 31), "clc_pm_pearson: patch tensor too large");
   PearsonParams p;
-  p.q = q; p.y = y; p.mask = mask; p.out = out;
+  p.y = y; p.mask = mask; p.out = out;
   p.P = P; p.C = C; p.H = H; p.W = W; p.ph = ph; p.pw = pw; p.K = C * ph * pw; p.cw = W - pw + 1; p.chh = H - ph + 1;
   float* w = (float*)ws;
   float* x_sum = w; float* x_sq = w + P; float* S1 = w + 2 * P; float* S2 = S1 + (size_t)p.cw * p.chh;
-  p.x_sum = x_sum; p.x_sq = x_sq; p.S1 = S1; p.S2 = S2;
-  hipLaunchKernelGGL(pm_patch_stats_kernel, dim3(P), dim3(256), 0, ST, q, p.K, x_sum, x_sq);
+  float* qc = w + (((size_t)2 * P + (size_t)2 * p.cw * p.chh + 63) / 64) * 64;   // centred patches, 256-byte aligned
+  p.q = qc; p.x_sum = x_sum; p.x_sq = x_sq; p.S1 = S1; p.S2 = S2;
+  hipLaunchKernelGGL(pm_patch_stats_kernel, dim3(P), dim3(256), 0, ST, q, p.K, qc, x_sum, x_sq);
   CLC_LAUNCH_CHECK();
   hipLaunchKernelGGL(pm_box_sums_kernel, dim3((p.cw * p.chh + 255) / 256), dim3(256), 0, ST, y, C, H, W, ph, pw, S1, S2);
   CLC_LAUNCH_CHECK();

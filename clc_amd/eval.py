@@ -69,3 +69,80 @@ def evaluate(net, samples: Iterable[Tuple[torch.Tensor, Sequence[torch.Tensor]]]
         rows.append({"bpp": bitrate, "psnr": compute_psnr(x, x_hat)})
     n = max(1, len(rows))
     return {"rows": rows, "avg_bpp": sum(r["bpp"] for r in rows) / n, "avg_psnr": sum(r["psnr"] for r in rows) / n, "avg_time_s": t_total / n}
+
+
+# ----------------------------------------------------------------------------------------------- checkpoints / RD sweep (§8(f)-3)
+
+
+def load_checkpoint(net, checkpoint, map_location="cpu"):
+    """Load a reference-format checkpoint into `net` (/root/reference/eval_CLC.py:284-291, train_CLC.py:459-465): a path or a dict,
+    optionally wrapped as {"state_dict": ...}, keys optionally prefixed "module." (nn.DataParallel); extra keys are ignored and
+    missing ones keep their values (CLC.load_state_dict, CLC_run.py:599-618); the CDF tables are rebuilt if absent (net.update())."""
+    ck = torch.load(checkpoint, map_location=map_location, weights_only=False) if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__") else checkpoint
+    sd = ck["state_dict"] if isinstance(ck, dict) and "state_dict" in ck else ck
+    sd = {k.replace("module.", ""): v for k, v in sd.items()}
+    net.load_state_dict(sd)
+    net.update()
+    return {k: ck[k] for k in ("epoch", "loss") if isinstance(ck, dict) and k in ck}
+
+
+def find_checkpoints(models_dir):
+    """The reference's layout (eval_CLC.py:183-204): <models_dir>/<tag>_<lambda>/<lambda>checkpoint_best.pth.tar, sorted by lambda."""
+    import glob
+    import os
+
+    out = []
+    for d in sorted(glob.glob(os.path.join(models_dir, "*_*"))):
+        lam = os.path.basename(d).rsplit("_", 1)[-1]
+        path = os.path.join(d, f"{lam}checkpoint_best.pth.tar")
+        if os.path.exists(path):
+            out.append({"path": path, "bitrate": float(lam) if lam.replace(".", "", 1).isdigit() else 0.0})
+    out.sort(key=lambda c: c["bitrate"])
+    return out
+
+
+def rd_sweep(make_net, checkpoints, samples, results_dir, device="cuda", use_engine=True, plot=True):
+    """eval_CLC.py:main (259-440): evaluate every checkpoint on `samples` (list of (image, [refs])), write rd_results.csv with the
+    reference's columns and (when matplotlib is importable) rd_curve.png.  make_net() builds the model for one checkpoint."""
+    import csv
+    import os
+
+    os.makedirs(results_dir, exist_ok=True)
+    results = []
+    csv_path = os.path.join(results_dir, "rd_results.csv")
+    samples = list(samples)
+    with open(csv_path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Checkpoint", "Bitrate (bpp)", "PSNR (dB)", "Time (s)"])
+        for cp in checkpoints:
+            net = make_net().to(device).eval()
+            load_checkpoint(net, cp["path"], map_location="cpu")
+            engine = None
+            if use_engine:
+                from .codec import CodecEngine
+
+                engine = CodecEngine(net)
+            r = evaluate(net, samples, device=device, engine=engine)
+            results.append({"checkpoint": cp["path"], "bitrate": r["avg_bpp"], "psnr": r["avg_psnr"], "time": r["avg_time_s"]})
+            w.writerow([cp["path"], f"{r['avg_bpp']:.4f}", f"{r['avg_psnr']:.2f}", f"{r['avg_time_s']:.4f}"])
+            f.flush()
+    if plot:
+        try:
+            import matplotlib
+
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+
+            rs = sorted(results, key=lambda r: r["bitrate"])
+            plt.figure(figsize=(10, 6))
+            plt.plot([r["bitrate"] for r in rs], [r["psnr"] for r in rs], "o-", linewidth=2, markersize=8)
+            plt.xlabel("Bitrate (bpp)")
+            plt.ylabel("PSNR (dB)")
+            plt.title("Rate-Distortion Performance")
+            plt.grid(True, linestyle="--", alpha=0.7)
+            plt.tight_layout()
+            plt.savefig(os.path.join(results_dir, "rd_curve.png"), dpi=150)
+            plt.close()
+        except ImportError:
+            pass
+    return results, csv_path

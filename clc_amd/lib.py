@@ -117,7 +117,7 @@ SIGNATURES = {
     "clc_clm_fuse": (_i, [_pp, _pp, _i, _i, _i, fp, _i, fp, _i, _l, _i, _i, fp]),
     "clc_pm_prep": (_i, [fp, fp, _i, _i, _i, _f, fp]),
     "clc_pm_gauss_mask": (_i, [fp, _i, _i, _i, _i, fp]),
-    "clc_pm_pearson_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "clc_pm_pearson_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "clc_pm_pearson": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, fp, fp, fp, _sz, fp]),
     "clc_pm_topk": (_i, [fp, _i, _i, _i, fp, fp, fp]),
     "clc_pm_gather": (_i, [fp, _i, _i, _i, _i, _i, fp, fp, _i, _f, fp, fp]),

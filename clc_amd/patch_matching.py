@@ -45,7 +45,7 @@ def L2_or_pearson_corr(x, y, patch_h, patch_w, mask=None):
     H, W = y.shape[2], y.shape[3]
     out = torch.empty((1, P, H - ph + 1, W - pw + 1), device=x.device, dtype=torch.float32)
     L = _L()
-    nbytes = L.clc_pm_pearson_workspace_bytes(P, H, W, ph, pw)
+    nbytes = L.clc_pm_pearson_workspace_bytes(P, C, H, W, ph, pw)
     ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
     m = _chk(mask, "mask") if mask is not None else None
     _lib.check(L.clc_pm_pearson(x.data_ptr(), P, y.data_ptr(), C, H, W, ph, pw, m.data_ptr() if m is not None else None, out.data_ptr(),

@@ -314,7 +314,7 @@ int clc_clm_fuse(const float* const* feats, const float* const* atts, int M, int
  * clc_pm_gather:     SI_Wraper / SI_Finder patch gather + re-tiling; temperature < 0: plain argmax copy (k = 1) */
 int clc_pm_prep(const float* x, float* out, int n_img, int H, int W, float in_scale, clc_stream_t stream);
 int clc_pm_gauss_mask(float* out, int img_h, int img_w, int ph, int pw, clc_stream_t stream);
-size_t clc_pm_pearson_workspace_bytes(int P, int H, int W, int ph, int pw);
+size_t clc_pm_pearson_workspace_bytes(int P, int C, int H, int W, int ph, int pw);
 int clc_pm_pearson(const float* q, int P, const float* y, int C, int H, int W, int ph, int pw, const float* mask,
                    float* out, void* ws, size_t ws_bytes, clc_stream_t stream);
 int clc_pm_topk(const float* corr, int P, int npos, int k, float* val, int32_t* idx, clc_stream_t stream);

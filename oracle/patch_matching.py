@@ -57,12 +57,15 @@ def _gather_patches(y, index, patch_h, patch_w, corr_w):
     return y[0][:, rows, cols].movedim(0, -3)
 
 
-def SI_Wraper(cross_corr, patch_h, patch_w, patchs_num, y, k=1, temperature=15):
+def SI_Wraper(cross_corr, patch_h, patch_w, patchs_num, y, k=1, temperature=15, is_stack=False):
     _, _, corr_h, corr_w = cross_corr.shape
     _, C, fh, fw = y.shape
     value, index = torch.topk(cross_corr.reshape(-1, corr_h * corr_w), k, dim=1)
     weight = F.softmax(value * temperature, dim=1)
     patches = _gather_patches(y, index, patch_h, patch_w, corr_w)              # [P,k,C,ph,pw]
+    if is_stack:   # Patch_Matching.py:235-236: candidate-major channel stack, no weights
+        p = patches.reshape(fh // patch_h, fw // patch_w, k, C, patch_h, patch_w).permute(2, 3, 0, 4, 1, 5)
+        return p.reshape(1, k * C, fh, fw)
     p = (patches * weight[:, :, None, None, None]).sum(1)                       # [P,C,ph,pw]
     return p.reshape(fh // patch_h, fw // patch_w, C, patch_h, patch_w).permute(2, 0, 3, 1, 4).reshape(1, C, fh, fw)
 

@@ -350,3 +350,42 @@ def test_eval_pad_crop_psnr_bitrate(dev):
         out = m(xp, [pe.pad(r.to(dev), 128)[0]])
     cpu_out = {"x_hat": out["x_hat"].cpu(), "likelihoods": {k: v.cpu() for k, v in out["likelihoods"].items()}}
     assert abs(pe.compute_bpp(out) - ol.compute_bpp(cpu_out)) <= 1e-5
+
+
+def test_checkpoint_loading_and_rd_sweep(dev, tmp_path):
+    """§8(f)-3: reference-format checkpoints ({"state_dict": {"module.<key>": ...}}, the directory layout eval_CLC.py:183-204 globs,
+    CDF buffers included so the resize path of load_state_dict runs) load into the HIP model; the sweep writes the reference's CSV
+    (eval_CLC.py:395-411) with the numbers evaluate() gives by hand."""
+    import csv
+
+    from clc_amd import eval as pe
+    from clc_amd import models as pm
+    from clc_amd.recipe import apply_weight_recipe, synthetic_image
+    from oracle import graph as og
+
+    cps = []
+    for lam, seed in (("0.0067", 0), ("0.025", 1)):
+        o = og.CLC(N=64, num_ref_frames=1)
+        apply_weight_recipe(o, seed)
+        o.update(force=True)
+        d = tmp_path / f"0322_{lam}"
+        d.mkdir()
+        sd = {"module." + k: v for k, v in o.state_dict().items()}
+        sd["module.some_future_buffer"] = torch.zeros(3)          # extra keys are ignored (CLC_run.py:604-607)
+        torch.save({"epoch": 7, "state_dict": sd, "loss": 1.0}, d / f"{lam}checkpoint_best.pth.tar")
+        cps.append(o)
+    found = pe.find_checkpoints(str(tmp_path))
+    assert [c["bitrate"] for c in found] == [0.0067, 0.025]
+    net = pm.CLC(N=64, num_ref_frames=1).to(dev)
+    meta = pe.load_checkpoint(net, found[1]["path"])
+    assert meta["epoch"] == 7
+    for k, v in cps[1].state_dict().items():
+        assert torch.equal(net.state_dict()[k].cpu(), v), k
+    samples = [(synthetic_image(1, 200, 300, 40 + i, smooth=True)[0], [synthetic_image(1, 180, 260, 50 + i, smooth=True)[0]]) for i in range(2)]
+    results, csv_path = pe.rd_sweep(lambda: pm.CLC(N=64, num_ref_frames=1), found, samples, str(tmp_path / "res"), device=dev)
+    rows = list(csv.reader(open(csv_path)))
+    assert rows[0] == ["Checkpoint", "Bitrate (bpp)", "PSNR (dB)", "Time (s)"] and len(rows) == 3
+    by_hand = pe.evaluate(net.eval(), samples, device=dev)      # eager model.compress / decompress, checkpoint 2
+    assert abs(results[1]["bitrate"] - by_hand["avg_bpp"]) < 1e-12 and abs(results[1]["psnr"] - by_hand["avg_psnr"]) < 1e-9
+    assert rows[2][1] == f"{by_hand['avg_bpp']:.4f}" and rows[2][2] == f"{by_hand['avg_psnr']:.2f}"
+    assert results[0]["bitrate"] != results[1]["bitrate"]

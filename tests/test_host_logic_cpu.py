@@ -1,4 +1,6 @@
 """Host-side logic that needs no GPU: state_dict contract, checkpoint loading, flat arenas, loss bookkeeping."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -78,3 +80,35 @@ def test_eval_helpers_match_reference_definitions():
     assert xp.shape == (1, 3, 256, 384) and padding == (42, 42, 28, 28)
     assert torch.equal(crop(xp, padding), x)
     assert abs(compute_psnr(x, x + 0.1) - 20.0) < 1e-3
+
+
+def test_compat_install_resolves_reference_import_surface():
+    """clc_amd.compat.install(): every module-level import of train_CLC.py:17-26, eval_CLC.py:1-17 and models/CLC_run.py:1-20 that
+    belongs to the path (not torchvision / tensorboard / the dataset pipeline) resolves, to classes of this package."""
+    import subprocess
+    import sys
+
+    code = r"""
+import sys
+import clc_amd.compat as c
+done = c.install()
+from compressai.datasets import ImageFolder
+from compressai.zoo import models as zoo
+from pytorch_msssim import ms_ssim
+from models import TCM, CLC
+from compressai.entropy_models import EntropyBottleneck, GaussianConditional
+from compressai.ans import BufferedRansEncoder, RansDecoder
+from compressai.models import CompressionModel
+from compressai.layers import (AttentionBlock, ResidualBlock, ResidualBlockUpsample, ResidualBlockWithStride, conv3x3, subpel_conv3x3)
+from timm.models.layers import trunc_normal_, DropPath
+import clc_amd.models, clc_amd.entropy_models, clc_amd.ans, clc_amd.layers
+assert CLC is clc_amd.models.CLC and TCM is clc_amd.models.TCM and zoo["clc"] is CLC
+assert EntropyBottleneck is clc_amd.entropy_models.EntropyBottleneck and RansDecoder is clc_amd.ans.RansDecoder
+assert ResidualBlockWithStride is clc_amd.layers.ResidualBlockWithStride and issubclass(CLC, CompressionModel)
+m = CLC(N=64, num_ref_frames=1)          # constructs on the CPU (kernels only run on the GPU)
+assert sum(p.numel() for p in m.parameters()) == 70643852 or round(sum(p.numel() for p in m.parameters()) / 1e6, 2) == 70.64
+assert isinstance(DropPath(0.0), __import__("torch").nn.Identity)
+print("ok", len(done))
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stderr[-2000:]

@@ -20,6 +20,8 @@ def test_oracle_matches_reference_golden():
     assert torch.equal(fin, g["finder"])
     wr = opm.SI_Wraper(g["corr"] * g["mask"], 16, 16, 24, g["y_img"][0:1], k=3, temperature=15)
     np.testing.assert_allclose(wr.numpy(), g["wraper_k3"].numpy(), rtol=0, atol=1e-6)
+    st = opm.SI_Wraper(g["corr"] * g["mask"], 16, 16, 24, g["y_img"][0:1], k=3, temperature=15, is_stack=True)
+    assert torch.equal(st, g["wraper_k3_stack"])
     x = g["x_dec"][0:1] * 255
     np.testing.assert_allclose(opm.rgb_transform(opm.reduce_mean_and_std_normalize_images(x))[:, 2].numpy(),
                                (0.5 * ((x[:, 0] - 93.70454143384742) / 73.56493292844912 + (x[:, 2] - 94.84678088809876) / 76.74838442810665)).numpy(), rtol=1e-5, atol=1e-6)
@@ -36,16 +38,20 @@ def test_hip_matches_reference_golden(dev):
     q_in = g["x_dec"][0:1].reshape(1, 3, 4, 16, 6, 16).permute(0, 2, 4, 1, 3, 5).reshape(-1, 3, 16, 16).contiguous()
     q = pm.rgb_transform_normalized(q_in.to(dev), 255.0)
     assert (q.cpu() - g["q"]).abs().max().item() < 1e-4
-    # Pearson map (cancellation-prone formula: fp32 summation order moves the 4th digit)
+    # Pearson map: the kernels accumulate the CENTRED products (patch - its mean) and take the window variance in double, so the
+    # map agrees with the genuine function's output (itself within 5e-6 of an fp64 evaluation) to 2e-5
     corr = pm.L2_or_pearson_corr(g["q"].to(dev), g["r"].to(dev), 16, 16)
     assert corr.shape == g["corr"].shape
-    assert (corr.cpu() - g["corr"]).abs().max().item() < 2e-3
-    # the matches themselves: same winning positions -> identical copied patches
+    assert (corr.cpu() - g["corr"]).abs().max().item() < 2e-5
+    # the matches themselves: same winning positions -> identical copied patches (a tie within 2e-5 may pick the other position)
     fin = pm.SI_Finder_at_Image_Domain(g["x_dec"].to(dev), g["y_img"].to(dev), 16, 16, g["y_dec"].to(dev), mask=mask)
     agree = (fin.cpu() == g["finder"]).float().mean().item()
-    assert agree > 0.97, agree
+    assert agree > 0.999, agree
     wr = pm.SI_Wraper((g["corr"] * g["mask"]).to(dev), 16, 16, 24, g["y_img"][0:1].to(dev), k=3, temperature=15)
     assert (wr.cpu() - g["wraper_k3"]).abs().max().item() < 1e-5
+    # is_stack=True: the k candidates unweighted, candidate-major along the channels (Patch_Matching.py:235-236)
+    st = pm.SI_Wraper((g["corr"] * g["mask"]).to(dev), 16, 16, 24, g["y_img"][0:1].to(dev), k=3, temperature=15, is_stack=True)
+    assert st.shape == (1, 9, 64, 96) and torch.equal(st.cpu(), g["wraper_k3_stack"])
 
 
 @pytest.mark.gpu
@@ -62,8 +68,8 @@ def test_hip_pearson_config3_shape(dev):
     ref = opm.L2_or_pearson_corr(q, r, 16, 16)
     out = pm.L2_or_pearson_corr(q.to(dev), r.to(dev), 16, 16)
     assert out.shape == (1, 256, 241, 241)
-    assert (out.cpu() - ref).abs().max().item() < 3e-3
+    assert (out.cpu() - ref).abs().max().item() < 3e-5
     # arg-max agreement
     a = out.cpu().reshape(256, -1).argmax(1)
     b = ref.reshape(256, -1).argmax(1)
-    assert (a == b).float().mean().item() > 0.97
+    assert (a == b).float().mean().item() > 0.99
