@@ -230,6 +230,7 @@ class _SliceCodec(CompressionModel):
         if getattr(self, "_keep_boundary", False):
             # outputs of the analysis transform / reference branch: where clc_amd.train.TrainEngine cuts the backward pass in two
             # so that the gradient exchange of everything downstream overlaps the backward of these two encoders
+            y, ref_features = ops.cut(y), ops.cut(ref_features)
             self._boundary = (y, ref_features)
         y_shape = y.shape[2:]
         z = self.h_a(y)

@@ -633,6 +633,25 @@ def cat_halves(a, b, buf):
     return _CatHalvesFn.apply(a, b, buf)
 
 
+class _CutFn(Function):
+    """Identity marking a place where a backward pass may be cut in two (clc_amd.train.TrainEngine's two-phase backward).
+    torch.autograd.backward(..., inputs=[t]) EXECUTES t.grad_fn once more than it needs to (the engine marks the producer of a
+    captured non-leaf tensor as needed) and a Python Function cannot see that its results are unwanted (ctx.needs_input_grad is
+    static) — a convolution there would write its filter gradient twice.  With this no-op as the producer, nothing is."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def cut(x):
+    return _CutFn.apply(x) if x is not None and x.requires_grad else x
+
+
 # ----------------------------------------------------------------------------------- split / chunk
 
 
