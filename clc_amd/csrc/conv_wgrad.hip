@@ -969,6 +969,7 @@ bool sk_collect(const Pending* pend, int n, SKGroup& g, float* region, int slot_
   }
   if (g.count == 0) return false;
   long G = g.total / min_units;                     // a workgroup's chain of MFMAs must amortise its prologue / partial-tile write
+  if (clc_tuning[CLC_TUNE_SK_HALF] && max_g > kCUs) max_g = kCUs;   // one workgroup per CU: leaves wave slots to a concurrent stream
   g.G = (int)(G < 1 ? 1 : (G > max_g ? max_g : G));
   return true;
 }

@@ -249,7 +249,7 @@ class _SliceCodec(CompressionModel):
                 y_slice, scale, mu, noise=noise_all[:, i * S:(i + 1) * S] if noise_all is not None else None)
             y_lik.append(lik)
             y_hat_slices.append(self._refine(i, mean_support, y_hat_slice, ref_features))
-        x_hat = self.g_s(torch.cat(y_hat_slices, dim=1))
+        x_hat = self.g_s(ops.flush_point(torch.cat(y_hat_slices, dim=1)))
         return {"x_hat": x_hat,
                 "likelihoods": {"y": torch.cat(y_lik, dim=1), "z": z_likelihoods},
                 "para": {"means": torch.cat(mus, dim=1), "scales": torch.cat(scales, dim=1), "y": y}}

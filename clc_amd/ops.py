@@ -47,10 +47,11 @@ def enable_wgrad_stream(enable=True):
 WGRAD_GROUP = int(os.environ.get("CLC_WGRAD_GROUP", "64"))             # problems per grouped launch (library cap: 64)
 # ... or as soon as this much work is queued.  Default: effectively never (flush by count).
 WGRAD_FLUSH_GFLOP = float(os.environ.get("CLC_WGRAD_FLUSH_GFLOP", "1000"))
-_PENDING = []
+_PENDING = {}           # kernel-family id -> [(descriptor, keep-alive tuple)]
 _PENDING_FLOP = [0.0]
 _PENDING_STREAMS = {}   # streams that queued a problem since the last flush (their work must be ordered before the launch)
-_PENDING_POST = []      # callables run right after the grouped launch, on its stream (consumers of deferred temporaries)
+_PENDING_POST = {}      # kernel-family id -> callables run right after that family's launch, on its stream (consumers of deferred temporaries)
+_LAST_DEFER_VID = [0]   # family of the problem queued last (a post hook registers itself under it)
 
 
 _GROUP_WS = {}   # stream id -> persistent partial-tile workspace of the stream-K grouped filter-gradient launches
@@ -71,38 +72,46 @@ def _launch_wgrad_group(arr, n):
     _lib.check(_L().clc_conv2d_wgrad_batched_sk(arr, n, wp, wb, _stream()), "clc_conv2d_wgrad_batched_sk")
 
 
-def flush_wgrads():
-    if not _PENDING:
-        return
-    arr = (_lib.WgradDesc * len(_PENDING))(*[d for d, _ in _PENDING])
+def _flush_family(vid, target):
+    """launch the queued problems of ONE kernel family (clc_conv2d_wgrad_variant id) as a stream-K group, then its post hooks"""
+    items = _PENDING.pop(vid, [])
+    posts = _PENDING_POST.pop(vid, [])
+    with torch.cuda.stream(target):
+        if items:
+            arr = (_lib.WgradDesc * len(items))(*[d for d, _ in items])
+            if PROFILE is None:
+                _launch_wgrad_group(arr, len(items))
+            else:   # bracketed by events and credited with its problems' algorithmic FLOPs (bench.py's roofline leg)
+                fl = sum(2.0 * d.N * d.OH * d.OW * d.ks * d.ks * d.Cin * d.Cout for d, _ in items)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _launch_wgrad_group(arr, len(items))
+                e1.record()
+                PROFILE.append(("conv_wgrad_group", vid, fl, e0, e1, f"{len(items)} problems"))
+        for fn in posts:
+            fn()
+    _KEEPALIVE.append([k for _, k in items])
+
+
+def _flush_target():
     cur = torch.cuda.current_stream()
     target = WGRAD_STREAM if WGRAD_STREAM is not None else cur
     for sid, st in _PENDING_STREAMS.items():   # the operands were produced on these streams
         if sid != target.cuda_stream:
             target.wait_stream(st)
     _PENDING_STREAMS.clear()
-    with torch.cuda.stream(target):
-        if PROFILE is None:
-            _launch_wgrad_group(arr, len(_PENDING))
-        else:
-            # one call per kernel family (the families are separate grids inside the grouped call anyway: same kernels, same
-            # work split), each bracketed by events and credited with its problems' algorithmic FLOPs
-            fams = {}
-            for d, _k in _PENDING:
-                fams.setdefault(_L().clc_conv2d_wgrad_variant(C.byref(d)), []).append(d)
-            for vid, ds in fams.items():
-                sub = (_lib.WgradDesc * len(ds))(*ds)
-                fl = sum(2.0 * d.N * d.OH * d.OW * d.ks * d.ks * d.Cin * d.Cout for d in ds)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                _launch_wgrad_group(sub, len(ds))
-                e1.record()
-                PROFILE.append(("conv_wgrad_group", vid, fl, e0, e1, f"{len(ds)} problems"))
-        for fn in _PENDING_POST:
-            fn()
-    _PENDING_POST.clear()
-    _KEEPALIVE.append([k for _, k in _PENDING])
-    _PENDING.clear()
+    return target
+
+
+def flush_wgrads():
+    """Launch everything queued.  Problems wait in one queue PER KERNEL FAMILY (a family's queue is launched as soon as it holds
+    WGRAD_GROUP problems): a flush then costs one stream-K grid (+ compact + fix-up) per family that has work, with full groups,
+    instead of one under-filled grid of every family for each 64 problems in arrival order."""
+    if not _PENDING and not _PENDING_POST:
+        return
+    target = _flush_target()
+    for vid in sorted(set(_PENDING) | set(_PENDING_POST)):
+        _flush_family(vid, target)
     _PENDING_FLOP[0] = 0.0
 
 
@@ -422,10 +431,15 @@ def wgrad_raw(x, dy, *, ks, stride, pad, Cout, Cin, want_bias, in_op=IN_NONE, dw
     if defer:
         cur = torch.cuda.current_stream()   # the operands are produced on this stream: ordered before the launch at flush time
         _PENDING_STREAMS[cur.cuda_stream] = cur
-        _PENDING.append((d, (x, dy, dys_t, dw, db, ws)))
+        vid = _L().clc_conv2d_wgrad_variant(C.byref(d))
+        _LAST_DEFER_VID[0] = vid
+        q = _PENDING.setdefault(vid, [])
+        q.append((d, (x, dy, dys_t, dw, db, ws)))
         _PENDING_FLOP[0] += 2.0 * N * OH * OW * ks * ks * Cin * Cout
-        if len(_PENDING) >= WGRAD_GROUP or _PENDING_FLOP[0] >= WGRAD_FLUSH_GFLOP * 1e9:
+        if _PENDING_FLOP[0] >= WGRAD_FLUSH_GFLOP * 1e9:
             flush_wgrads()
+        elif len(q) >= WGRAD_GROUP:
+            _flush_family(vid, _flush_target())
         return None, None
     if PROFILE is None:
         _lib.check(_L().clc_conv2d_wgrad(C.byref(d), _stream()), "clc_conv2d_wgrad")
@@ -652,6 +666,24 @@ def cut(x):
     return _CutFn.apply(x) if x is not None and x.requires_grad else x
 
 
+class _FlushPointFn(Function):
+    """Identity whose backward launches the filter gradients queued so far (the synthesis transform's, when placed at its input):
+    on the side stream (CLC_WGRAD_STREAM=1) these MFMA-bound grids then run beside the latency-bound backward of the slice loop."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        flush_wgrads()
+        return g
+
+
+def flush_point(x):
+    return _FlushPointFn.apply(x) if (WGRAD_DEFER and WGRAD_STREAM is not None and x.requires_grad) else x
+
+
 # ----------------------------------------------------------------------------------- split / chunk
 
 
@@ -829,7 +861,7 @@ class _GDNParamFn(Function):
                     def post(gm=gm, beta=beta, dgf=dgf, dbe=dbe, gg=gg, gb=gb):
                         _lib.check(_L().clc_gdn_reparam_bwd(gm.data_ptr(), beta.data_ptr(), Cc, gamma_bound, beta_bound, dgf.data_ptr(),
                                                             dbe.data_ptr(), gg.data_ptr(), gb.data_ptr(), 1, _stream()), "clc_gdn_reparam_bwd")
-                    _PENDING_POST.append(post)
+                    _PENDING_POST.setdefault(_LAST_DEFER_VID[0], []).append(post)
                     _KEEPALIVE.append((gm, beta, dgf, dbe))
                 else:
                     dgf, dbe = wgrad_raw(xk, dvk, ks=1, stride=1, pad=0, Cout=Cc, Cin=Cc, want_bias=True, in_op=IN_SQUARE)
