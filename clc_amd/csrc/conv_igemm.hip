@@ -58,6 +58,7 @@ struct ConvParams {
   const float* w2; const float* bias2; int group_rows;   // rows >= group_rows (second half of the batch) use w2 / bias2
   int pre_deriv;               // y_pre <- act'(v) instead of v
   const float* res_gate; int ldg, rg_act, rg_pre;   // residual term *= act'(res_gate)
+  const float* out_gate; int ldog, og_act, og_pre;   // whole result *= act'(out_gate)
   int dma_place;               // conv_igemm_dma2_kernel: 1 = next tile's DMA pieces at the top of the iteration, 0 = between the MFMA groups
 };
 
@@ -169,6 +170,7 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, float acc, f
   }
   v = apply_act(v, p.act);
   if (p.res && !p.res_first) v += rterm;
+  if (p.out_gate) v *= act_deriv(p.out_gate[pix * p.ldog + ch], p.og_act, p.og_pre);
   p.y[pix * p.ldy + ch] = v;
 }
 
@@ -201,6 +203,7 @@ __device__ __forceinline__ void epilogue_store4(const ConvParams& p, const float
 #pragma unroll
   for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], p.act);
   if (p.res && !p.res_first) v = v + rv;
+  if (p.out_gate) v = v * act_deriv4(*reinterpret_cast<const f32x4*>(p.out_gate + pix * p.ldog + co), p.og_act, p.og_pre);
   *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + co) = v;
 }
 
@@ -1015,7 +1018,7 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   }
   {
     auto ok4 = [](const void* ptr, int ld) { return ptr == nullptr || (aligned16(ptr) && ld % 4 == 0); };
-    p.vec_epi = !d->shuffle && d->Cout % 4 == 0 && ok4(d->y, d->ldy) && ok4(d->res, d->ldr) && ok4(d->mul, d->ldm) && ok4(d->y_pre, d->ldp) && ok4(d->res_gate, d->ldg);
+    p.vec_epi = !d->shuffle && d->Cout % 4 == 0 && ok4(d->y, d->ldy) && ok4(d->res, d->ldr) && ok4(d->mul, d->ldm) && ok4(d->y_pre, d->ldp) && ok4(d->res_gate, d->ldg) && ok4(d->out_gate, d->ldog);
   }
   int classes = 1;
   p.M = d->N * d->OH * d->OW;
@@ -1023,6 +1026,8 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   p.w2 = d->w2; p.bias2 = d->bias2; p.group_rows = 0; p.pre_deriv = d->pre_deriv;
   p.dma_place = clc_tuning[CLC_TUNE_DMA_PLACE];
   p.res_gate = d->res ? d->res_gate : nullptr; p.ldg = d->ldg; p.rg_act = d->res_gate_act; p.rg_pre = d->res_gate_pre;
+  p.out_gate = d->out_gate; p.ldog = d->ldog; p.og_act = d->out_gate_act; p.og_pre = d->out_gate_pre;
+  CLC_CHECK(!d->out_gate || !d->shuffle, "clc_conv2d: out_gate with shuffle");
   if (d->w2) {   // second half of the batch on a second filter set; rows are image-major, so the halves split at M/2
     CLC_CHECK(d->N % 2 == 0, "clc_conv2d: w2 needs an even batch (got N=%d)", d->N);
     CLC_CHECK((d->bias == nullptr) == (d->bias2 == nullptr), "clc_conv2d: bias / bias2 must both be given or both NULL");

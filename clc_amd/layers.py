@@ -73,13 +73,13 @@ class Conv2d(nn.Conv2d):
         self.weight._clc_is_filter = True
 
     def forward(self, x, act=ACT_NONE, res=None, res_scale=1.0, res_first=False, shuffle=False, pair=None, fold_in=None, fold_out=None, out=None,
-                grad_slot=None, park_dx=None):
+                grad_slot=None, park_dx=None, gate_in=None, gate_out=None):
         """pair: a second Conv2d of the same shape applied to the second half of the batch in the same launch.
         fold_in / fold_out: ops.GradFold of a residual block (see there)."""
         return ops.conv2d(x, self.weight, self.bias, stride=self.stride[0], act=act, res=res, res_scale=res_scale,
                           res_first=res_first, shuffle=shuffle, w2=pair.weight if pair is not None else None,
                           b2=pair.bias if pair is not None else None, fold_in=fold_in, fold_out=fold_out, out=out, grad_slot=grad_slot,
-                          park_dx=park_dx)
+                          park_dx=park_dx, gate_in=gate_in, gate_out=gate_out)
 
 
 class Linear(nn.Linear):
@@ -89,9 +89,9 @@ class Linear(nn.Linear):
         super().__init__(*a, **kw)
         self.weight._clc_is_filter = True
 
-    def forward(self, x, act=ACT_NONE, res=None, pair=None, fold_in=None, fold_out=None, out=None):
+    def forward(self, x, act=ACT_NONE, res=None, pair=None, fold_in=None, fold_out=None, out=None, gate_in=None, gate_out=None):
         return ops.linear(x, self.weight, self.bias, act=act, res=res, w2=pair.weight if pair is not None else None,
-                          b2=pair.bias if pair is not None else None, fold_in=fold_in, fold_out=fold_out, out=out)
+                          b2=pair.bias if pair is not None else None, fold_in=fold_in, fold_out=fold_out, out=out, gate_in=gate_in, gate_out=gate_out)
 
 
 def _halves(x):
@@ -134,8 +134,8 @@ class SubpelConv3x3(nn.Sequential):
         assert r == 2
         super().__init__(Conv2d(i, o * r * r, 3), PixelShuffle2())
 
-    def forward(self, x, act=ACT_NONE, res=None, pair=None, fold_in=None, park_dx=None):
-        return self[0](x, act=act, res=res, shuffle=True, pair=pair[0] if pair is not None else None, fold_in=fold_in, park_dx=park_dx)
+    def forward(self, x, act=ACT_NONE, res=None, pair=None, fold_in=None, park_dx=None, gate_out=None):
+        return self[0](x, act=act, res=res, shuffle=True, pair=pair[0] if pair is not None else None, fold_in=fold_in, park_dx=park_dx, gate_out=gate_out)
 
 
 def subpel_conv3x3(i, o, r=1):
@@ -189,15 +189,17 @@ class ResidualBlockWithStride(nn.Module):
             co = self.conv1.out_channels
             w1 = torch.nn.functional.pad(self.conv1.weight.permute(0, 2, 3, 1).reshape(co, 9 * cin), (0, 32 - 9 * cin))
             ws = torch.nn.functional.pad(self.skip.weight.reshape(co, cin), (4 * cin, 32 - 5 * cin))
-            t = self.conv2(ops.linear(col, w1, self.conv1.bias, act=ACT_LRELU))
+            g = ops.ActGate()   # conv2's data gradient arrives already multiplied by LeakyReLU'
+            t = self.conv2(ops.linear(col, w1, self.conv1.bias, act=ACT_LRELU, gate_out=g), gate_in=g)
             return self.gdn(t, res=ops.linear(col, ws, self.skip.bias))
         if self.skip is not None and x.requires_grad:
             # x feeds conv1 and the skip conv: the skip's input gradient (computed first in backward) is parked and added in
             # conv1's data-gradient epilogue instead of by an autograd add kernel
-            f = ops.GradFold()
-            t = self.conv2(self.conv1(x, act=ACT_LRELU, fold_in=f))
+            f, g = ops.GradFold(), ops.ActGate()
+            t = self.conv2(self.conv1(x, act=ACT_LRELU, fold_in=f, gate_out=g), gate_in=g)
             return self.gdn(t, res=self.skip(x, park_dx=f))
-        t = self.conv2(self.conv1(x, act=ACT_LRELU))
+        g = ops.ActGate()
+        t = self.conv2(self.conv1(x, act=ACT_LRELU, gate_out=g), gate_in=g)
         identity = self.skip(x) if self.skip is not None else x
         return self.gdn(t, res=identity)
 
@@ -213,10 +215,11 @@ class ResidualBlockUpsample(nn.Module):
 
     def forward(self, x, pair=None):
         f = ops.GradFold() if x.requires_grad else None   # upsample's input gradient is added in subpel_conv's data-gradient epilogue
+        g = ops.ActGate()                                 # conv's data gradient arrives already multiplied by LeakyReLU'
         if pair is not None:   # two blocks side by side on a batch-stacked input (the mean / scale hyper-synthesis nets)
-            t = self.conv(self.subpel_conv(x, act=ACT_LRELU, pair=pair.subpel_conv, fold_in=f), pair=pair.conv)
+            t = self.conv(self.subpel_conv(x, act=ACT_LRELU, pair=pair.subpel_conv, fold_in=f, gate_out=g), pair=pair.conv, gate_in=g)
             return self.igdn(t, res=self.upsample(x, pair=pair.upsample, park_dx=f), pair=pair.igdn)
-        t = self.conv(self.subpel_conv(x, act=ACT_LRELU, fold_in=f))
+        t = self.conv(self.subpel_conv(x, act=ACT_LRELU, fold_in=f, gate_out=g), gate_in=g)
         return self.igdn(t, res=self.upsample(x, park_dx=f))
 
 
@@ -232,13 +235,15 @@ class ResidualBlock(nn.Module):
         """lrelu(conv2(lrelu(conv1 x))) + identity (+ extra_identity * x, used by ConvTransBlock's `+ conv_x`)."""
         if self.skip is None:
             f = ops.GradFold() if x.requires_grad else None   # d(identity) is added in conv1's data-gradient epilogue
-            t = self.conv1(x, act=ACT_LRELU, fold_in=f, grad_slot=grad_slot, pair=pair.conv1 if pair is not None else None)
+            g = ops.ActGate()
+            t = self.conv1(x, act=ACT_LRELU, fold_in=f, grad_slot=grad_slot, pair=pair.conv1 if pair is not None else None, gate_out=g)
             return self.conv2(t, act=ACT_LRELU, res=x, res_scale=1.0 + extra_identity, fold_out=f, out=out,
-                              pair=pair.conv2 if pair is not None else None)
+                              pair=pair.conv2 if pair is not None else None, gate_in=g)
         assert pair is None
         assert out is None
-        t = self.conv1(x, act=ACT_LRELU)
-        out = self.conv2(t, act=ACT_LRELU, res=self.skip(x))
+        g = ops.ActGate()
+        t = self.conv1(x, act=ACT_LRELU, gate_out=g)
+        out = self.conv2(t, act=ACT_LRELU, res=self.skip(x), gate_in=g)
         return out + extra_identity * x if extra_identity else out
 
 
@@ -252,9 +257,10 @@ class ResidualUnit(nn.Module):
     def forward(self, x, pair=None):
         q = pair.conv if pair is not None else (None,) * 5
         f = ops.GradFold(gated=True) if x.requires_grad else None
-        t = self.conv[0](x, act=ACT_RELU, pair=q[0], fold_in=f)
-        t = self.conv[2](t, act=ACT_RELU, pair=q[2])
-        return self.conv[4](t, act=ACT_RELU, res=x, res_first=True, pair=q[4], fold_out=f)
+        g0, g1 = ops.ActGate(), ops.ActGate()   # each ReLU' rides in the NEXT layer's data-gradient epilogue
+        t = self.conv[0](x, act=ACT_RELU, pair=q[0], fold_in=f, gate_out=g0)
+        t = self.conv[2](t, act=ACT_RELU, pair=q[2], gate_in=g0, gate_out=g1)
+        return self.conv[4](t, act=ACT_RELU, res=x, res_first=True, pair=q[4], fold_out=f, gate_in=g1)
 
 
 class AttentionBlock(nn.Module):
@@ -313,21 +319,24 @@ class Block(nn.Module):
             f1 = ops.GradFold() if x.requires_grad else None
             x = self.msa(self.ln1(x, pair=pair.ln1, fold_in=f1, grad_slot=grad_slot), res=x, pair=pair.msa, fold_out=f1)
             f2 = ops.GradFold() if x.requires_grad else None
-            h = self.mlp[0](self.ln2(x, pair=pair.ln2, fold_in=f2), act=ACT_GELU, pair=pair.mlp[0])
-            return self.mlp[2](h, res=x, pair=pair.mlp[2], fold_out=f2, out=out)
+            g = ops.ActGate()
+            h = self.mlp[0](self.ln2(x, pair=pair.ln2, fold_in=f2), act=ACT_GELU, pair=pair.mlp[0], gate_out=g)
+            return self.mlp[2](h, res=x, pair=pair.mlp[2], fold_out=f2, out=out, gate_in=g)
         if pair is None:
             # x + f(LN(x)) twice: the residual gradients are added inside the LayerNorm backward passes
             f1 = ops.GradFold() if x.requires_grad else None
             x = self.msa(self.ln1(x, fold_in=f1, grad_slot=grad_slot), res=x, fold_out=f1)
             f2 = ops.GradFold() if x.requires_grad else None
-            h = self.mlp[0](self.ln2(x, fold_in=f2), act=ACT_GELU)
-            return self.mlp[2](h, res=x, fold_out=f2, out=out)
+            g = ops.ActGate()
+            h = self.mlp[0](self.ln2(x, fold_in=f2), act=ACT_GELU, gate_out=g)
+            return self.mlp[2](h, res=x, fold_out=f2, out=out, gate_in=g)
         assert out is None
         f1 = ops.GradFold() if x.requires_grad else None
         x = self.msa(self.ln1(x, pair=pair.ln1, fold_in=f1), res=x, pair=pair.msa, fold_out=f1)
         f2 = ops.GradFold() if x.requires_grad else None
-        h = self.mlp[0](self.ln2(x, pair=pair.ln2, fold_in=f2), act=ACT_GELU, pair=pair.mlp[0])
-        return self.mlp[2](h, res=x, pair=pair.mlp[2], fold_out=f2)
+        g = ops.ActGate()
+        h = self.mlp[0](self.ln2(x, pair=pair.ln2, fold_in=f2), act=ACT_GELU, pair=pair.mlp[0], gate_out=g)
+        return self.mlp[2](h, res=x, pair=pair.mlp[2], fold_out=f2, gate_in=g)
 
 
 class ConvTransBlock(nn.Module):

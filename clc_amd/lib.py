@@ -30,7 +30,8 @@ class ConvDesc(C.Structure):
                 ("shuffle", C.c_int), ("res_first", C.c_int),
                 ("xs", fp), ("ldxs", C.c_int), ("xs_act", C.c_int), ("xs_pre", C.c_int),
                 ("w2", fp), ("bias2", fp), ("pre_deriv", C.c_int),
-                ("res_gate", fp), ("ldg", C.c_int), ("res_gate_act", C.c_int), ("res_gate_pre", C.c_int)]
+                ("res_gate", fp), ("ldg", C.c_int), ("res_gate_act", C.c_int), ("res_gate_pre", C.c_int),
+                ("out_gate", fp), ("ldog", C.c_int), ("out_gate_act", C.c_int), ("out_gate_pre", C.c_int)]
 
 
 class WgradDesc(C.Structure):

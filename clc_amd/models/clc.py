@@ -45,9 +45,10 @@ class SliceTransform(nn.Sequential):
     def forward(self, x, final_act=ACT_NONE, res=None, pair=None):
         """pair: a second SliceTransform of the same shape for the second half of the batch (one launch per layer)."""
         q = pair if pair is not None else (None,) * 5
-        t = self[0](x, act=ACT_GELU, pair=q[0])
-        t = self[2](t, act=ACT_GELU, pair=q[2])
-        return self[4](t, act=final_act, res=res, pair=q[4])
+        g0, g1 = ops.ActGate(), ops.ActGate()   # each GELU' (stored forward) rides in the NEXT layer's data-gradient epilogue
+        t = self[0](x, act=ACT_GELU, pair=q[0], gate_out=g0)
+        t = self[2](t, act=ACT_GELU, pair=q[2], gate_in=g0, gate_out=g1)
+        return self[4](t, act=final_act, res=res, pair=q[4], gate_in=g1)
 
 
 class PointwiseMLP(nn.Sequential):
@@ -57,7 +58,8 @@ class PointwiseMLP(nn.Sequential):
         super().__init__(conv1x1(cin, mid), GELU(), conv1x1(mid, cout))
 
     def forward(self, x):
-        return self[2](self[0](x, act=ACT_GELU))
+        g = ops.ActGate()
+        return self[2](self[0](x, act=ACT_GELU, gate_out=g), gate_in=g)
 
 
 class ReferenceEncoder(nn.Module):

@@ -233,6 +233,21 @@ class GradFold:
         return g, s, gate
 
 
+class ActGate:
+    """Hands a layer's activation derivative to the ONE convolution that consumes its output.
+
+    y = act(conv_a(x)); z = conv_b(y).  In backward conv_b's data-gradient kernel produces dL/dy; multiplying it by act'(.) in that
+    kernel's epilogue gives conv_a the gradient of its PRE-activation directly, so conv_a's own data- and filter-gradient kernels
+    need no operand prologue (they run on the LDS-DMA path, and skip one tensor read each).  conv_a registers what the derivative
+    needs (its output for LeakyReLU / ReLU, the stored derivative for GELU); conv_b applies it and sets `done`; conv_a then treats
+    its incoming gradient as already gated.  Only valid when conv_b is the sole consumer of y."""
+
+    __slots__ = ("saved", "act", "pre", "done")
+
+    def __init__(self):
+        self.saved, self.act, self.pre, self.done = None, ACT_NONE, False, False
+
+
 class GradSlots:
     """One gradient buffer for the consumers of a channel split (ConvTransBlock: conv1_1's output feeds the conv branch and
     the transformer branch, CLC_run.py:212-214): each consumer's backward kernel writes its gradient straight into its
@@ -315,7 +330,7 @@ def to_kernel_weight(w: torch.Tensor) -> torch.Tensor:
 
 def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_NONE, norm=NORM_NONE, mul=None,
              res=None, res_scale=1.0, res_first=False, y_pre=None, shuffle=False, transposed=False, out=None, out_hw=None,
-             xs=None, xs_act=ACT_NONE, xs_pre=False, w2=None, bias2=None, pre_deriv=False, res_gate=None):
+             xs=None, xs_act=ACT_NONE, xs_pre=False, w2=None, bias2=None, pre_deriv=False, res_gate=None, out_gate=None):
     """One clc_conv2d launch. ``w`` must already be in kernel layout [Cout][ks][ks][Cin]."""
     _require_gpu(x, "conv2d")
     x, xp, N, H, W, Cin, ldx = nhwc(x)
@@ -352,6 +367,10 @@ def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_
             gt, gp, *_r, ldg = nhwc(res_gate[0])
             d.res_gate, d.ldg, d.res_gate_act, d.res_gate_pre = gp, ldg, int(res_gate[1]), int(res_gate[2])
             keep.append(gt)
+    if out_gate is not None:   # (saved tensor, activation, saved-is-pre-activation): whole result *= act'(saved)
+        ot, otp, *_r, ldog = nhwc(out_gate[0])
+        d.out_gate, d.ldog, d.out_gate_act, d.out_gate_pre = otp, ldog, int(out_gate[1]), int(out_gate[2])
+        keep.append(ot)
     if y_pre is not None:
         q, qp, *_r, ldp = nhwc(y_pre)
         assert q is y_pre
@@ -496,7 +515,7 @@ class _ConvFn(Function):
 
     @staticmethod
     def forward(ctx, x, w, b, res, ks, stride, act, res_scale, shuffle, res_first, w2=None, b2=None, fold_in=None, fold_out=None, out_buf=None,
-                grad_slot=None, park_dx=None):
+                grad_slot=None, park_dx=None, gate_in=None, gate_out=None):
         if x.dim() != 4 or x.shape[1] != w.shape[1]:
             # (the kernels take Cin from the activation: a mismatch would walk off the end of the filter buffer)
             raise _lib.ClcError(f"conv2d: input {tuple(x.shape)} does not match the filter {tuple(w.shape)} (expected {w.shape[1]} input channels)")
@@ -523,6 +542,10 @@ class _ConvFn(Function):
         ctx.cfg = (ks, stride, ACT_SAVED_DERIV if deriv else act, res_scale, shuffle, b is not None, res is not None, res_first)
         saved_act = y_pre if save_pre else (y if act in (ACT_LRELU, ACT_RELU, ACT_HALFTANH) else None)
         ctx.use_pre = save_pre
+        ctx.gates = (gate_in, gate_out)
+        if gate_out is not None and need_grad and act in (ACT_LRELU, ACT_RELU, ACT_GELU) and res is None:
+            # what the consumer's data-gradient epilogue needs to apply this layer's activation derivative
+            gate_out.saved, gate_out.act, gate_out.pre = saved_act, (ACT_SAVED_DERIV if deriv else act), save_pre
         ctx.bias_ref = b
         ctx.pair = (w2, b2)
         ctx.grad_slot = grad_slot   # (GradSlots, total channels, offset): where the data gradient is to be written
@@ -563,6 +586,9 @@ class _ConvFn(Function):
         # pass) unless the unshuffle copy or a pre-activation residual needs dz materialised
         # (only for the one-instruction derivatives; GELU arrives here as ACT_SAVED_DERIV: its derivative was stored forward)
         fold_in, fold_out = ctx.folds
+        gate_in, gate_out = ctx.gates
+        if gate_out is not None and gate_out.done:
+            act = ACT_NONE          # the consumer's data-gradient kernel already multiplied dy by this layer's activation derivative
         # residual added BEFORE the activation (ResidualUnit): d(res) = dy * act'(out).  When the branch's first layer will fold it
         # into its data-gradient epilogue, park the RAW dy with the gate and skip the activation-backward pass altogether
         gate_park = (need_res and res_first and not shuffle and act in (ACT_LRELU, ACT_RELU) and fold_out is not None
@@ -606,26 +632,31 @@ class _ConvFn(Function):
             extra, extra_scale, gate = fold_in.take() if fold_in is not None else (None, 1.0, None)
             gs = ctx.grad_slot
             dx_out = gs[0].view(x, gs[1], gs[2], x.shape[1]) if gs is not None else None
+            og = None
+            if gate_in is not None and gate_in.saved is not None and extra is None and ctx.park_dx is None:
+                # this layer is the only consumer of the producer's activated output: hand it d(pre-activation)
+                og = (gate_in.saved, gate_in.act, gate_in.pre)
+                gate_in.done = True
             dx = conv_raw(dz, wt_of(w), None, ks=ks, stride=stride, pad=pad, transposed=True, out_hw=(x.shape[2], x.shape[3]),
-                          w2=(wt_of(w2) if w2 is not None else None), res=extra, res_scale=extra_scale, res_gate=gate, out=dx_out, **fa)
+                          w2=(wt_of(w2) if w2 is not None else None), res=extra, res_scale=extra_scale, res_gate=gate, out=dx_out, out_gate=og, **fa)
         elif fold_in is not None:
             fold_in.consumed = True
         if dx is not None and ctx.park_dx is not None and ctx.park_dx.park(dx):
             dx = None
-        return dx, dw, db, dres, None, None, None, None, None, None, dw2, db2, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, dw2, db2, None, None, None, None, None, None, None
 
 
 def conv2d(x, w, b=None, *, stride=1, act=ACT_NONE, res=None, res_scale=1.0, shuffle=False, res_first=False, w2=None, b2=None,
-           fold_in=None, fold_out=None, out=None, grad_slot=None, park_dx=None):
+           fold_in=None, fold_out=None, out=None, grad_slot=None, park_dx=None, gate_in=None, gate_out=None):
     """out: optional destination (a pixel-major view, e.g. a channel slice of a wider buffer) written in place."""
     ks = w.shape[2] if w.dim() == 4 else 1
     return _ConvFn.apply(x, w, b, res, ks, stride, act, float(res_scale), bool(shuffle), bool(res_first), w2, b2, fold_in, fold_out, out,
-                         grad_slot, park_dx)
+                         grad_slot, park_dx, gate_in, gate_out)
 
 
-def linear(x, w, b=None, *, act=ACT_NONE, res=None, w2=None, b2=None, fold_in=None, fold_out=None, out=None):
+def linear(x, w, b=None, *, act=ACT_NONE, res=None, w2=None, b2=None, fold_in=None, fold_out=None, out=None, gate_in=None, gate_out=None):
     """nn.Linear on channels (tokens are pixels): x [N,Cin,H,W] pixel-major, w [Cout,Cin]."""
-    return _ConvFn.apply(x, w, b, res, 1, 1, act, 1.0, False, False, w2, b2, fold_in, fold_out, out)
+    return _ConvFn.apply(x, w, b, res, 1, 1, act, 1.0, False, False, w2, b2, fold_in, fold_out, out, None, None, gate_in, gate_out)
 
 
 class _CatHalvesFn(Function):

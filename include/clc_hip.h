@@ -92,6 +92,11 @@ typedef struct {
    * kernel add the gradient of a residual branch that passed through an activation (ResidualUnit: relu(conv(..) + x)) without a
    * separate activation-backward pass */
   const float* res_gate; int ldg; int res_gate_act; int res_gate_pre;
+  /* optional gate on the whole result: y *= act'(out_gate) — a data-gradient kernel hands the PRODUCING layer its gradient
+   * already multiplied by that layer's activation derivative (out_gate = the producer's activated output, i.e. this layer's
+   * forward input, for LeakyReLU / ReLU; the stored derivative for GELU), so the producer's own gradient kernels need no
+   * operand prologue (and run on the LDS-DMA path). */
+  const float* out_gate; int ldog; int out_gate_act; int out_gate_pre;
 } clc_conv_desc;
 
 int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream);

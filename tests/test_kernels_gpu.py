@@ -618,3 +618,45 @@ def test_convtransblock_and_swatten_vs_reference_golden(dev):
         ys = swa.to(dev)(_dev(torch.from_numpy(g["swatten_x"]), dev)).cpu()
     _close(yc, torch.from_numpy(g["ctb_y"]), 2e-5, "ConvTransBlock vs reference class")
     _close(ys, torch.from_numpy(g["swatten_y"]), 2e-5, "SWAtten vs reference class")
+
+
+@pytest.mark.parametrize("kind", ["lrelu3x3", "relu1x1", "gelu_linear", "subpel_lrelu", "big_lrelu"])
+def test_activation_gate_in_consumer_dgrad(dev, kind):
+    """ops.ActGate: z = conv_b(act(conv_a(x))) — conv_b's data-gradient epilogue multiplies by act'(.), conv_a's gradient kernels then
+    run without an operand prologue.  Every gradient against plain torch autograd, and bit-identical forward with / without gates."""
+    from clc_amd import ops
+
+    if kind == "big_lrelu":
+        N, C, H, W = 4, 64, 128, 128     # conv_a's data gradient on the 128-row LDS-DMA tile
+    else:
+        N, C, H, W = 2, 64, 32, 32
+    act = {"lrelu3x3": 1, "relu1x1": 2, "gelu_linear": 3, "subpel_lrelu": 1, "big_lrelu": 1}[kind]
+    ks = 1 if kind in ("relu1x1", "gelu_linear") else 3
+    shuffle = kind == "subpel_lrelu"
+    Ca = 4 * C if shuffle else C
+    x = _rand((N, C, H, W), 1)
+    wa = _rand((Ca, C, ks, ks), 2, (1.0 / (C * ks * ks)) ** 0.5)
+    ba = _rand((Ca,), 3, 0.1)
+    wb = _rand((96, C, 3, 3), 4, (1.0 / (C * 9)) ** 0.5)
+    bb = _rand((96,), 5, 0.1)
+    ref_in = [t.clone().requires_grad_() for t in (x, wa, ba, wb, bb)]
+    t = F.conv2d(ref_in[0], ref_in[1], ref_in[2], padding=ks // 2)
+    if shuffle:
+        t = F.pixel_shuffle(t, 2)
+    a = {1: lambda v: F.leaky_relu(v, 0.01), 2: F.relu, 3: F.gelu}[act](t)
+    ref = F.conv2d(a, ref_in[3], ref_in[4], padding=1)
+    gy = _rand(ref.shape, 6)
+    ref.backward(gy)
+    outs = {}
+    for gated in (True, False):
+        d = [_dev(t_, dev, grad=True) for t_ in (x, wa, ba, wb, bb)]
+        g = ops.ActGate() if gated else None
+        ya = ops.conv2d(d[0], d[1], d[2], act=act, shuffle=shuffle, gate_out=g)
+        y = ops.conv2d(ya, d[3], d[4], gate_in=g)
+        y.backward(_dev(gy, dev))
+        assert (g.done if gated else True)
+        outs[gated] = (y.detach(), [t_.grad for t_ in d])
+        _close(y, ref, 3e-5, f"{kind} fwd")
+        for name, got, want in zip(("dx", "dwa", "dba", "dwb", "dbb"), outs[gated][1], [r.grad for r in ref_in]):
+            _close(got, want, 2e-4, f"{kind} gated={gated} {name}")
+    assert torch.equal(outs[True][0], outs[False][0])
