@@ -233,6 +233,9 @@ class GradFold:
         return g, s, gate
 
 
+ACT_GATES = int(os.environ.get("CLC_ACT_GATE", "1"))   # 0: every layer applies its own activation derivative (A/B knob)
+
+
 class ActGate:
     """Hands a layer's activation derivative to the ONE convolution that consumes its output.
 
@@ -543,9 +546,11 @@ class _ConvFn(Function):
         saved_act = y_pre if save_pre else (y if act in (ACT_LRELU, ACT_RELU, ACT_HALFTANH) else None)
         ctx.use_pre = save_pre
         ctx.gates = (gate_in, gate_out)
-        if gate_out is not None and need_grad and act in (ACT_LRELU, ACT_RELU, ACT_GELU) and res is None:
-            # what the consumer's data-gradient epilogue needs to apply this layer's activation derivative
-            gate_out.saved, gate_out.act, gate_out.pre = saved_act, (ACT_SAVED_DERIV if deriv else act), save_pre
+        if gate_out is not None and ACT_GATES and need_grad and act in (ACT_LRELU, ACT_RELU, ACT_GELU) and res is None:
+            # what the consumer's data-gradient epilogue needs to apply this layer's activation derivative.  detach(): a plain alias
+            # without grad_fn — the gate must not close a reference cycle y -> grad_fn -> ctx -> gate -> y (the activations would
+            # then live until a garbage-collection pass instead of until the backward pass has used them)
+            gate_out.saved, gate_out.act, gate_out.pre = saved_act.detach(), (ACT_SAVED_DERIV if deriv else act), save_pre
         ctx.bias_ref = b
         ctx.pair = (w2, b2)
         ctx.grad_slot = grad_slot   # (GradSlots, total channels, offset): where the data gradient is to be written

@@ -639,11 +639,13 @@ def test_activation_gate_in_consumer_dgrad(dev, kind):
     ba = _rand((Ca,), 3, 0.1)
     wb = _rand((96, C, 3, 3), 4, (1.0 / (C * 9)) ** 0.5)
     bb = _rand((96,), 5, 0.1)
+    with torch.no_grad():   # the kernel's own activated output decides which side of 0 a pre-activation of ~1e-8 falls on (see test_conv_fwd_bwd)
+        ya_gpu = ops.conv2d(_dev(x, dev), _dev(wa, dev), _dev(ba, dev), act=act, shuffle=shuffle).cpu()
     ref_in = [t.clone().requires_grad_() for t in (x, wa, ba, wb, bb)]
     t = F.conv2d(ref_in[0], ref_in[1], ref_in[2], padding=ks // 2)
     if shuffle:
         t = F.pixel_shuffle(t, 2)
-    a = {1: lambda v: F.leaky_relu(v, 0.01), 2: F.relu, 3: F.gelu}[act](t)
+    a = {1: lambda v: torch.where(ya_gpu > 0, v, 0.01 * v), 2: lambda v: torch.where(ya_gpu > 0, v, 0.0 * v), 3: F.gelu}[act](t)
     ref = F.conv2d(a, ref_in[3], ref_in[4], padding=1)
     gy = _rand(ref.shape, 6)
     ref.backward(gy)
