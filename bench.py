@@ -289,11 +289,20 @@ def main():
             raise SystemExit("--gpus N>1 must be launched as: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    # Rehearsal knobs (one-GPU box): CLC_SINGLE_DEVICE=1 puts every rank on cuda:0 and CLC_DIST_BACKEND=gloo exchanges the gradients
+    # through gloo — RCCL refuses two ranks on one device — so the multi-rank step structure (graphs A1 | exchange | A2 | exchange | B)
+    # can be exercised with real kernels.  The driver's runs use neither: one rank per GPU over RCCL.
+    if os.environ.get("CLC_SINGLE_DEVICE", "0") == "1":
+        local_rank = 0
+    backend = os.environ.get("CLC_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from clc_amd import models
     from clc_amd.train import TrainEngine, broadcast_parameters
@@ -339,7 +348,8 @@ def main():
         "config": {"workload": f"CLC N=64 lambda={args.lmbda} MSE, {args.size}x{args.size} bs{args.batch}/GPU, n_refs={args.n_refs}: "
                                "fwd + RD loss + bwd + clip_grad_norm + AdamW + aux step (configs[1])",
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "ranks_seen": (dist.get_world_size() if world > 1 else 1),
-                   "collective": ("RCCL all-reduce of the flat fp32 gradient arena (64 MiB buckets), overlapped with the analysis-transform backward"
+                   "collective": ((("RCCL" if backend == "nccl" else backend) + " all-reduce of the flat fp32 gradient arena (64 MiB buckets) in two phases: everything "
+                                   "downstream of the encoders goes on the wire while the analysis-transform / reference-encoder backward runs")
                                   if world > 1 else "none"), "hip_graph": not args.no_graph, "final_loss": loss},
     }
     if not args.no_roofline:  # every rank runs it (the eager step contains the gradient all-reduce); rank 0 reports

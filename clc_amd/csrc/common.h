@@ -12,7 +12,9 @@ void clc_set_error(const char* fmt, ...);
 
 // Process-wide tuning switches (clc_set_tuning): A/B knobs that select between kernel variants computing the SAME bits.
 enum { CLC_TUNE_DMA_LOOP = 0 /* 1: conv_igemm_dma_kernel, 2: conv_igemm_dma2_kernel (re-timed K loop) */, CLC_TUNE_WGRAD_STREAMK = 1,
-       CLC_TUNE_DMA_PLACE = 2 /* dma2 kernel: 1 = DMA pieces at the top of the K iteration, 0 = between the MFMA groups */, CLC_TUNE_SK_HALF = 3 /* stream-K grids of one workgroup per CU */, CLC_TUNE_COUNT = 16 };
+       CLC_TUNE_DMA_PLACE = 2 /* dma2 kernel: 1 = DMA pieces at the top of the K iteration, 0 = between the MFMA groups */, CLC_TUNE_SK_HALF = 3 /* stream-K grids of one workgroup per CU */,
+       CLC_TUNE_SPLITK_PIX = 4 /* per-image map size up to which the split-K conv family is used (>= 256) */, CLC_TUNE_SPLITK_MAXC = 5 /* ... for at most this many output channels */,
+       CLC_TUNE_COUNT = 16 };
 extern int clc_tuning[CLC_TUNE_COUNT];
 
 #define CLC_CHECK(cond, ...)            \

@@ -1049,14 +1049,18 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   // summation order — hence its bits — is the same in any batch.
   const int img_pix = (d->transposed && d->stride == 2) ? (d->OH / 2) * (d->OW / 2) : d->OH * d->OW;
   const int C = d->Cout;
-  if (img_pix <= 256) {
+  // Maps up to 32x32 with few channels are latency-bound the same way (a 64 -> 64 3x3 at 8x32x32 is 128 tiles of 64x64: half the
+  // CUs, one 18-K-tile MFMA chain per wave): tuning key CLC_TUNE_SPLITK_PIX moves them to the split-K family too.
+  const int splitk_pix = clc_tuning[CLC_TUNE_SPLITK_PIX] > 0 ? clc_tuning[CLC_TUNE_SPLITK_PIX] : 256;
+  const bool small_map = img_pix <= 256 || (img_pix <= splitk_pix && C <= clc_tuning[CLC_TUNE_SPLITK_MAXC]);
+  if (small_map) {
     // Heavy data gradients of the slice loop (3x3, 224 -> 448..768 on the stacked batch): enough 64x64 tiles to fill the
     // chip without splitting K, and the LDS-tiled kernel shares each operand tile among 4 waves where the split-K family
     // re-fetches fragments per wave (224 -> 704 @ 4096 rows: 192 -> 130 us).  Data gradients exist in training only, so the
     // codec path's batch-invariant family rule is untouched.  (The forward layers of the same nets measured slower this way.)
     static const int heavy_dgrad = getenv("CLC_HEAVY_DGRAD") ? atoi(getenv("CLC_HEAVY_DGRAD")) : 1;   // 0: A/B knob
     static const int heavy_min = getenv("CLC_HEAVY_MIN") ? atoi(getenv("CLC_HEAVY_MIN")) : 60;   // K-tiles (224-channel 3x3: 63); the 36-tile ones measured faster on split-K in the step
-    if (heavy_dgrad && d->transposed && d->ks * d->ks * p.kc_tiles >= heavy_min && C >= 128 &&
+    if (heavy_dgrad && img_pix <= 256 && d->transposed && d->ks * d->ks * p.kc_tiles >= heavy_min && C >= 128 &&
         (long)((p.M + 63) / 64) * ((C + 63) / 64) * classes >= 128)
       return launch<64, 64, 2, 2>(p, classes, st);
     // 32x32 tiles: these layers are bound by how many CUs get MFMA work (f32 MFMA = 64 cycles each), not by operand
