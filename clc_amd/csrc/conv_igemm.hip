@@ -695,10 +695,12 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
 // KW = waves per tile = K-split factor: 8, or 4 for layers of at most 4 K-tiles (1x1 convolutions with Cin <= 128: most of
 // the SWAtten / Swin linears) — half of an 8-wave workgroup would idle there and the wide ones (128 -> 512 on 4096 stacked
 // rows = 1024 tiles) would need 4 rounds of 512-thread workgroups instead of one round of 256-thread ones.
-template <int BN, bool TR, int KW>
-__global__ __launch_bounds__(64 * KW, KW == 8 ? 1 : 2)
+// PF = K-tiles a wave keeps in flight.  KW = 8: PF = 3 needs ~200-256 VGPRs (one 8-wave workgroup per CU); PF = 1 fits 128 (two per
+// CU: the other workgroup's loads cover this one's latency instead of its own prefetch) — CLC_TUNE_SPLITK_PF picks.
+template <int BN, bool TR, int KW, int PF>
+__global__ __launch_bounds__(64 * KW, KW == 8 ? (PF >= 2 ? 1 : 4) : 4)
 void conv_igemm_splitk_kernel(const ConvParams p) {
-  constexpr int BM = 32, TN = BN / 32, PF = (KW == 4) ? 1 : 3;   // PF = K-tiles prefetched per wave
+  constexpr int BM = 32, TN = BN / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];   // combine buffer [KW][TN][16][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
@@ -864,16 +866,16 @@ int launch(const ConvParams& p, int classes, hipStream_t st) {
   return p.transposed ? launch_t<BM, BN, WM, WN, true>(p, classes, st) : launch_t<BM, BN, WM, WN, false>(p, classes, st);
 }
 
-template <int BN, bool TR, int KW>
+template <int BN, bool TR, int KW, int PF>
 int launch_splitk_t(const ConvParams& p, int classes, hipStream_t st) {
   dim3 grid((p.M + 31) / 32, (p.Cout + BN - 1) / BN, classes);
   const size_t lds = (size_t)KW * (BN / 32) * 16 * 64 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_splitk_kernel<BN, TR, KW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_splitk_kernel<BN, TR, KW, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_splitk_kernel<BN, TR, KW>), grid, dim3(64 * KW), lds, st, p);
+  hipLaunchKernelGGL((conv_igemm_splitk_kernel<BN, TR, KW, PF>), grid, dim3(64 * KW), lds, st, p);
   CLC_LAUNCH_CHECK();
   return (3 << 20) | (KW << 16) | (32 << 3) | (BN >> 5);  // family 3 = conv_igemm_splitk_kernel<BN,TR,KW>
 }
@@ -882,8 +884,10 @@ int launch_splitk(const ConvParams& p, int classes, hipStream_t st) {
   // the K-split factor is a function of the layer shape alone (never of the batch), like the family itself
   static const int kw4 = getenv("CLC_SPLITK_KW4") ? atoi(getenv("CLC_SPLITK_KW4")) : 1;   // 0: always 8 waves (A/B knob)
   if (kw4 && p.ks * p.ks * p.kc_tiles <= 4)
-    return p.transposed ? launch_splitk_t<BN, true, 4>(p, classes, st) : launch_splitk_t<BN, false, 4>(p, classes, st);
-  return p.transposed ? launch_splitk_t<BN, true, 8>(p, classes, st) : launch_splitk_t<BN, false, 8>(p, classes, st);
+    return p.transposed ? launch_splitk_t<BN, true, 4, 1>(p, classes, st) : launch_splitk_t<BN, false, 4, 1>(p, classes, st);
+  if (clc_tuning[CLC_TUNE_SPLITK_PF] == 1)
+    return p.transposed ? launch_splitk_t<BN, true, 8, 1>(p, classes, st) : launch_splitk_t<BN, false, 8, 1>(p, classes, st);
+  return p.transposed ? launch_splitk_t<BN, true, 8, 3>(p, classes, st) : launch_splitk_t<BN, false, 8, 3>(p, classes, st);
 }
 
 // small-Cin (image, Cin<=4, unaligned) direct convolution: one thread per (pixel, 4 output channels)
