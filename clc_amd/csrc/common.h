@@ -15,6 +15,7 @@ enum { CLC_TUNE_DMA_LOOP = 0 /* 1: conv_igemm_dma_kernel, 2: conv_igemm_dma2_ker
        CLC_TUNE_DMA_PLACE = 2 /* dma2 kernel: 1 = DMA pieces at the top of the K iteration, 0 = between the MFMA groups */, CLC_TUNE_SK_HALF = 3 /* stream-K grids of one workgroup per CU */,
        CLC_TUNE_SPLITK_PIX = 4 /* per-image map size up to which the split-K conv family is used (>= 256) */, CLC_TUNE_SPLITK_MAXC = 5 /* ... for at most this many output channels */,
        CLC_TUNE_SPLITK_PF = 6 /* K-tiles in flight per wave of the 8-wave split-K conv kernel: 3 (one workgroup per CU) or 1 (two) */,
+       CLC_TUNE_1X1_TILE = 7 /* large-map 1x1 convolutions with at most this many K-tiles use the 128x64 tile (0: off) */,
        CLC_TUNE_COUNT = 16 };
 extern int clc_tuning[CLC_TUNE_COUNT];
 

@@ -1088,6 +1088,8 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   }
   // 8 waves per tile (4 per SIMD at 2 workgroups/CU): measured +3..15 % over 4 waves on every large-map shape
   // (1x1 128->128 @128^2: 63 -> 73 TF); the summation order per output element does not depend on the wave grid
+  // (CLC_TUNE_1X1_TILE: HBM-bound 1x1 layers with few K-tiles on the narrower tile — 48 KB of LDS, three workgroups per CU)
+  if (clc_tuning[CLC_TUNE_1X1_TILE] && d->ks == 1 && p.kc_tiles <= clc_tuning[CLC_TUNE_1X1_TILE] && C > 32) return launch<128, 64, 4, 2>(p, classes, st);
   if (C % 128 == 0 || C >= 384) return launch<128, 128, 4, 2>(p, classes, st);
   if (C > 32) return launch<128, 64, 4, 2>(p, classes, st);
   return launch<64, 32, 2, 1>(p, classes, st);
