@@ -222,23 +222,30 @@ def roofline_leg(engine, x, refs):
         f, bm, bn = variant >> 20, (variant >> 3) & 0x1FF, (variant & 7) << 5
         if f == 3:
             return f"conv_igemm_splitk_kernel<{bn}, {tr}, {(variant >> 16) & 15}>"
-        return f"conv_igemm{ {1: '', 2: '_dma', 4: '_dma2'}[f]}_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}>"
+        if f in (4, 5):   # family 5 = the 1x1 instantiation (its own symbol)
+            return f"conv_igemm_dma2_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}, {1 if f == 5 else 3}>"
+        return f"conv_igemm{ {1: '', 2: '_dma'}[f]}_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}>"
 
     agg = {}
-    for fam, variant, flops, e0, e1, *_shape in rec:
-        key = kernel_name(fam, variant, _shape[0] if _shape else "")
-        a = agg.setdefault(key, [0.0, 0.0, 0])
+    for fam, variant, flops, e0, e1, *rest in rec:
+        key = kernel_name(fam, variant, rest[0] if rest else "")
+        a = agg.setdefault(key, [0.0, 0.0, 0, 0.0])
         a[0] += flops
         a[1] += max(e0.elapsed_time(e1) * 1e-3 - empty, 1e-7)
         a[2] += 1
+        a[3] += rest[1] if len(rest) > 1 else 0.0
     total_t = sum(a[1] for a in agg.values())
     total_f = sum(a[0] for a in agg.values())
     # the dominant KERNEL by summed time; a stream-K filter-gradient family competes with its algorithmic FLOPs over the time of its
     # main kernel + compact + fix-up launches (the bracket cannot separate them; the fix-up is ~1-3 % of it)
     single = {k: v for k, v in agg.items() if "_kernel<" in k}
     dom = max((single or agg).items(), key=lambda kv: kv[1][1])
-    name, (f, t, n) = dom
-    achieved = f / t / 1e12
+    name, (f, t, n, nb) = dom
+    # the 1x1 / linear instantiation (..., 1>) moves ~50 FLOP per byte on 128-channel layers — under the f32 ridge once the residual and
+    # saved-activation streams are counted — so its roofline is HBM; everything else is MFMA
+    hbm_bound = name.startswith("conv_igemm_dma2_kernel") and name.endswith(", 1>") and nb > 0
+    achieved = (nb / t / 1e9) if hbm_bound else (f / t / 1e12)
+    peak = HBM_PEAK_GBS if hbm_bound else F32_MFMA_PEAK_TFLOPS
     # HBM-side bytes per launch of that kernel from the committed PMC passes (separate `rocprofv3 --pmc FETCH_SIZE` /
     # `--pmc WRITE_SIZE` runs of this same command, gfx950 FETCH_SIZE correction applied: tools/pmc_traffic.py); null when the
     # file does not list the kernel
@@ -250,9 +257,10 @@ def roofline_leg(engine, x, refs):
             traffic = round((k["fetch_bytes_per_step"] + k["write_bytes_per_step"]) / k["launches_per_step"])
     except (OSError, KeyError, ValueError):
         traffic = None
-    table = {k: {"launches": v[2], "gflop": round(v[0] / 1e9, 2), "ms": round(v[1] * 1e3, 3), "tflops": round(v[0] / v[1] / 1e12, 2)} for k, v in agg.items()}
-    return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+    table = {k: {"launches": v[2], "gflop": round(v[0] / 1e9, 2), "ms": round(v[1] * 1e3, 3), "tflops": round(v[0] / v[1] / 1e12, 2),
+                 **({"algorithmic_gb_per_s": round(v[3] / v[1] / 1e9, 1)} if v[3] else {})} for k, v in agg.items()}
+    return {"bound": "hbm" if hbm_bound else "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s" if hbm_bound else "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic,
             "launches_per_step": n, "avg_launch_ms": round(t / n * 1e3, 4), "event_bracket_overhead_ms": round(empty * 1e3, 5),
             "timing_note": "event-bracketed eager step (HIP events cannot be recorded inside a hipGraph on ROCm 7.2), enqueued behind a spin kernel so "
                            "that the launches run back to back as in the graph replay of the timed region; a bracket still adds the timestamp packets' "

@@ -503,7 +503,9 @@ void conv_igemm_dma_kernel(const ConvParams p) {
 //   * group 0's fragments of the next tile are read right after the barrier, two fragment register sets are offered to the
 //     scheduler (hipcc still sinks most reads to just before their first MFMA; pinning the order with sched_group_barrier
 //     did not change that).
-template <int BM, int BN, int WM, int WN, bool TR>
+// KS = 1: the 1x1 / linear instantiation (one tap: no tap grid, no validity mask; its own symbol, so profiles tell the HBM-bound
+// 1x1 layers from the MFMA-bound 3x3 ones); KS = 3: everything else.
+template <int BM, int BN, int WM, int WN, bool TR, int KS>
 __global__ __launch_bounds__(64 * WM * WN, (64 * WM * WN) >= 512 ? 4 : ((64 * WM * WN) >= 256 ? 2 : 4))
 void conv_igemm_dma2_kernel(const ConvParams p) {
   constexpr int NT = 64 * WM * WN;
@@ -520,7 +522,7 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
   const int cls = blockIdx.z, ph = cls >> 1, pw = cls & 1;
   const bool half = p.transposed && p.stride == 2;
   const int DH = half ? p.OH / 2 : p.OH, DW = half ? p.OW / 2 : p.OW;
-  const TapGrid tg = make_taps(p, ph, pw);
+  const TapGrid tg = KS == 1 ? TapGrid{0, 0, 1, 1, 1} : make_taps(p, ph, pw);   // (KS = 1 is dispatched for stride 1 only)
 
   const bool second = p.w2 != nullptr && m0 >= p.group_rows;
   const float* wsel = second ? p.w2 : p.w;
@@ -841,26 +843,28 @@ int launch_dma_t(const ConvParams& p, int classes, hipStream_t st) {
   CLC_LAUNCH_CHECK();
   return (2 << 20) | (WM << 16) | (WN << 12) | (BM << 3) | (BN >> 5);  // family 2 = conv_igemm_dma_kernel<BM,BN,WM,WN>
 }
-template <int BM, int BN, int WM, int WN, bool TR>
+template <int BM, int BN, int WM, int WN, bool TR, int KS>
 int launch_dma2_t(const ConvParams& p, int classes, hipStream_t st) {
   dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, classes);
   constexpr size_t lds_ab = (size_t)2 * (BM + BN) * BK * sizeof(float), lds_c = (size_t)BM * (BN + 4) * sizeof(float);
   constexpr size_t lds = lds_ab > lds_c ? lds_ab : lds_c;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma2_kernel<BM, BN, WM, WN, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma2_kernel<BM, BN, WM, WN, TR, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_dma2_kernel<BM, BN, WM, WN, TR>), grid, dim3(64 * WM * WN), lds, st, p);
+  hipLaunchKernelGGL((conv_igemm_dma2_kernel<BM, BN, WM, WN, TR, KS>), grid, dim3(64 * WM * WN), lds, st, p);
   CLC_LAUNCH_CHECK();
-  return (4 << 20) | (WM << 16) | (WN << 12) | (BM << 3) | (BN >> 5);  // family 4 = conv_igemm_dma2_kernel<BM,BN,WM,WN>
+  return ((KS == 1 ? 5 : 4) << 20) | (WM << 16) | (WN << 12) | (BM << 3) | (BN >> 5);  // family 4 / 5 = conv_igemm_dma2_kernel<BM,BN,WM,WN,TR,3 / 1>
 }
 template <int BM, int BN, int WM, int WN>
 int launch(const ConvParams& p, int classes, hipStream_t st) {
   static const int use_dma = getenv("CLC_DMA") ? atoi(getenv("CLC_DMA")) : 1;   // CLC_DMA=0: register staging everywhere (A/B knob)
   static const int dma_small = getenv("CLC_DMA_SMALL") ? atoi(getenv("CLC_DMA_SMALL")) : 1;
   if (use_dma && p.in_op == CLC_IN_NONE && p.xs == nullptr && (BM >= 128 || dma_small) && clc_tuning[CLC_TUNE_DMA_LOOP] == 2)
-    return p.transposed ? launch_dma2_t<BM, BN, WM, WN, true>(p, classes, st) : launch_dma2_t<BM, BN, WM, WN, false>(p, classes, st);
+    return p.ks == 1 && p.stride == 1
+               ? (p.transposed ? launch_dma2_t<BM, BN, WM, WN, true, 1>(p, classes, st) : launch_dma2_t<BM, BN, WM, WN, false, 1>(p, classes, st))
+               : (p.transposed ? launch_dma2_t<BM, BN, WM, WN, true, 3>(p, classes, st) : launch_dma2_t<BM, BN, WM, WN, false, 3>(p, classes, st));
   if (use_dma && p.in_op == CLC_IN_NONE && p.xs == nullptr && (BM >= 128 || dma_small))   // no input prologue -> the tiles can go straight to LDS
     return p.transposed ? launch_dma_t<BM, BN, WM, WN, true>(p, classes, st) : launch_dma_t<BM, BN, WM, WN, false>(p, classes, st);
   return p.transposed ? launch_t<BM, BN, WM, WN, true>(p, classes, st) : launch_t<BM, BN, WM, WN, false>(p, classes, st);

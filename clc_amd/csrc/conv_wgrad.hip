@@ -23,6 +23,16 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0));
 }
 
+// A kernel-argument scalar behind an opaque move.  The problem descriptors of a grouped launch are indexed dynamically, and the
+// register allocator treats their (invariant) s_loads as free to re-issue: under SGPR pressure it reloaded H, W, ldx ... from
+// memory in front of EVERY buffer load of the K loop, each with an s_waitcnt lgkmcnt(0) (ISA of the r2 stream-K kernels: 16
+// scalar loads per K-tile).  A pinned value lives in an SGPR (or spills to a VGPR lane) instead.
+__device__ __forceinline__ int pin_s(int x) {
+  int r;
+  asm("s_mov_b32 %0, %1" : "=s"(r) : "s"(x));
+  return r;
+}
+
 struct WgradParams {
   const float* x; const float* dy; float* partial; float* bias_partial;
   unsigned x_bytes, dy_bytes;
@@ -58,6 +68,10 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
   const int co0 = by * BM;
   const int ntiles = (k_end - k_begin + BK - 1) / BK;
   const bool do_bias = (o.b != nullptr) && (bx == 0);
+  // everything the K loop reads, pinned (see pin_s)
+  const int pCout = pin_s(p.Cout), pCin = pin_s(p.Cin), pH = pin_s(p.H), pW = pin_s(p.W), pOH = pin_s(p.OH), pOW = pin_s(p.OW);
+  const int plddy = pin_s(p.lddy), plddys = pin_s(p.lddys), pldx = pin_s(p.ldx), pstride = pin_s(p.stride), ppad = pin_s(p.pad);
+  const int pows = pin_s(p.ow_shift), pimgs = pin_s(p.img_shift), pact = pin_s(p.dys_act), ppre = pin_s(p.dys_pre);
 
   f32x4 a_reg[A_P], b_reg[B_P], bias_acc[A_P], s_reg[A_P];
 #pragma unroll
@@ -74,9 +88,9 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
     for (int i = 0; i < A_P; ++i) {
       const int piece = tid + i * NT, row = piece / AQ, q = piece - row * AQ;
       const int pix = kbase + row, co = co0 + q * 4;
-      const bool ok = row < BK && pix < k_end && co < p.Cout;
-      a_reg[i] = buf_load4(dr, ok ? ((unsigned)pix * (unsigned)p.lddy + (unsigned)co) * 4u : kOOB);
-      if (fuse_act) s_reg[i] = buf_load4(sr, ok ? ((unsigned)pix * (unsigned)p.lddys + (unsigned)co) * 4u : kOOB);
+      const bool ok = row < BK && pix < k_end && co < pCout;
+      a_reg[i] = buf_load4(dr, ok ? ((unsigned)pix * (unsigned)plddy + (unsigned)co) * 4u : kOOB);
+      if (fuse_act) s_reg[i] = buf_load4(sr, ok ? ((unsigned)pix * (unsigned)plddys + (unsigned)co) * 4u : kOOB);
     }
 #pragma unroll
     for (int i = 0; i < B_P; ++i) {
@@ -84,25 +98,25 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
       const int pix = kbase + row, ci = ci0 + q * 4;
       const int pp = pix < k_end ? pix : k_begin;
       int n, oy, ox;
-      if (p.ow_shift >= 0) {   // block-uniform: every map of a 2^k-sized image is a power of two
-        n = pp >> p.img_shift;
-        const int r = pp & ((1 << p.img_shift) - 1);
-        oy = r >> p.ow_shift; ox = r & ((1 << p.ow_shift) - 1);
+      if (pows >= 0) {   // block-uniform: every map of a 2^k-sized image is a power of two
+        n = pp >> pimgs;
+        const int r = pp & ((1 << pimgs) - 1);
+        oy = r >> pows; ox = r & ((1 << pows) - 1);
       } else {
-        n = pp / (p.OH * p.OW);
-        const int r = pp - n * (p.OH * p.OW);
-        oy = r / p.OW; ox = r - oy * p.OW;
+        n = pp / (pOH * pOW);
+        const int r = pp - n * (pOH * pOW);
+        oy = r / pOW; ox = r - oy * pOW;
       }
-      const int iy = oy * p.stride - p.pad + kh, ix = ox * p.stride - p.pad + kw;
-      const bool ok = row < BK && pix < k_end && ci < p.Cin && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      b_reg[i] = buf_load4(xr, ok ? ((unsigned)((n * p.H + iy) * p.W + ix) * (unsigned)p.ldx + (unsigned)ci) * 4u : kOOB);
+      const int iy = oy * pstride - ppad + kh, ix = ox * pstride - ppad + kw;
+      const bool ok = row < BK && pix < k_end && ci < pCin && (unsigned)iy < (unsigned)pH && (unsigned)ix < (unsigned)pW;
+      b_reg[i] = buf_load4(xr, ok ? ((unsigned)((n * pH + iy) * pW + ix) * (unsigned)pldx + (unsigned)ci) * 4u : kOOB);
     }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
       const int piece = tid + i * NT, row = piece / AQ, q = piece - row * AQ;
-      if (fuse_act) a_reg[i] = a_reg[i] * act_deriv4(s_reg[i], p.dys_act, p.dys_pre);
+      if (fuse_act) a_reg[i] = a_reg[i] * act_deriv4(s_reg[i], pact, ppre);
       if (row < BK) *reinterpret_cast<f32x4*>(As + (buf * BK + row) * BM + q * 4) = a_reg[i];
       if (do_bias) bias_acc[i] += a_reg[i];
     }
@@ -214,8 +228,11 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int 
   const int ci0 = bx * 64, co0 = by * 64;
   const int ntiles = t_end - t_begin;
   const bool do_bias = (o.b != nullptr) && (bx == 0);
-  const int lcols = p.ow_shift - LTW;                       // log2(tile columns per image row)
-  const int lrows = (p.img_shift - p.ow_shift) - (5 - LTW); // log2(tile rows per image)
+  const int lcols = pin_s(p.ow_shift - LTW);                       // log2(tile columns per image row)
+  const int lrows = pin_s((p.img_shift - p.ow_shift) - (5 - LTW)); // log2(tile rows per image)
+  // everything the K loop reads, pinned (see pin_s)
+  const int pCout = pin_s(p.Cout), pCin = pin_s(p.Cin), pH = pin_s(p.H), pW = pin_s(p.W), pOH = pin_s(p.OH), pOW = pin_s(p.OW);
+  const int plddy = pin_s(p.lddy), plddys = pin_s(p.lddys), pldx = pin_s(p.ldx), pact = pin_s(p.dys_act), ppre = pin_s(p.dys_pre);
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
@@ -231,26 +248,26 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int 
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int piece = tid + i * 256, row = piece >> 4, q = piece & 15;
-      const int pix = (n * p.OH + oy0 + (row >> LTW)) * p.OW + ox0 + (row & (TW - 1));
+      const int pix = (n * pOH + oy0 + (row >> LTW)) * pOW + ox0 + (row & (TW - 1));
       const int co = co0 + q * 4;
-      const bool ok = co < p.Cout;
-      a_reg[i] = buf_load4(dr, ok ? ((unsigned)pix * (unsigned)p.lddy + (unsigned)co) * 4u : kOOB);
-      if (fuse_act) s_reg[i] = buf_load4(sr, ok ? ((unsigned)pix * (unsigned)p.lddys + (unsigned)co) * 4u : kOOB);
+      const bool ok = co < pCout;
+      a_reg[i] = buf_load4(dr, ok ? ((unsigned)pix * (unsigned)plddy + (unsigned)co) * 4u : kOOB);
+      if (fuse_act) s_reg[i] = buf_load4(sr, ok ? ((unsigned)pix * (unsigned)plddys + (unsigned)co) * 4u : kOOB);
     }
 #pragma unroll
     for (int i = 0; i < X_P; ++i) {
       const int piece = tid + i * 256, xp = piece >> 4, q = piece & 15;
       const int wy = xp / XW, wx = xp - wy * XW;
       const int iy = oy0 + wy - 1, ix = ox0 + wx - 1, ci = ci0 + q * 4;
-      const bool ok = xp < XP && ci < p.Cin && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      x_reg[i] = buf_load4(xr, ok ? ((unsigned)((n * p.H + iy) * p.W + ix) * (unsigned)p.ldx + (unsigned)ci) * 4u : kOOB);
+      const bool ok = xp < XP && ci < pCin && (unsigned)iy < (unsigned)pH && (unsigned)ix < (unsigned)pW;
+      x_reg[i] = buf_load4(xr, ok ? ((unsigned)((n * pH + iy) * pW + ix) * (unsigned)pldx + (unsigned)ci) * 4u : kOOB);
     }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int piece = tid + i * 256;
-      if (fuse_act) a_reg[i] = a_reg[i] * act_deriv4(s_reg[i], p.dys_act, p.dys_pre);
+      if (fuse_act) a_reg[i] = a_reg[i] * act_deriv4(s_reg[i], pact, ppre);
       *reinterpret_cast<f32x4*>(As + buf * 32 * 64 + piece * 4) = a_reg[i];
       if (do_bias) bias_acc[i] += a_reg[i];
     }

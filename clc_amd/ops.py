@@ -391,8 +391,12 @@ def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_
         variant = _lib.check(_L().clc_conv2d(C.byref(d), _stream()), "clc_conv2d")
         e1.record()
         pix = N * H * W if transposed else N * OH * OW
+        opix = N * OH * OW
+        # algorithmic HBM bytes of the launch: operand read once, result written once, every epilogue tensor once
+        nbytes = 4.0 * (N * H * W * Cin + Cout * ks * ks * Cin
+                        + opix * Cout * (1 + (res is not None) + (mul is not None) + (y_pre is not None) + (out_gate is not None)))
         PROFILE.append(("conv_igemm" if variant != 1 else "conv_direct_small", variant, 2.0 * pix * ks * ks * Cin * Cout, e0, e1,
-                        f"{'dgrad' if transposed else 'fwd'} {Cin}->{Cout} k{ks} s{stride} {N}x{H}x{W}" + (" +actbwd" if xs is not None else "")))
+                        f"{'dgrad' if transposed else 'fwd'} {Cin}->{Cout} k{ks} s{stride} {N}x{H}x{W}" + (" +actbwd" if xs is not None else ""), nbytes))
     return out
 
 
