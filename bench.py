@@ -187,6 +187,7 @@ def roofline_leg(engine, x, refs):
     """One eager (non-graph) step with every conv / wgrad launch bracketed by HIP events on its launch stream."""
     import torch
 
+    from clc_amd import lib as _clib
     from clc_amd import ops
 
     torch.cuda.synchronize()
@@ -208,6 +209,10 @@ def roofline_leg(engine, x, refs):
         rec = ops.PROFILE
     finally:
         ops.PROFILE = None
+    _L = _clib.load()
+    splitk_pf = _L.clc_set_tuning(6, 1)
+    _L.clc_set_tuning(6, splitk_pf)
+
     def kernel_name(fam, variant, shape):
         """the name rocprofv3 --kernel-trace reports for this launch (template arguments from the C ABI's variant id)"""
         if fam == "conv_wgrad_group":   # one kernel family of a grouped stream-K filter-gradient call (+ its compact / fix-up launches)
@@ -220,8 +225,9 @@ def roofline_leg(engine, x, refs):
             return fam   # conv_direct_small / single (non-deferred) wgrad calls
         tr = "true" if str(shape).startswith("dgrad") else "false"
         f, bm, bn = variant >> 20, (variant >> 3) & 0x1FF, (variant & 7) << 5
-        if f == 3:
-            return f"conv_igemm_splitk_kernel<{bn}, {tr}, {(variant >> 16) & 15}>"
+        if f == 3:   # <BN, TR, KW, PF>: 4-wave tiles keep one K-tile in flight, 8-wave ones CLC_TUNE_SPLITK_PF (key 6)
+            kw = (variant >> 16) & 15
+            return f"conv_igemm_splitk_kernel<{bn}, {tr}, {kw}, {1 if kw == 4 or splitk_pf == 1 else 3}>"
         if f in (4, 5):   # family 5 = the 1x1 instantiation (its own symbol)
             return f"conv_igemm_dma2_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}, {1 if f == 5 else 3}>"
         return f"conv_igemm{ {1: '', 2: '_dma'}[f]}_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}>"

@@ -396,7 +396,10 @@ def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_
         nbytes = 4.0 * (N * H * W * Cin + Cout * ks * ks * Cin
                         + opix * Cout * (1 + (res is not None) + (mul is not None) + (y_pre is not None) + (out_gate is not None)))
         PROFILE.append(("conv_igemm" if variant != 1 else "conv_direct_small", variant, 2.0 * pix * ks * ks * Cin * Cout, e0, e1,
-                        f"{'dgrad' if transposed else 'fwd'} {Cin}->{Cout} k{ks} s{stride} {N}x{H}x{W}" + (" +actbwd" if xs is not None else ""), nbytes))
+                        f"{'dgrad' if transposed else 'fwd'} {Cin}->{Cout} k{ks} s{stride} {N}x{H}x{W}" + (" +actbwd" if xs is not None else "")
+                        + "".join(t for t, on in ((" b", bias is not None), (f" a{act}", act != ACT_NONE), (" res", res is not None), (" mul", mul is not None),
+                                                  (" pre", y_pre is not None), (" rg", res_gate is not None), (" og", out_gate is not None), (" w2", w2 is not None)) if on),
+                        nbytes))
     return out
 
 

@@ -9,7 +9,7 @@ import torch
 from bench import synthetic_batch
 from clc_amd import models, ops
 from clc_amd.train import TrainEngine
-from oracle.recipe import apply_weight_recipe
+from clc_amd.recipe import apply_weight_recipe
 
 
 def main():
@@ -29,15 +29,17 @@ def main():
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
     agg = {}
-    for fam, variant, flops, e0, e1, shape in rec:
-        a = agg.setdefault((shape, variant), [0, 0.0, 0.0])
+    for fam, variant, flops, e0, e1, shape, *rest in rec:
+        nbytes = rest[0] if rest else 0
+        a = agg.setdefault((shape, variant), [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += e0.elapsed_time(e1)
         a[2] += flops
+        a[3] += nbytes or 0
     tot = sum(a[1] for a in agg.values())
     print(f"total conv-launch time {tot:.2f} ms over {sum(a[0] for a in agg.values())} launches (eager, event-bracketed: includes ~launch gaps)")
-    for (shape, variant), (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
-        print(f"{ms:7.3f} ms  n={n:3d}  {ms / n * 1e3:7.1f} us  {fl / ms / 1e9:6.1f} TF  v{variant:<6d} {shape}")
+    for (shape, variant), (n, ms, fl, nb) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:90]:
+        print(f"{ms:7.3f} ms  n={n:3d}  {ms / n * 1e3:7.1f} us  {fl / ms / 1e9:6.1f} TF  {nb / ms / 1e6:6.0f} GB/s  v{variant:<6d} {shape}")
 
 
 if __name__ == "__main__":
