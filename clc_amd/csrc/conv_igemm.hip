@@ -55,7 +55,8 @@ struct ConvParams {
   unsigned x_bytes, w_bytes;
   const float* xs; int ldxs, xs_act, xs_pre; unsigned xs_bytes;   // fused activation backward on the gathered operand
   int vec_epi;                 // every epilogue operand is 16-B addressable per 4 channels -> float4 epilogue
-  const float* w2; const float* bias2; int group_rows;   // rows >= group_rows (second half of the batch) use w2 / bias2
+  const float* w2; const float* bias2; int group_rows;   // rows [k * group_rows, (k + 1) * group_rows) use filter set k: w, w2, w3, w4
+  const float* w3; const float* bias3; const float* w4; const float* bias4;
   int pre_deriv;               // y_pre <- act'(v) instead of v
   const float* res_gate; int ldg, rg_act, rg_pre;   // residual term *= act'(res_gate)
   const float* out_gate; int ldog, og_act, og_pre;   // whole result *= act'(out_gate)
@@ -228,9 +229,9 @@ void conv_igemm_kernel(const ConvParams p) {
   const int DH = half ? p.OH / 2 : p.OH, DW = half ? p.OW / 2 : p.OW;
   const TapGrid tg = make_taps(p, ph, pw);
 
-  const bool second = p.w2 != nullptr && m0 >= p.group_rows;   // block-uniform: tiles never straddle the two batch halves
-  const float* wsel = second ? p.w2 : p.w;
-  const float* bsel = second ? p.bias2 : p.bias;
+  const int fset = p.group_rows ? min(m0 / p.group_rows, 3) : 0;   // block-uniform: tiles never straddle two filter sets
+  const float* wsel = fset == 0 ? p.w : (fset == 1 ? p.w2 : (fset == 2 ? p.w3 : p.w4));
+  const float* bsel = fset == 0 ? p.bias : (fset == 1 ? p.bias2 : (fset == 2 ? p.bias3 : p.bias4));
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wsel), 0, p.w_bytes, 0x00020000);
 
@@ -377,9 +378,9 @@ void conv_igemm_dma_kernel(const ConvParams p) {
   const int DH = half ? p.OH / 2 : p.OH, DW = half ? p.OW / 2 : p.OW;
   const TapGrid tg = make_taps(p, ph, pw);
 
-  const bool second = p.w2 != nullptr && m0 >= p.group_rows;
-  const float* wsel = second ? p.w2 : p.w;
-  const float* bsel = second ? p.bias2 : p.bias;
+  const int fset = p.group_rows ? min(m0 / p.group_rows, 3) : 0;   // block-uniform: tiles never straddle two filter sets
+  const float* wsel = fset == 0 ? p.w : (fset == 1 ? p.w2 : (fset == 2 ? p.w3 : p.w4));
+  const float* bsel = fset == 0 ? p.bias : (fset == 1 ? p.bias2 : (fset == 2 ? p.bias3 : p.bias4));
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wsel), 0, p.w_bytes, 0x00020000);
 
@@ -537,9 +538,9 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
   const int DH = half ? p.OH / 2 : p.OH, DW = half ? p.OW / 2 : p.OW;
   const TapGrid tg = KS == 1 ? TapGrid{0, 0, 1, 1, 1} : make_taps(p, ph, pw);   // (KS = 1 is dispatched for stride 1 only)
 
-  const bool second = p.w2 != nullptr && m0 >= p.group_rows;
-  const float* wsel = second ? p.w2 : p.w;
-  const float* bsel = second ? p.bias2 : p.bias;
+  const int fset = p.group_rows ? min(m0 / p.group_rows, 3) : 0;   // block-uniform: tiles never straddle two filter sets
+  const float* wsel = fset == 0 ? p.w : (fset == 1 ? p.w2 : (fset == 2 ? p.w3 : p.w4));
+  const float* bsel = fset == 0 ? p.bias : (fset == 1 ? p.bias2 : (fset == 2 ? p.bias3 : p.bias4));
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wsel), 0, p.w_bytes, 0x00020000);
 
@@ -726,9 +727,9 @@ void conv_igemm_splitk_kernel(const ConvParams p) {
   const int DH = half ? p.OH / 2 : p.OH, DW = half ? p.OW / 2 : p.OW;
   const TapGrid tg = make_taps(p, ph, pw);
 
-  const bool second = p.w2 != nullptr && m0 >= p.group_rows;   // block-uniform
-  const float* wsel = second ? p.w2 : p.w;
-  const float* bsel = second ? p.bias2 : p.bias;
+  const int fset = p.group_rows ? min(m0 / p.group_rows, 3) : 0;   // block-uniform: tiles never straddle two filter sets
+  const float* wsel = fset == 0 ? p.w : (fset == 1 ? p.w2 : (fset == 2 ? p.w3 : p.w4));
+  const float* bsel = fset == 0 ? p.bias : (fset == 1 ? p.bias2 : (fset == 2 ? p.bias3 : p.bias4));
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wsel), 0, p.w_bytes, 0x00020000);
 
@@ -1052,12 +1053,19 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   p.res_gate = d->res ? d->res_gate : nullptr; p.ldg = d->ldg; p.rg_act = d->res_gate_act; p.rg_pre = d->res_gate_pre;
   p.out_gate = d->out_gate; p.ldog = d->ldog; p.og_act = d->out_gate_act; p.og_pre = d->out_gate_pre;
   CLC_CHECK(!d->out_gate || !d->shuffle, "clc_conv2d: out_gate with shuffle");
-  if (d->w2) {   // second half of the batch on a second filter set; rows are image-major, so the halves split at M/2
-    CLC_CHECK(d->N % 2 == 0, "clc_conv2d: w2 needs an even batch (got N=%d)", d->N);
-    CLC_CHECK((d->bias == nullptr) == (d->bias2 == nullptr), "clc_conv2d: bias / bias2 must both be given or both NULL");
-    CLC_CHECK(aligned16(d->w2) && (d->Cin % 4 == 0) && (d->ldx % 4 == 0), "clc_conv2d: w2 needs the aligned (Cin %% 4 == 0) path");
-    p.group_rows = p.M / 2;
-    CLC_CHECK(p.group_rows % 128 == 0, "clc_conv2d: w2 needs (N/2)*rows-per-image to be a multiple of the largest tile (128), got %d", p.group_rows);
+  p.w3 = d->w3; p.bias3 = d->bias3; p.w4 = d->w4; p.bias4 = d->bias4;
+  if (d->w2) {   // 2 or 4 filter sets on equal parts of the batch; rows are image-major, so the parts split at multiples of M / sets
+    const int sets = d->w3 ? 4 : 2;
+    CLC_CHECK((d->w3 != nullptr) == (d->w4 != nullptr), "clc_conv2d: w3 and w4 must be given together");
+    CLC_CHECK(d->N % sets == 0, "clc_conv2d: %d filter sets need a batch that is a multiple of %d (got N=%d)", sets, sets, d->N);
+    CLC_CHECK((d->bias == nullptr) == (d->bias2 == nullptr) && (!d->w3 || ((d->bias == nullptr) == (d->bias3 == nullptr) && (d->bias == nullptr) == (d->bias4 == nullptr))),
+              "clc_conv2d: the bias must be given for every filter set or for none");
+    CLC_CHECK(aligned16(d->w2) && (!d->w3 || (aligned16(d->w3) && aligned16(d->w4))) && (d->Cin % 4 == 0) && (d->ldx % 4 == 0),
+              "clc_conv2d: filter sets need the aligned (Cin %% 4 == 0) path");
+    p.group_rows = p.M / sets;
+    CLC_CHECK(p.group_rows % 128 == 0, "clc_conv2d: filter sets need (N/sets)*rows-per-image to be a multiple of the largest tile (128), got %d", p.group_rows);
+  } else {
+    CLC_CHECK(!d->w3 && !d->w4, "clc_conv2d: w3 / w4 without w2");
   }
 
   const bool vec_ok = (d->Cin % 4 == 0) && (d->ldx % 4 == 0) && aligned16(d->x) && aligned16(d->w);

