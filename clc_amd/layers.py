@@ -400,12 +400,15 @@ class SWAtten(AttentionBlock):
             self.non_local_block = SwinBlock(input_dim, input_dim, head_dim, window_size, drop_path)
             self.in_conv = self.out_conv = None
 
-    def forward(self, x, pair=None):
+    def forward(self, x, pair=None, in_fold=None, in_slot=None):
         """pair: a second SWAtten of the same shape; x then holds both inputs stacked along the batch ([2B, C, H, W]) and
-        every convolution / linear of the two modules runs as ONE launch over both halves."""
+        every convolution / linear of the two modules runs as ONE launch over both halves.
+        in_fold / in_slot: GradFold / gradient slot of the first convolution (ops.SliceSupport)."""
         if pair is not None:
             if self.in_conv is not None:
-                x = self.in_conv(x, pair=pair.in_conv)
+                x = self.in_conv(x, pair=pair.in_conv, fold_in=in_fold, grad_slot=in_slot)
+            else:
+                assert in_fold is None and in_slot is None
             def branch_a():
                 a = x
                 for m, q in zip(self.conv_a, pair.conv_a):

@@ -42,13 +42,14 @@ class SliceTransform(nn.Sequential):
     def __init__(self, cin, cout):
         super().__init__(Conv2d(cin, 224, 3), GELU(), Conv2d(224, 128, 3), GELU(), Conv2d(128, cout, 3))
 
-    def forward(self, x, final_act=ACT_NONE, res=None, pair=None):
-        """pair: a second SliceTransform of the same shape for the second half of the batch (one launch per layer)."""
+    def forward(self, x, final_act=ACT_NONE, res=None, pair=None, out=None):
+        """pair: a second SliceTransform of the same shape for the second half of the batch (one launch per layer).
+        out: destination of the result (a channel range of a wider buffer)."""
         q = pair if pair is not None else (None,) * 5
         g0, g1 = ops.ActGate(), ops.ActGate()   # each GELU' (stored forward) rides in the NEXT layer's data-gradient epilogue
         t = self[0](x, act=ACT_GELU, pair=q[0], gate_out=g0)
         t = self[2](t, act=ACT_GELU, pair=q[2], gate_in=g0, gate_out=g1)
-        return self[4](t, act=final_act, res=res, pair=q[4], gate_in=g1)
+        return self[4](t, act=final_act, res=res, pair=q[4], gate_in=g1, out=out)
 
 
 class PointwiseMLP(nn.Sequential):
@@ -158,16 +159,20 @@ class _SliceCodec(CompressionModel):
     def _ref(self, ref_frames):
         return None
 
-    def _slice_params(self, i, latent_means, latent_scales, y_hat_slices, ref_features, y_shape, ref_pair=None):
+    def _slice_params(self, i, latent_means, latent_scales, y_hat_slices, ref_features, y_shape, ref_pair=None, sup=None):
         support = y_hat_slices if self.max_support_slices < 0 else y_hat_slices[: self.max_support_slices]
         rows = latent_means.shape[0] * latent_means.shape[2] * latent_means.shape[3]
         if ops.PAIR_SLICES and rows % 128 == 0:   # (the paired launch needs the batch halves to fall on tile boundaries)
             # The mean- and the scale-parameter nets are the same architecture on different inputs: stack the inputs along
             # the batch and run every layer of the two nets as ONE launch (second half of the batch on the second net's
             # filters).  These 16x16-map layers are latency-bound: twice the rows cost about the same time.
-            both = torch.cat((torch.cat([latent_means] + support, dim=1), torch.cat([latent_scales] + support, dim=1)), dim=0)
-            both = self.atten_mean[i][0](both, pair=self.atten_scale[i][0])
-            mean_support, _ = ops.split_batch(both)
+            if sup is not None:   # (ops.SliceSupport: the stacked input is a channel prefix of one buffer, no concatenation)
+                both, fold, slot = sup.take(i, support, last=(i == self.num_slices - 1))
+                both = self.atten_mean[i][0](both, pair=self.atten_scale[i][0], in_fold=fold, in_slot=slot)
+            else:
+                both = torch.cat((torch.cat([latent_means] + support, dim=1), torch.cat([latent_scales] + support, dim=1)), dim=0)
+                both = self.atten_mean[i][0](both, pair=self.atten_scale[i][0])
+            both, mean_support = ops.whole_and_first_half(both)
             if ref_features is not None:
                 if ref_pair is None:
                     ref_pair = torch.cat((ref_features, ref_features), dim=0)
@@ -202,21 +207,23 @@ class _SliceCodec(CompressionModel):
             mu, scale = mu[:, :, : y_shape[0], : y_shape[1]], scale[:, :, : y_shape[0], : y_shape[1]]
         return mean_support, mu, scale
 
-    def _refine(self, i, mean_support, y_hat_slice, ref_features):
+    def _refine(self, i, mean_support, y_hat_slice, ref_features, out=None):
         """y_hat_slice + 0.5*tanh(lrp(...)) with the tanh and the add fused in the last conv's epilogue."""
         if ref_features is not None:
-            return self.ref_lrp_transforms[i](torch.cat([mean_support, y_hat_slice, ref_features], dim=1), final_act=ACT_HALFTANH, res=y_hat_slice)
-        return self.lrp_transforms[i](torch.cat([mean_support, y_hat_slice], dim=1), final_act=ACT_HALFTANH, res=y_hat_slice)
+            return self.ref_lrp_transforms[i](torch.cat([mean_support, y_hat_slice, ref_features], dim=1), final_act=ACT_HALFTANH, res=y_hat_slice, out=out)
+        return self.lrp_transforms[i](torch.cat([mean_support, y_hat_slice], dim=1), final_act=ACT_HALFTANH, res=y_hat_slice, out=out)
 
-    def _hyper_synthesis(self, z_hat):
+    def _hyper_synthesis(self, z_hat, stacked=False):
         """(latent_means, latent_scales) = (h_mean_s(z_hat), h_scale_s(z_hat)) (CLC_run.py:532-533): the two nets are the same
-        architecture on the same input — stacked along the batch they run as ONE launch per layer."""
+        architecture on the same input — stacked along the batch they run as ONE launch per layer.
+        stacked: return the stacked result [means; scales] itself (ops.SliceSupport takes it whole)."""
         rows = z_hat.shape[0] * z_hat.shape[2] * z_hat.shape[3]
         if ops.PAIR_SLICES and ops.PAIR_HYPER and rows % 128 == 0 and z_hat.shape[0] % 2 == 0:
             both = torch.cat((z_hat, z_hat), dim=0)
             for m, q in zip(self.h_mean_s, self.h_scale_s):
                 both = m(both, pair=q)
-            return ops.split_batch(both)
+            return both if stacked else ops.split_batch(both)
+        assert not stacked
         return self.h_mean_s(z_hat), self.h_scale_s(z_hat)
 
     @staticmethod
@@ -237,21 +244,36 @@ class _SliceCodec(CompressionModel):
         y_shape = y.shape[2:]
         z = self.h_a(y)
         z_likelihoods, z_hat = self.entropy_bottleneck.likelihood_and_ste(z)
-        latent_means, latent_scales = self._hyper_synthesis(z_hat)
+        S = y.shape[1] // self.num_slices
+        sup = y_buf = None
+        rows = z_hat.shape[0] * z_hat.shape[2] * z_hat.shape[3]
+        if (ops.SUPPORT_BUFFER and ops.PAIR_SLICES and ops.PAIR_HYPER and rows % 128 == 0 and z_hat.shape[0] % 2 == 0
+                and (y.shape[0] * y.shape[2] * y.shape[3]) % 128 == 0 and 0 <= self.max_support_slices <= self.num_slices):
+            both = self._hyper_synthesis(z_hat, stacked=True)
+            if tuple(both.shape[2:]) == tuple(y.shape[2:]):
+                sup = ops.SliceSupport(both, self.max_support_slices, S)
+                latent_means, latent_scales = both[:y.shape[0]], both[y.shape[0]:]   # (shapes only: the nets read them through `sup`)
+                y_buf = ops.new_act(y.shape[0], y.shape[1], y.shape[2], y.shape[3], y)   # y_hat: every slice's refined result, written in place
+            else:
+                latent_means, latent_scales = ops.split_batch(both)
+        else:
+            latent_means, latent_scales = self._hyper_synthesis(z_hat)
         y_hat_slices, y_lik, mus, scales = [], [], [], []
         ref_pair = torch.cat((ref_features, ref_features), dim=0) if (ref_features is not None and ops.PAIR_SLICES) else None
-        S = y.shape[1] // self.num_slices
         # the additive-noise proxy of training (one uniform draw per latent element): all slices' noise in ONE launch
         noise_all = torch.empty_like(y, memory_format=CL).uniform_(-0.5, 0.5) if self.gaussian_conditional.training else None
         for i, y_slice in enumerate(ops.split_channels(y, [S] * self.num_slices)):
-            mean_support, mu, scale = self._slice_params(i, latent_means, latent_scales, y_hat_slices, ref_features, y_shape, ref_pair)
+            mean_support, mu, scale = self._slice_params(i, latent_means, latent_scales, y_hat_slices, ref_features, y_shape, ref_pair, sup)
             mus.append(mu)
             scales.append(scale)
             lik, y_hat_slice = self.gaussian_conditional.likelihood_and_ste(
                 y_slice, scale, mu, noise=noise_all[:, i * S:(i + 1) * S] if noise_all is not None else None)
             y_lik.append(lik)
-            y_hat_slices.append(self._refine(i, mean_support, y_hat_slice, ref_features))
-        x_hat = self.g_s(ops.flush_point(torch.cat(y_hat_slices, dim=1)))
+            y_hat_slices.append(self._refine(i, mean_support, y_hat_slice, ref_features, out=y_buf[:, i * S:(i + 1) * S] if y_buf is not None else None))
+            if sup is not None and i < sup.n:
+                sup.add(i, y_hat_slices[-1])
+        y_hat = ops.gather_channels(y_buf, y_hat_slices) if y_buf is not None else torch.cat(y_hat_slices, dim=1)
+        x_hat = self.g_s(ops.flush_point(y_hat))
         return {"x_hat": x_hat,
                 "likelihoods": {"y": torch.cat(y_lik, dim=1), "z": z_likelihoods},
                 "para": {"means": torch.cat(mus, dim=1), "scales": torch.cat(scales, dim=1), "y": y}}

@@ -160,6 +160,7 @@ BRANCH_STREAMS = False
 # Paired layers: the mean- and scale-parameter nets of a slice run as one launch per layer over a stacked batch (CLC_PAIR=0:
 # two launches, optionally on forked streams).
 PAIR_SLICES = int(os.environ.get("CLC_PAIR", "1"))   # default on: half the launches of the slice loop, no reliance on hipGraph branch concurrency
+SUPPORT_BUFFER = int(os.environ.get("CLC_SUPPORT_BUFFER", "1"))   # slice loop: one support buffer + one gradient buffer instead of per-slice concatenations (SliceSupport)
 QUAD_UNITS = int(os.environ.get("CLC_QUAD_UNITS", "1"))   # paired SWAttens: the ResidualUnits of conv_a and conv_b of both nets in one chain (4 filter sets)
 PAIR_HYPER = int(os.environ.get("CLC_PAIR_HYPER", "1"))   # also pair the mean / scale hyper-synthesis nets (h_mean_s, h_scale_s)
 BRANCH_SLOTS = set(os.environ.get("CLC_BRANCH", "scale").split(","))   # which forks are taken (debug knob)
@@ -765,6 +766,11 @@ class _SplitBatchFn(Function):
         return x[:h], x[h:]
 
     @staticmethod
+    def backward_pad(ga):
+        """[ga; 0]"""
+        return torch.cat((ga, torch.zeros_like(ga)), dim=0)
+
+    @staticmethod
     def backward(ctx, ga, gb):
         shape, dtype, device = ctx.meta
         h = shape[0] // 2
@@ -777,6 +783,31 @@ class _SplitBatchFn(Function):
 
 def split_batch(x):
     return _SplitBatchFn.apply(x)
+
+
+class _WholeAndFirstHalfFn(Function):
+    """x [2B, ...] -> (x, x[:B]) for a tensor that is consumed whole by one layer and by its first half by another (the stacked
+    output of the paired attention blocks: both halves feed the paired cc transforms, the mean half also the lrp transform,
+    CLC_run.py:560-581).  Backward: the half's gradient is added INTO the whole's gradient (this node is its only holder): one
+    half-size add, where a split + autograd's accumulation would zero-fill, concatenate and add full-size tensors."""
+
+    @staticmethod
+    def forward(ctx, x):
+        h = x.shape[0] // 2
+        return x.view_as(x), x[:h]
+
+    @staticmethod
+    def backward(ctx, g_whole, g_half):
+        if g_whole is None:
+            return _SplitBatchFn.backward_pad(g_half)
+        if g_half is not None:
+            h = g_whole.shape[0] // 2
+            g_whole[:h] += g_half
+        return g_whole
+
+
+def whole_and_first_half(x):
+    return _WholeAndFirstHalfFn.apply(x)
 
 
 
@@ -819,6 +850,95 @@ class _SplitFn(Function):
                 _lib.check(_L().clc_copy2d(gp, ldg, dst, Cc, rows, sz, _stream()), "clc_copy2d")
             o += sz
         return (dx, None) + (None,) * len(ctx.sizes)
+
+
+class SliceSupport:
+    """The input of the slice loop's parameter nets without the per-slice concatenations (CLC_run.py:541-566).
+
+    Slice i's mean- / scale-parameter nets read cat([latent_means | latent_scales] + y_hat_slices[:min(i, 5)]): the same leading
+    channels every time.  ONE buffer P [2B, C0 + n * S] holds them — rows [0, B) the mean net's input, rows [B, 2B) the scale
+    net's; the stacked latents are copied in once, support slice j once (into both halves) — and slice i's nets read the channel
+    prefix P[:, :C0 + S * min(i, n)] through its leading dimension: 3 concatenation launches per slice become 1 copy per
+    support slice.  Backward mirrors it: every slice's first convolution adds its data gradient onto the same prefix of ONE
+    gradient buffer G in its epilogue (GradFold + GradSlots), so the ~100 gradient-accumulation adds autograd would launch for
+    the many consumers of the latents and of each support slice collapse to one add per support slice (its two halves).
+    Support slice j's gradient is complete once slice j + 1 — its earliest consumer, the last to run backward — has added
+    its share; that node hands it to autograd, and slice 0's node hands over the latents' gradient."""
+
+    def __init__(self, both, n_support, S):
+        self.C0, self.S, self.n = both.shape[1], int(S), int(n_support)
+        self.both = both
+        self.P = new_act(both.shape[0], self.C0 + self.n * self.S, both.shape[2], both.shape[3], both)
+        # the buffer is filled THROUGH an alias with its own version counter: the prefixes handed out by take() are saved for backward by
+        # their consumers, and the later slices' copies (into channels those prefixes do not cover) must not invalidate them
+        self.Pw = torch.empty(0, device=both.device, dtype=both.dtype).set_(self.P.untyped_storage(), self.P.storage_offset(), self.P.size(), self.P.stride())
+        self.Pw[:, :self.C0].copy_(both.detach())
+        self.grad = both.requires_grad and torch.is_grad_enabled()
+        self.slots = GradSlots()
+        if self.grad:
+            self.slots.buf = new_act(*self.P.shape, both)
+
+    def width(self, i):
+        return self.C0 + self.S * min(i, self.n)
+
+    def add(self, j, y_hat):
+        """support slice j (j < n) -> both halves of the buffer, one launch"""
+        N2, Ct, H, W = self.P.shape
+        self.Pw.view(2, N2 // 2, Ct, H, W)[:, :, self.C0 + j * self.S:self.C0 + (j + 1) * self.S].copy_(y_hat.detach())
+
+    def take(self, i, supports, last):
+        """-> (input of slice i's nets, fold_in, grad_slot) for their first convolution.  last: slice i is the final slice (its
+        backward runs first: it initialises the gradient buffer instead of adding to it)."""
+        assert len(supports) == min(i, self.n)
+        x = _SupportTakeFn.apply(self, i, self.both, *supports)
+        if not self.grad:
+            return x, None, None
+        fold = None
+        if not last:
+            fold = GradFold()
+            fold.park(self.slots.buf[:, :self.width(i)])
+        return x, fold, (self.slots, self.P.shape[1], 0)
+
+
+class _SupportTakeFn(Function):
+    @staticmethod
+    def forward(ctx, sup, i, both, *supports):
+        ctx.sup, ctx.i, ctx.k = sup, i, len(supports)
+        return sup.P[:, :sup.width(i)].detach()
+
+    @staticmethod
+    def backward(ctx, dx):
+        sup, i = ctx.sup, ctx.i
+        G = sup.slots.buf   # (dx is its prefix: the first convolution of the nets wrote / accumulated in place)
+        B = G.shape[0] // 2
+        grads = [None] * ctx.k
+        if 1 <= i <= sup.n:   # slice i is the earliest consumer of support slice i - 1: everything later has already added its share
+            c0 = sup.C0 + (i - 1) * sup.S
+            grads[i - 1] = G[:B, c0:c0 + sup.S] + G[B:, c0:c0 + sup.S]
+        g_both = G[:, :sup.C0] if i == 0 else None
+        return (None, None, g_both) + tuple(grads)
+
+
+class _GatherChannelsFn(Function):
+    """The channel concatenation of tensors that were WRITTEN into consecutive channel ranges of one buffer (out=): returns the
+    buffer, and the backward hands each producer its channel range of the incoming gradient as a view — no copy either way."""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        ctx.sizes = [p.shape[1] for p in parts]
+        return buf.detach()
+
+    @staticmethod
+    def backward(ctx, dy):
+        outs, o = [], 0
+        for sz in ctx.sizes:
+            outs.append(dy[:, o:o + sz])
+            o += sz
+        return (None,) + tuple(outs)
+
+
+def gather_channels(buf, parts):
+    return _GatherChannelsFn.apply(buf, *parts)
 
 
 def split_channels(x, sizes, slots=None):

@@ -2,6 +2,8 @@
 """Summaries of a rocprofv3 rocpd database (`rocprofv3 --kernel-trace --stats -d DIR -o NAME -- python bench.py ...`).
 
   python tools/prof_db.py stats  DB [--md OUT.md] [--csv OUT.csv]   per-kernel calls / total / average / share
+  python tools/prof_db.py seq    DB [--from I] [--count N]           the dispatches of that step in order: start offset, duration,
+                                                                     idle gap in front, workgroups, name
   python tools/prof_db.py step   DB                                  timeline of ONE steady-state (hipGraph-replayed) step:
                                                                      wall, union-busy, concurrency histogram, and for every
                                                                      kernel family the time it runs ALONE on the chip
@@ -54,6 +56,21 @@ def cmd_stats(args):
     print(text)
 
 
+def cmd_seq(args):
+    rows = load(args.db)
+    marks = [i for i, r in enumerate(rows) if r[0].startswith("grad_sqnorm_kernel")]
+    step = rows[marks[-3] + 1: marks[-2] + 1]
+    t0, prev_end, gaps, busy = step[0][1], step[0][1], 0, 0
+    for i, (n, s0, e0, q, st, wg, v, l) in enumerate(step):
+        gap = s0 - prev_end
+        gaps += max(gap, 0)
+        busy += e0 - s0
+        if args.first <= i < args.first + args.count:
+            print(f"{i:5d} +{(s0 - t0) / 1e3:9.1f} us  {(e0 - s0) / 1e3:7.1f} us  gap {gap / 1e3:5.1f}  wg {wg:6d}  {n}")
+        prev_end = max(prev_end, e0)
+    print(f"step: {len(step)} dispatches, busy {busy / 1e6:.3f} ms, idle gaps {gaps / 1e6:.3f} ms")
+
+
 def cmd_step(args):
     rows = load(args.db)
     marks = [i for i, r in enumerate(rows) if r[0].startswith("grad_sqnorm_kernel")]
@@ -103,5 +120,7 @@ if __name__ == "__main__":
     s = sub.add_parser("stats"); s.add_argument("db"); s.add_argument("--md"); s.add_argument("--csv"); s.add_argument("--top", type=int, default=60)
     s.set_defaults(fn=cmd_stats)
     t = sub.add_parser("step"); t.add_argument("db"); t.set_defaults(fn=cmd_step)
+    q = sub.add_parser("seq"); q.add_argument("db"); q.add_argument("--from", dest="first", type=int, default=0)
+    q.add_argument("--count", type=int, default=100000); q.set_defaults(fn=cmd_seq)
     a = ap.parse_args()
     a.fn(a)
