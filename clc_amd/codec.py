@@ -124,7 +124,7 @@ class CodecEngine:
             ref_features = m._ref(pl.refs)
             y = m.g_a(xx)
             y_shape = y.shape[2:]
-            z = m.h_a(y)
+            z = m._fuse_z(m.h_a(y))
             eb = m.entropy_bottleneck
             med = eb._get_medians().reshape(1, -1, 1, 1)
             z_sym = torch.round(z - med).to(torch.int32)                    # == EntropyBottleneck.compress's symbols

@@ -159,6 +159,9 @@ class _SliceCodec(CompressionModel):
     def _ref(self, ref_frames):
         return None
 
+    def _fuse_z(self, z):
+        return z
+
     def _slice_params(self, i, latent_means, latent_scales, y_hat_slices, ref_features, y_shape, ref_pair=None, sup=None):
         support = y_hat_slices if self.max_support_slices < 0 else y_hat_slices[: self.max_support_slices]
         rows = latent_means.shape[0] * latent_means.shape[2] * latent_means.shape[3]
@@ -242,7 +245,7 @@ class _SliceCodec(CompressionModel):
             y, ref_features = ops.cut(y), ops.cut(ref_features)
             self._boundary = (y, ref_features)
         y_shape = y.shape[2:]
-        z = self.h_a(y)
+        z = self._fuse_z(self.h_a(y))
         z_likelihoods, z_hat = self.entropy_bottleneck.likelihood_and_ste(z)
         S = y.shape[1] // self.num_slices
         sup = y_buf = None
@@ -284,7 +287,7 @@ class _SliceCodec(CompressionModel):
         ref_features = self._ref(ref_frames)
         y = self.g_a(x)
         y_shape = y.shape[2:]
-        z = self.h_a(y)
+        z = self._fuse_z(self.h_a(y))
         z_strings = self.entropy_bottleneck.compress(z)
         z_hat = self.entropy_bottleneck.decompress(z_strings, z.size()[-2:])
         latent_scales = self.h_scale_s(z_hat)
@@ -366,9 +369,27 @@ class CLC(_SliceCodec):
             raise ValueError(f"expected {self.num_ref_frames} reference frames, got {R}")
         refs = self._prep(torch.cat(list(ref_frames), dim=0)) if R > 1 else self._prep(ref_frames[0])
         feats = self.ref_encoder(refs)                      # one batched pass over all R references
+        self._ref_latents = feats if self.wire_clm else None   # [R*B, M, h, w], reference-major
         if R > 1:
             feats = torch.cat(feats.chunk(R, dim=0), dim=1)  # [B, R*M, h, w] in reference order
         return self.ref_feature_adapter(feats)
+
+    # SURVEY §8(f)-4 — NOT reference behaviour: the reference constructs feature_alignment / multi_ref_fusion (CLC_run.py:359-369) and
+    # never calls them.  wire_clm = True applies them the one way their constructor shapes admit: CLM(192) pairs the hyper-latent z with
+    # a 192-channel feature of each reference at z's resolution — h_a of that reference's latent, one batched pass — and
+    # multi_ref_fusion (192 * (R + 1) -> 256 -> 192) fuses z with the R aligned features.  Encoder side only (forward / compress):
+    # the decoder receives the fused z_hat.  oracle/graph.py restates the same definition; the modules themselves are pinned against
+    # the genuine classes (tests/golden/dormant.npz).
+    wire_clm = False
+
+    def _fuse_z(self, z):
+        lat = getattr(self, "_ref_latents", None)
+        if not self.wire_clm or lat is None:
+            return z
+        R = self.num_ref_frames
+        zr = self.h_a(lat).chunk(R, dim=0)
+        aligned = [self.feature_alignment[r](z, zr[r]) for r in range(R)]
+        return self.multi_ref_fusion(torch.cat([z] + aligned, dim=1))
 
     extract_ref_features = _ref
 

@@ -306,7 +306,8 @@ class TrainEngine:
         n_el = self.opt.grad_flat.numel()
         self.early_params = early
         self.sync = GradSync(self.opt.grad_flat, phases=([(cut, n_el), (0, cut)] if cut else None))
-        self.two_phase = bool(cut) and hasattr(self.model, "_boundary_ok")
+        # (wire_clm: the reference latents also feed h_a, so (y, ref_features) no longer separates the encoders from the rest)
+        self.two_phase = bool(cut) and hasattr(self.model, "_boundary_ok") and not getattr(self.model, "wire_clm", False)
         self.aux_sync = GradSync(self.aux_opt.grad_flat)
 
     def _fwd_bwd(self, x, refs):

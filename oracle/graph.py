@@ -216,11 +216,14 @@ class _SliceCodecMixin:
     def _ref(self, ref_frames):
         return None
 
+    def _fuse_z(self, z):
+        return z
+
     def forward(self, x, ref_frames=None):
         ref_features = self._ref(ref_frames)
         y = self.g_a(x)
         y_shape = y.shape[2:]
-        z = self.h_a(y)
+        z = self._fuse_z(self.h_a(y))
         _, z_likelihoods = self.entropy_bottleneck(z)
         z_offset = self.entropy_bottleneck._get_medians()
         z_hat = ste_round(z - z_offset) + z_offset
@@ -244,7 +247,7 @@ class _SliceCodecMixin:
         ref_features = self._ref(ref_frames)
         y = self.g_a(x)
         y_shape = y.shape[2:]
-        z = self.h_a(y)
+        z = self._fuse_z(self.h_a(y))
         z_strings = self.entropy_bottleneck.compress(z)
         z_hat = self.entropy_bottleneck.decompress(z_strings, z.size()[-2:])
         latent_scales, latent_means = self._hyper(z_hat)
@@ -339,10 +342,24 @@ class CLC(_SliceCodecMixin, CompressionModel):
         self.gaussian_conditional = GaussianConditional(None)
 
     def _ref(self, ref_frames):
+        self._ref_latents = None
         if ref_frames is None or not self.use_ref:
             return None
         feats = [self.ref_encoder(r) for r in ref_frames]
+        self._ref_latents = feats
         return self.ref_feature_adapter(torch.cat(feats, dim=1))
+
+    # SURVEY §8(f)-4 — NOT reference behaviour (the reference constructs feature_alignment / multi_ref_fusion, CLC_run.py:359-369,
+    # and never calls them).  wire_clm = True applies them the one way their constructor shapes admit: CLM(192) pairs the hyper-latent
+    # z with a 192-channel feature of each reference at z's resolution — h_a of that reference's latent — and multi_ref_fusion
+    # (192 * (R + 1) -> 256 -> 192) fuses z with the R aligned features.  Encoder side only: the decoder receives the fused z_hat.
+    wire_clm = False
+
+    def _fuse_z(self, z):
+        if not self.wire_clm or getattr(self, "_ref_latents", None) is None:
+            return z
+        aligned = [self.feature_alignment[r](z, self.h_a(f)) for r, f in enumerate(self._ref_latents)]
+        return self.multi_ref_fusion(torch.cat([z] + aligned, dim=1))
 
     extract_ref_features = _ref
 

@@ -645,6 +645,29 @@ def test_convtransblock_and_swatten_vs_reference_golden(dev):
     _close(ys, torch.from_numpy(g["swatten_y"]), 2e-5, "SWAtten vs reference class")
 
 
+def test_dormant_clm_and_fusion_vs_reference_golden(dev):
+    """the modules the reference constructs and never calls (in-file CLM, multi_ref_fusion; CLC_run.py:284-313,
+    359-369) on the HIP path against outputs of the genuine classes (tests/golden/dormant.npz)."""
+    import os
+
+    import numpy as np
+
+    from clc_amd.models import clc as pm
+    from clc_amd.recipe import apply_weight_recipe
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "dormant.npz"))
+    clm = pm.CLM(192, head_dim=32, window_size=4)
+    apply_weight_recipe(clm, 5)
+    fus = pm.PointwiseMLP(384, 256, 192)
+    apply_weight_recipe(fus, 6)
+    x, r = _dev(torch.from_numpy(g["x"]), dev), _dev(torch.from_numpy(g["ref"]), dev)
+    with torch.no_grad():
+        a = clm.to(dev)(x, r)
+        f = fus.to(dev)(torch.cat([x, a], dim=1))
+    _close(a.cpu(), torch.from_numpy(g["clm_y"]), 2e-5, "CLM vs reference class")
+    _close(f.cpu(), torch.from_numpy(g["fusion_y"]), 2e-5, "multi_ref_fusion vs reference class")
+
+
 @pytest.mark.parametrize("kind", ["lrelu3x3", "relu1x1", "gelu_linear", "subpel_lrelu", "big_lrelu"])
 def test_activation_gate_in_consumer_dgrad(dev, kind):
     """ops.ActGate: z = conv_b(act(conv_a(x))) — conv_b's data-gradient epilogue multiplies by act'(.), conv_a's gradient kernels then

@@ -126,6 +126,40 @@ def test_backward_parity(dev, kind, R, B):
     print(kind, R, "checked", checked, "worst rel err", worst)
 
 
+@pytest.mark.parametrize("R", [1])
+def test_wire_clm_forward_backward_vs_oracle(dev, R):
+    """SURVEY 8(f)-4 (an extension, not reference behaviour): wire_clm = True routes the hyper-latent through feature_alignment /
+    multi_ref_fusion (clc_amd/models/clc.py `_fuse_z`; the same definition restated in oracle/graph.py).  Loss terms, every parameter
+    gradient — the dormant modules' included — and the codec round trip against the oracle."""
+    from clc_amd.train import RateDistortionLoss as PRD
+    from oracle.loss import RateDistortionLoss as ORD
+
+    o, p = _pair("clc", R, dev)
+    o.wire_clm = p.wire_clm = True
+    x, refs = _inputs(1, R, size=512)   # (CLM's Swin block has 4x4 windows: the hyper-latent must be larger, i.e. the image >= 512)
+    lo = ORD(0.0067)(o(x, refs), x)
+    lo["loss"].backward()
+    xd, rd = x.to(dev), [r.to(dev) for r in refs]
+    lp = PRD(0.0067)(p(xd, rd), xd)
+    lp["loss"].backward()
+    for k in ("loss", "bpp_loss", "mse_loss"):
+        assert abs(lo[k].item() - lp[k].item()) <= 2e-4 * max(1.0, abs(lo[k].item())), (k, lo[k].item(), lp[k].item())
+    _grad_parity(o, p)
+    names = [n for n, q in p.named_parameters() if n.startswith(("feature_alignment", "multi_ref_fusion")) and q.grad is not None and float(q.grad.abs().max()) > 0]
+    assert len(names) > 50, "the wired modules received no gradient"
+    # with the wiring off the same weights give the reference graph (other z, other loss)
+    o.wire_clm = p.wire_clm = False
+    with torch.no_grad():
+        assert abs(PRD(0.0067)(p(xd, rd), xd)["loss"].item() - lp["loss"].item()) > 1e-6
+    # codec: encoder-side only — the decoder needs no change
+    p.wire_clm = True
+    p.update(force=True)
+    with torch.no_grad():
+        out = p.compress(xd[:1], [r[:1] for r in rd])
+        rec = p.decompress(out["strings"], out["shape"], [r[:1] for r in rd])
+    assert rec["x_hat"].shape == (1, 3, 512, 512) and torch.isfinite(rec["x_hat"]).all()
+
+
 def test_config1_bs8_train_mode_step_vs_oracle(dev):
     """BASELINE configs[1] at its quoted size (CLC lambda 0.0067 MSE, 256x256, batch 8, 1 reference), TRAIN mode: the additive-noise
     proxy is injected identically on both sides (one U(-1/2,1/2) tensor for y, one for z), so the loss terms (<= 2e-4) and the

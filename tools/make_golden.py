@@ -101,6 +101,23 @@ def block_goldens(ref):
     print("blocks:", len(out), "arrays")
 
 
+def dormant_goldens(ref):
+    """The modules the reference constructs and never calls (CLC_run.py:284-313, 359-369): the genuine in-file CLM class and a
+    multi_ref_fusion stack on recipe weights and seeded inputs -> pins the product's / the oracle's versions of them."""
+    mod = sys.modules["models.CLC_run"]
+    g = torch.Generator().manual_seed(11)
+    clm = mod.CLM(192, head_dim=32, window_size=4).eval()
+    apply_weight_recipe(clm, 5)
+    x, r = torch.randn(2, 192, 8, 8, generator=g), torch.randn(2, 192, 8, 8, generator=g)
+    fus = torch.nn.Sequential(mod.conv1x1(192 * 2, 256), torch.nn.GELU(), mod.conv1x1(256, 192)).eval()
+    apply_weight_recipe(fus, 6)
+    with torch.no_grad():
+        a = clm(x, r)
+        out = {"x": x.numpy(), "ref": r.numpy(), "clm_y": a.numpy(), "fusion_y": fus(torch.cat([x, a], dim=1)).numpy()}
+    np.savez_compressed(os.path.join(OUT, "dormant.npz"), **out)
+    print("dormant:", {k: v.shape for k, v in out.items()})
+
+
 def rans_goldens():
     gc = leaves.GaussianConditional(None)
     gc.update_scale_table(leaves.get_scale_table())
@@ -235,9 +252,13 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "pm":
         patch_matching_goldens()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "dormant":
+        dormant_goldens(ref)
+        return
     graph_goldens(ref)
     codec_goldens(ref)
     block_goldens(ref)
+    dormant_goldens(ref)
     rans_goldens()
     clm_goldens()
     patch_matching_goldens()
