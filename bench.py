@@ -220,7 +220,9 @@ def roofline_leg(engine, x, refs):
                 return "wgrad_small_kernel"
             if variant in (64908, 64916, 64932):
                 return f"conv_wgrad_taps_sk_kernel<{variant - 64900}>"
-            return f"conv_wgrad_sk_kernel<{variant // 1000}, {variant % 1000}, 2, 2>"
+            # (a family's flush is up to two launches — <..., true> LDS-DMA staged, <..., false> register staged for problems with a
+            # fused activation derivative / squared input — timed together under the first name)
+            return f"conv_wgrad_sk_kernel<{variant // 1000}, {variant % 1000}, 2, 2, true>"
         if fam != "conv_igemm" or variant < (1 << 20):
             return fam   # conv_direct_small / single (non-deferred) wgrad calls
         tr = "true" if str(shape).startswith("dgrad") else "false"

@@ -17,6 +17,7 @@ enum { CLC_TUNE_DMA_LOOP = 0 /* 1: conv_igemm_dma_kernel, 2: conv_igemm_dma2_ker
        CLC_TUNE_SPLITK_PF = 6 /* K-tiles in flight per wave of the 8-wave split-K conv kernel: 3 (one workgroup per CU) or 1 (two) */,
        CLC_TUNE_1X1_TILE = 7 /* large-map 1x1 convolutions with at most this many K-tiles use the 128x64 tile (0: off) */,
        CLC_TUNE_XCD_MAP = 8 /* dma2 conv kernel: channel tiles of a pixel tile back to back on one XCD: 0 off, 1 = 1x1 layers, 2 = all */,
+       CLC_TUNE_WGRAD_DMA = 9 /* filter-gradient tile kernels: LDS-DMA staging for problems without operand arithmetic */,
        CLC_TUNE_COUNT = 16 };
 extern int clc_tuning[CLC_TUNE_COUNT];
 

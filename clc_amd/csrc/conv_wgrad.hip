@@ -33,6 +33,13 @@ __device__ __forceinline__ int pin_s(int x) {
   return r;
 }
 
+// LDS-DMA: 64 lanes x 16 B from per-lane byte offsets of the buffer straight into LDS at dst (wave-uniform) + 16 * lane
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds_dst, unsigned byte_off) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass of hipcc cannot type-check the LDS address-space cast)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, byte_off, 0, 0, 0);
+#endif
+}
+
 struct WgradParams {
   const float* x; const float* dy; float* partial; float* bias_partial;
   unsigned x_bytes, dy_bytes;
@@ -51,7 +58,7 @@ struct WgradParams {
 // mode 1: same layout, accumulate (single writer per element); mode 2: compact tile image (stream-K partial slot).
 struct OutSpec { float* w; float* b; int mode; };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool DMA = false>
 __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, const int by, const int k_begin, const int k_end, const OutSpec o, const int tid) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -112,6 +119,47 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
       b_reg[i] = buf_load4(xr, ok ? ((unsigned)((n * pH + iy) * pW + ix) * (unsigned)pldx + (unsigned)ci) * 4u : kOOB);
     }
   };
+  // Operands that need no arithmetic on the way in (no fused activation derivative on dy, no squared input) go from global memory
+  // STRAIGHT to LDS (LDS-DMA): piece p of a tile lands at float offset 4 p of the tile image, which is exactly where 64
+  // consecutive lanes x 16 B of one DMA instruction go — no staging registers, no ds_write, and the next tile's pieces are in flight
+  // from the top of the iteration.  Same LDS image, same MFMA order: the results do not change.
+  // (DMA: the host put only such problems into this launch — dma_ok())
+  static_assert(!DMA || ((BK * BM / 4) % NT == 0 && (BK * BN / 4) % NT == 0), "whole DMA instructions per tile");
+  constexpr bool use_dma = DMA;
+  const int wave_base = (tid >> 6) * 64;   // (first piece of this wave in a group of NT pieces)
+  auto dma_tile = [&](int kt, int buf) {
+    const int kbase = k_begin + kt * BK;
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) {
+      const int piece = tid + i * NT, row = piece / AQ, q = piece - row * AQ;
+      const int pix = kbase + row, co = co0 + q * 4;
+      const bool ok = pix < k_end && co < pCout;
+      dma16(dr, As + buf * BK * BM + (i * NT + wave_base) * 4, ok ? ((unsigned)pix * (unsigned)plddy + (unsigned)co) * 4u : kOOB);
+    }
+#pragma unroll
+    for (int i = 0; i < B_P; ++i) {
+      const int piece = tid + i * NT, row = piece / BQ, q = piece - row * BQ;
+      const int pix = kbase + row, ci = ci0 + q * 4;
+      const int pp = pix < k_end ? pix : k_begin;
+      int n, oy, ox;
+      if (pows >= 0) {
+        n = pp >> pimgs;
+        const int r = pp & ((1 << pimgs) - 1);
+        oy = r >> pows; ox = r & ((1 << pows) - 1);
+      } else {
+        n = pp / (pOH * pOW);
+        const int r = pp - n * (pOH * pOW);
+        oy = r / pOW; ox = r - oy * pOW;
+      }
+      const int iy = oy * pstride - ppad + kh, ix = ox * pstride - ppad + kw;
+      const bool ok = pix < k_end && ci < pCin && (unsigned)iy < (unsigned)pH && (unsigned)ix < (unsigned)pW;
+      dma16(xr, Bs + buf * BK * BN + (i * NT + wave_base) * 4, ok ? ((unsigned)((n * pH + iy) * pW + ix) * (unsigned)pldx + (unsigned)ci) * 4u : kOOB);
+    }
+  };
+  auto bias_from_lds = [&](int buf) {   // (the DMA path has no staging registers to sum: the dY tile is read back, 4 floats per piece)
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) bias_acc[i] += *reinterpret_cast<const f32x4*>(As + buf * BK * BM + (tid + i * NT) * 4);
+  };
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_P; ++i) {
@@ -136,15 +184,21 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   if (ntiles > 0) {
-    load_tile(0);
-    store_tile(0);
+    if (use_dma) {
+      dma_tile(0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      load_tile(0);
+      store_tile(0);
+    }
     __syncthreads();
   }
   const int khalf = lane >> 5, li = lane & 31;
   for (int kt = 0; kt < ntiles; ++kt) {
     const int buf = kt & 1;
     const bool more = kt + 1 < ntiles;
-    if (more) load_tile(kt + 1);
+    if (more) { if (use_dma) dma_tile(kt + 1, buf ^ 1); else load_tile(kt + 1); }
+    if (use_dma && do_bias) bias_from_lds(buf);
     const float* Ab = As + (buf * BK + khalf) * BM + wm * (BM / WM) + li;
     const float* Bb = Bs + (buf * BK + khalf) * BN + wn * (BN / WN) + li;
 #pragma unroll
@@ -160,7 +214,8 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    if (more) store_tile(buf ^ 1);
+    if (use_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's pieces have landed
+    else if (more) store_tile(buf ^ 1);
     __syncthreads();
   }
 
@@ -512,7 +567,7 @@ void conv_wgrad_taps_sk_kernel(const SKGroup g) {
 // resident workgroups per CU the register / LDS budget of each tile shape allows (= the split-K kernels' occupancy)
 constexpr int sk_wg_per_cu(int bm, int bn) { return bm * bn >= 128 * 128 ? 2 : (bm * bn >= 128 * 64 ? 3 : 5); }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool DMA>
 __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 128 * 128 ? 2 : (BM * BN >= 128 * 64 ? 4 : 6)))
 void conv_wgrad_sk_kernel(const SKGroup g) {
   const int w = blockIdx.x;
@@ -528,7 +583,7 @@ void conv_wgrad_sk_kernel(const SKGroup g) {
     const int gx = g.gx[sgm.idx];
     if (!first) __syncthreads();
     const int ke = sgm.k1 * BK;
-    wgrad_body<BM, BN, WM, WN>(p, sgm.tile % gx, sgm.tile / gx, sgm.k0 * BK, ke < p.K ? ke : p.K, sk_out(g, p, sgm, g.T[sgm.idx], w, BM * BN), sk_tid());
+    wgrad_body<BM, BN, WM, WN, DMA>(p, sgm.tile % gx, sgm.tile / gx, sgm.k0 * BK, ke < p.K ? ke : p.K, sk_out(g, p, sgm, g.T[sgm.idx], w, BM * BN), sk_tid());
     first = false;
     u += sgm.k1 - sgm.k0;
   }
@@ -991,16 +1046,19 @@ bool sk_collect(const Pending* pend, int n, SKGroup& g, float* region, int slot_
   return true;
 }
 
-template <int BM, int BN>
+// problems whose operands need no arithmetic on the way into LDS (no fused activation derivative on dy, no squared input): LDS-DMA staging
+inline bool dma_ok(const Pending& e) { return clc_tuning[CLC_TUNE_WGRAD_DMA] && e.d->dys == nullptr && e.d->in_op == CLC_IN_NONE; }
+
+template <int BM, int BN, bool DMA>
 int launch_variant_sk(const Pending* pend, int n, float* region, hipStream_t st) {
   static SKGroup g;   // (host staging of the kernel argument; launches are issued by one host thread per process)
   constexpr int slot = (int)sk_slot_floats(BM * BN, BM);
-  if (!sk_collect(pend, n, g, region, slot, kCUs * sk_wg_per_cu(BM, BN), 16, [](const Pending& e) { return !e.pl.taps && e.pl.bm == BM && e.pl.bn == BN; },
+  if (!sk_collect(pend, n, g, region, slot, kCUs * sk_wg_per_cu(BM, BN), 16, [](const Pending& e) { return !e.pl.taps && e.pl.bm == BM && e.pl.bn == BN && dma_ok(e) == DMA; },
                   [](const Pending& e, int& gx, int& gy, int& T) {
                     gx = e.pl.nci * e.d->ks * e.d->ks; gy = (e.d->Cout + BM - 1) / BM; T = (e.p.K + BK - 1) / BK;
                   })) return 0;
   const size_t lds = (size_t)2 * BK * (BM + BN) * sizeof(float);
-  hipLaunchKernelGGL((conv_wgrad_sk_kernel<BM, BN, 2, 2>), dim3(g.G), dim3(256), lds, st, g);
+  hipLaunchKernelGGL((conv_wgrad_sk_kernel<BM, BN, 2, 2, DMA>), dim3(g.G), dim3(256), lds, st, g);
   CLC_LAUNCH_CHECK();
   if (g.G > 1) {
     hipLaunchKernelGGL(wgrad_sk_compact_kernel, dim3(1), dim3(1024), 0, st, g.plan, g.G, g.plan + 4 * 1280);
@@ -1063,13 +1121,17 @@ int flush_sk(Pending* pend, int& n, float* ws, hipStream_t st) {
   }
   int rc;
   float* r = ws;
-  if ((rc = launch_variant_sk<128, 128>(pend, n, r, st)) < 0) return rc;
+  if ((rc = launch_variant_sk<128, 128, true>(pend, n, r, st)) < 0) return rc;    // (the two launches of a family share its region: stream order)
+  if ((rc = launch_variant_sk<128, 128, false>(pend, n, r, st)) < 0) return rc;
   r += kSKRegion[0] + kSKPlanFloats;
-  if ((rc = launch_variant_sk<128, 64>(pend, n, r, st)) < 0) return rc;
+  if ((rc = launch_variant_sk<128, 64, true>(pend, n, r, st)) < 0) return rc;    // (the two launches of a family share its region: stream order)
+  if ((rc = launch_variant_sk<128, 64, false>(pend, n, r, st)) < 0) return rc;
   r += kSKRegion[1] + kSKPlanFloats;
-  if ((rc = launch_variant_sk<64, 128>(pend, n, r, st)) < 0) return rc;
+  if ((rc = launch_variant_sk<64, 128, true>(pend, n, r, st)) < 0) return rc;    // (the two launches of a family share its region: stream order)
+  if ((rc = launch_variant_sk<64, 128, false>(pend, n, r, st)) < 0) return rc;
   r += kSKRegion[2] + kSKPlanFloats;
-  if ((rc = launch_variant_sk<64, 64>(pend, n, r, st)) < 0) return rc;
+  if ((rc = launch_variant_sk<64, 64, true>(pend, n, r, st)) < 0) return rc;    // (the two launches of a family share its region: stream order)
+  if ((rc = launch_variant_sk<64, 64, false>(pend, n, r, st)) < 0) return rc;
   r += kSKRegion[3] + kSKPlanFloats;
   if ((rc = launch_taps_sk<32>(pend, n, r, st)) < 0) return rc;
   r += kSKRegion[4] + kSKPlanFloats;
