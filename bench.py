@@ -212,17 +212,18 @@ def roofline_leg(engine, x, refs):
     _L = _clib.load()
     splitk_pf = _L.clc_set_tuning(6, 1)
     _L.clc_set_tuning(6, splitk_pf)
+    wgrad_dma = _L.clc_set_tuning(9, 1)
+    _L.clc_set_tuning(9, wgrad_dma)
 
     def kernel_name(fam, variant, shape):
         """the name rocprofv3 --kernel-trace reports for this launch (template arguments from the C ABI's variant id)"""
         if fam == "conv_wgrad_group":   # one kernel family of a grouped stream-K filter-gradient call (+ its compact / fix-up launches)
+            dma = "true" if str(shape).endswith("dma=1") and wgrad_dma else "false"   # <..., true>: LDS-DMA-staged instantiation
             if variant == 1:
                 return "wgrad_small_kernel"
             if variant in (64908, 64916, 64932):
-                return f"conv_wgrad_taps_sk_kernel<{variant - 64900}>"
-            # (a family's flush is up to two launches — <..., true> LDS-DMA staged, <..., false> register staged for problems with a
-            # fused activation derivative / squared input — timed together under the first name)
-            return f"conv_wgrad_sk_kernel<{variant // 1000}, {variant % 1000}, 2, 2, true>"
+                return f"conv_wgrad_taps_sk_kernel<{variant - 64900}, {dma}>"
+            return f"conv_wgrad_sk_kernel<{variant // 1000}, {variant % 1000}, 2, 2, {dma}>"
         if fam != "conv_igemm" or variant < (1 << 20):
             return fam   # conv_direct_small / single (non-deferred) wgrad calls
         tr = "true" if str(shape).startswith("dgrad") else "false"

@@ -269,7 +269,7 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
 // the (TH+2) x (TW+2) input window are staged in LDS ONCE and the nine taps are nine shifted views of that window:
 // 64 co x (9 taps x 64 ci) outputs per workgroup, wave (wm, wn) = 32 co x 32 ci x 9 taps = 9 MFMA blocks (144 acc
 // registers), 10 ds_read_b32 per 9 MFMAs.  Same slab layout / fixed-order reduce as above.
-template <int TW>
+template <int TW, bool DMA = false>
 __device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int bx, const int by, const int t_begin, const int t_end, const OutSpec o, const int tid) {
   constexpr int TH = 32 / TW, XW = TW + 2, XH = TH + 2, XP = XH * XW;
   constexpr int LTW = TW == 32 ? 5 : (TW == 16 ? 4 : 3);
@@ -318,6 +318,31 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int 
       x_reg[i] = buf_load4(xr, ok ? ((unsigned)((n * pH + iy) * pW + ix) * (unsigned)pldx + (unsigned)ci) * 4u : kOOB);
     }
   };
+  // DMA (host: no fused activation derivative on dy): the dY rows and the input window go from global memory straight to LDS —
+  // piece p lands at float offset 4 p of its tile image, where 64 consecutive lanes x 16 B of one DMA instruction go (the last
+  // window instruction is partly masked) — which frees the 44 staging registers for a one-step-ahead fragment prefetch below.
+  const int wave_base = (tid >> 6) * 64;
+  auto dma_tile = [&](int t, int buf) {
+    const int bc = t & ((1 << lcols) - 1), t2 = t >> lcols;
+    const int br = t2 & ((1 << lrows) - 1), n = t2 >> lrows;
+    const int oy0 = br * TH, ox0 = bc * TW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = tid + i * 256, row = piece >> 4, q = piece & 15;
+      const int pix = (n * pOH + oy0 + (row >> LTW)) * pOW + ox0 + (row & (TW - 1));
+      const int co = co0 + q * 4;
+      dma16(dr, As + buf * 32 * 64 + (i * 256 + wave_base) * 4, co < pCout ? ((unsigned)pix * (unsigned)plddy + (unsigned)co) * 4u : kOOB);
+    }
+#pragma unroll
+    for (int i = 0; i < X_P; ++i) {
+      const int piece = tid + i * 256, xp = piece >> 4, q = piece & 15;
+      const int wy = xp / XW, wx = xp - wy * XW;
+      const int iy = oy0 + wy - 1, ix = ox0 + wx - 1, ci = ci0 + q * 4;
+      const bool ok = ci < pCin && (unsigned)iy < (unsigned)pH && (unsigned)ix < (unsigned)pW;
+      if (piece < XP * 16)
+        dma16(xr, Xs + buf * XP * 64 + (i * 256 + wave_base) * 4, ok ? ((unsigned)((n * pH + iy) * pW + ix) * (unsigned)pldx + (unsigned)ci) * 4u : kOOB);
+    }
+  };
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -340,29 +365,61 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int 
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   if (ntiles > 0) {
-    load_tile(t_begin);
-    store_tile(0);
+    if (DMA) {
+      dma_tile(t_begin, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      load_tile(t_begin);
+      store_tile(0);
+    }
     __syncthreads();
   }
   const int khalf = lane >> 5, li = lane & 31;
   for (int kt = 0; kt < ntiles; ++kt) {
     const int buf = kt & 1;
     const bool more = kt + 1 < ntiles;
-    if (more) load_tile(t_begin + kt + 1);
+    if (more) { if (DMA) dma_tile(t_begin + kt + 1, buf ^ 1); else load_tile(t_begin + kt + 1); }
     const float* Ab = As + buf * 32 * 64 + wm * 32 + li;
     const float* Xb = Xs + buf * XP * 64 + wn * 32 + li;
+    if (DMA) {
+      if (do_bias) {
 #pragma unroll
-    for (int ss = 0; ss < 16; ++ss) {
-      const int k = 2 * ss + khalf;
-      const float a = Ab[k * 64];
-      const float* xk = Xb + ((k >> LTW) * XW + (k & (TW - 1))) * 64;
+        for (int i = 0; i < 2; ++i) bias_acc[i] += *reinterpret_cast<const f32x4*>(As + buf * 32 * 64 + (tid + i * 256) * 4);
+      }
+      // the 10 operand values of k-step ss + 1 are read while the 9 MFMAs of step ss issue
+      float a[2], xv[2][9];
+      auto read_step = [&](int ss, float& av, float (&x9)[9]) {
+        const int k = 2 * ss + khalf;
+        av = Ab[k * 64];
+        const float* xk = Xb + ((k >> LTW) * XW + (k & (TW - 1))) * 64;
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+        for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
-          acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xk[(kh * XW + kw) * 64], acc[kh * 3 + kw], 0, 0, 0);
+          for (int kw = 0; kw < 3; ++kw) x9[kh * 3 + kw] = xk[(kh * XW + kw) * 64];
+      };
+      read_step(0, a[0], xv[0]);
+#pragma unroll
+      for (int ss = 0; ss < 16; ++ss) {
+        const int cur = ss & 1;
+        if (ss < 15) read_step(ss + 1, a[cur ^ 1], xv[cur ^ 1]);
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) acc[t9] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur], xv[cur][t9], acc[t9], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's pieces have landed
+    } else {
+#pragma unroll
+      for (int ss = 0; ss < 16; ++ss) {
+        const int k = 2 * ss + khalf;
+        const float a = Ab[k * 64];
+        const float* xk = Xb + ((k >> LTW) * XW + (k & (TW - 1))) * 64;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw)
+            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xk[(kh * XW + kw) * 64], acc[kh * 3 + kw], 0, 0, 0);
+      }
+      if (more) store_tile(buf ^ 1);
     }
-    if (more) store_tile(buf ^ 1);
     __syncthreads();
   }
 
@@ -543,7 +600,7 @@ __device__ __forceinline__ OutSpec sk_out(const SKGroup& g, const WgradParams& p
   return o;
 }
 
-template <int TW>
+template <int TW, bool DMA>
 __global__ __launch_bounds__(256, 2)
 void conv_wgrad_taps_sk_kernel(const SKGroup g) {
   const int w = blockIdx.x;
@@ -558,7 +615,7 @@ void conv_wgrad_taps_sk_kernel(const SKGroup g) {
     const WgradParams& p = g.p[sgm.idx];
     const int gx = g.gx[sgm.idx];
     if (!first) __syncthreads();   // the previous segment's LDS tiles / bias reduction are done with
-    wgrad_taps_body<TW>(p, sgm.tile % gx, sgm.tile / gx, sgm.k0, sgm.k1, sk_out(g, p, sgm, g.T[sgm.idx], w, 64 * 9 * 64), sk_tid());
+    wgrad_taps_body<TW, DMA>(p, sgm.tile % gx, sgm.tile / gx, sgm.k0, sgm.k1, sk_out(g, p, sgm, g.T[sgm.idx], w, 64 * 9 * 64), sk_tid());
     first = false;
     u += sgm.k1 - sgm.k0;
   }
@@ -1069,20 +1126,20 @@ int launch_variant_sk(const Pending* pend, int n, float* region, hipStream_t st)
   return 0;
 }
 
-template <int TW>
+template <int TW, bool DMA>
 int launch_taps_sk(const Pending* pend, int n, float* region, hipStream_t st) {
   static SKGroup g;
   constexpr int slot = (int)sk_slot_floats(64 * 9 * 64, 64);
-  if (!sk_collect(pend, n, g, region, slot, kCUs * 2, 4, [](const Pending& e) { return e.pl.taps == TW; },
+  if (!sk_collect(pend, n, g, region, slot, kCUs * 2, 4, [](const Pending& e) { return e.pl.taps == TW && dma_ok(e) == DMA; },
                   [](const Pending& e, int& gx, int& gy, int& T) { gx = e.pl.nci; gy = (e.d->Cout + 63) / 64; T = e.p.K >> 5; })) return 0;
   constexpr int XP = (32 / TW + 2) * (TW + 2);
   const size_t lds = (size_t)2 * (32 * 64 + XP * 64) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_taps_sk_kernel<TW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_taps_sk_kernel<TW, DMA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_taps_sk_kernel<TW>), dim3(g.G), dim3(256), lds, st, g);
+  hipLaunchKernelGGL((conv_wgrad_taps_sk_kernel<TW, DMA>), dim3(g.G), dim3(256), lds, st, g);
   CLC_LAUNCH_CHECK();
   if (g.G > 1) {
     hipLaunchKernelGGL(wgrad_sk_compact_kernel, dim3(1), dim3(1024), 0, st, g.plan, g.G, g.plan + 4 * 1280);
@@ -1133,11 +1190,14 @@ int flush_sk(Pending* pend, int& n, float* ws, hipStream_t st) {
   if ((rc = launch_variant_sk<64, 64, true>(pend, n, r, st)) < 0) return rc;    // (the two launches of a family share its region: stream order)
   if ((rc = launch_variant_sk<64, 64, false>(pend, n, r, st)) < 0) return rc;
   r += kSKRegion[3] + kSKPlanFloats;
-  if ((rc = launch_taps_sk<32>(pend, n, r, st)) < 0) return rc;
+  if ((rc = launch_taps_sk<32, true>(pend, n, r, st)) < 0) return rc;
+  if ((rc = launch_taps_sk<32, false>(pend, n, r, st)) < 0) return rc;
   r += kSKRegion[4] + kSKPlanFloats;
-  if ((rc = launch_taps_sk<16>(pend, n, r, st)) < 0) return rc;
+  if ((rc = launch_taps_sk<16, true>(pend, n, r, st)) < 0) return rc;
+  if ((rc = launch_taps_sk<16, false>(pend, n, r, st)) < 0) return rc;
   r += kSKRegion[5] + kSKPlanFloats;
-  if ((rc = launch_taps_sk<8>(pend, n, r, st)) < 0) return rc;
+  if ((rc = launch_taps_sk<8, true>(pend, n, r, st)) < 0) return rc;
+  if ((rc = launch_taps_sk<8, false>(pend, n, r, st)) < 0) return rc;
   n = 0;
   return 0;
 }

@@ -82,12 +82,19 @@ def _flush_family(vid, target):
             if PROFILE is None:
                 _launch_wgrad_group(arr, len(items))
             else:   # bracketed by events and credited with its problems' algorithmic FLOPs (bench.py's roofline leg)
-                fl = sum(2.0 * d.N * d.OH * d.OW * d.ks * d.ks * d.Cin * d.Cout for d, _ in items)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                _launch_wgrad_group(arr, len(items))
-                e1.record()
-                PROFILE.append(("conv_wgrad_group", vid, fl, e0, e1, f"{len(items)} problems"))
+                # one bracket per KERNEL: the C side runs a family's LDS-DMA-staged problems (no fused activation derivative on dy, no
+                # squared input) and the register-staged rest as two launches — the same split here, one call each
+                parts = ([d for d, _ in items if not d.dys and d.in_op == IN_NONE], [d for d, _ in items if d.dys or d.in_op != IN_NONE])
+                for staged_by_dma, ds in zip((True, False), parts):
+                    if not ds:
+                        continue
+                    sub = (_lib.WgradDesc * len(ds))(*ds)
+                    fl = sum(2.0 * d.N * d.OH * d.OW * d.ks * d.ks * d.Cin * d.Cout for d in ds)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    _launch_wgrad_group(sub, len(ds))
+                    e1.record()
+                    PROFILE.append(("conv_wgrad_group", vid, fl, e0, e1, f"{len(ds)} problems dma={int(staged_by_dma)}"))
         for fn in posts:
             fn()
     _KEEPALIVE.append([k for _, k in items])
