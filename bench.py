@@ -227,13 +227,13 @@ def roofline_leg(engine, x, refs):
         if fam != "conv_igemm" or variant < (1 << 20):
             return fam   # conv_direct_small / single (non-deferred) wgrad calls
         tr = "true" if str(shape).startswith("dgrad") else "false"
-        f, bm, bn = variant >> 20, (variant >> 3) & 0xFF, (variant & 7) << 5
+        f, bm, bn = (variant >> 20) & 15, (variant >> 3) & 0x1FF, (variant & 7) << 5
         if f == 3:   # <BN, TR, KW, PF>: 4-wave tiles keep one K-tile in flight, 8-wave ones CLC_TUNE_SPLITK_PF (key 6)
             kw = (variant >> 16) & 15
             return f"conv_igemm_splitk_kernel<{bn}, {tr}, {kw}, {1 if kw == 4 or splitk_pf == 1 else 3}>"
         if f in (4, 5):   # family 5 = the 1x1 instantiation (its own symbol)
             return (f"conv_igemm_dma2_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}, {1 if f == 5 else 3}, "
-                    f"{'true' if (variant >> 11) & 1 else 'false'}>")   # (last argument: squared operand = GDN's norm convolution)
+                    f"{(variant >> 24) & 3}>")   # (last argument: 1 = squared operand, GDN's norm convolution)
         return f"conv_igemm{ {1: '', 2: '_dma'}[f]}_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}>"
 
     agg = {}
@@ -253,7 +253,7 @@ def roofline_leg(engine, x, refs):
     name, (f, t, n, nb) = dom
     # the 1x1 / linear instantiation (..., 1>) moves ~50 FLOP per byte on 128-channel layers — under the f32 ridge once the residual and
     # saved-activation streams are counted — so its roofline is HBM; everything else is MFMA
-    hbm_bound = name.startswith("conv_igemm_dma2_kernel") and (name.endswith(", 1, false>") or name.endswith(", 1, true>")) and nb > 0
+    hbm_bound = name.startswith("conv_igemm_dma2_kernel") and (name.endswith(", 1, 0>") or name.endswith(", 1, 1>")) and nb > 0
     achieved = (nb / t / 1e9) if hbm_bound else (f / t / 1e12)
     peak = HBM_PEAK_GBS if hbm_bound else F32_MFMA_PEAK_TFLOPS
     # HBM-side bytes per launch of that kernel from the committed PMC passes (separate `rocprofv3 --pmc FETCH_SIZE` /

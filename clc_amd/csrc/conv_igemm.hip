@@ -507,7 +507,7 @@ void conv_igemm_dma_kernel(const ConvParams p) {
 //     did not change that).
 // KS = 1: the 1x1 / linear instantiation (one tap: no tap grid, no validity mask; its own symbol, so profiles tell the HBM-bound
 // 1x1 layers from the MFMA-bound 3x3 ones); KS = 3: everything else.
-template <int BM, int BN, int WM, int WN, bool TR, int KS, bool SQ = false>
+template <int BM, int BN, int WM, int WN, bool TR, int KS, int OP = 0>
 __global__ __launch_bounds__(64 * WM * WN, (64 * WM * WN) >= 512 ? 4 : ((64 * WM * WN) >= 256 ? 2 : 4))
 void conv_igemm_dma2_kernel(const ConvParams p) {
   constexpr int NT = 64 * WM * WN;
@@ -633,14 +633,16 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
 #pragma unroll
   for (int t8 = 0; t8 < 4; ++t8) fo[t8] = ((2 * t8 + hh) ^ sw) * 4;
   f32x4 af[2][TM], bf[2][TN];
-  // SQ (GDN's norm convolution, a 1x1 layer: its own instantiation): the operand is squared on its way out of LDS — DMA cannot
+  // OP = 1 (GDN's norm convolution, a 1x1 layer: its own instantiation): the operand is squared on its way OUT of LDS — DMA cannot.
+  // (The same trick for data gradients with a fused activation derivative on the operand — the saved tile fetched by DMA beside
+  // it, operand * act'(saved) at fragment read — was built and measured: -0.3 %, the second operand tile costs a resident workgroup.)
   auto read_frag = [&](int buf, int t8, f32x4 (&a)[TM], f32x4 (&b)[TN]) {
     const float* Ab = As + (buf * BM + wm * (BM / WM) + lr) * BK + fo[t8];
     const float* Bb = Bs + (buf * BN + wn * (BN / WN) + lr) * BK + fo[t8];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * BK);
-      if (SQ) a[i] = a[i] * a[i];
+      if (OP == 1) a[i] = a[i] * a[i];
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * BK);
@@ -861,29 +863,29 @@ int launch_dma_t(const ConvParams& p, int classes, hipStream_t st) {
   CLC_LAUNCH_CHECK();
   return (2 << 20) | (WM << 16) | (WN << 12) | (BM << 3) | (BN >> 5);  // family 2 = conv_igemm_dma_kernel<BM,BN,WM,WN>
 }
-template <int BM, int BN, int WM, int WN, bool TR, int KS, bool SQ = false>
+template <int BM, int BN, int WM, int WN, bool TR, int KS, int OP = 0>
 int launch_dma2_t(const ConvParams& p, int classes, hipStream_t st) {
   dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, classes);
   constexpr size_t lds_ab = (size_t)2 * (BM + BN) * BK * sizeof(float), lds_c = (size_t)BM * (BN + 4) * sizeof(float);
   constexpr size_t lds = lds_ab > lds_c ? lds_ab : lds_c;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma2_kernel<BM, BN, WM, WN, TR, KS, SQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma2_kernel<BM, BN, WM, WN, TR, KS, OP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   ConvParams q = p;
   const int xm = clc_tuning[CLC_TUNE_XCD_MAP];
   q.xcd_map = grid.y > 1 && grid.x % 8 == 0 && (xm == 2 || (xm == 1 && KS == 1));
-  hipLaunchKernelGGL((conv_igemm_dma2_kernel<BM, BN, WM, WN, TR, KS, SQ>), grid, dim3(64 * WM * WN), lds, st, q);
+  hipLaunchKernelGGL((conv_igemm_dma2_kernel<BM, BN, WM, WN, TR, KS, OP>), grid, dim3(64 * WM * WN), lds, st, q);
   CLC_LAUNCH_CHECK();
-  return ((KS == 1 ? 5 : 4) << 20) | (WM << 16) | (WN << 12) | ((SQ ? 1 : 0) << 11) | (BM << 3) | (BN >> 5);  // family 4 / 5 = conv_igemm_dma2_kernel<BM,BN,WM,WN,TR,3 / 1,SQ>
+  return ((KS == 1 ? 5 : 4) << 20) | (OP << 24) | (WM << 16) | (WN << 12) | (BM << 3) | (BN >> 5);  // family 4 / 5 = conv_igemm_dma2_kernel<BM,BN,WM,WN,TR,3 / 1,OP>
 }
 template <int BM, int BN, int WM, int WN>
 int launch(const ConvParams& p, int classes, hipStream_t st) {
   static const int use_dma = getenv("CLC_DMA") ? atoi(getenv("CLC_DMA")) : 1;   // CLC_DMA=0: register staging everywhere (A/B knob)
   static const int dma_small = getenv("CLC_DMA_SMALL") ? atoi(getenv("CLC_DMA_SMALL")) : 1;
   if (use_dma && p.in_op == CLC_IN_SQUARE && p.xs == nullptr && p.ks == 1 && p.stride == 1 && (BM >= 128 || dma_small) && clc_tuning[CLC_TUNE_DMA_LOOP] == 2)
-    return p.transposed ? launch_dma2_t<BM, BN, WM, WN, true, 1, true>(p, classes, st) : launch_dma2_t<BM, BN, WM, WN, false, 1, true>(p, classes, st);
+    return p.transposed ? launch_dma2_t<BM, BN, WM, WN, true, 1, 1>(p, classes, st) : launch_dma2_t<BM, BN, WM, WN, false, 1, 1>(p, classes, st);
   if (use_dma && p.in_op == CLC_IN_NONE && p.xs == nullptr && (BM >= 128 || dma_small) && clc_tuning[CLC_TUNE_DMA_LOOP] == 2)
     return p.ks == 1 && p.stride == 1
                ? (p.transposed ? launch_dma2_t<BM, BN, WM, WN, true, 1>(p, classes, st) : launch_dma2_t<BM, BN, WM, WN, false, 1>(p, classes, st))
