@@ -378,7 +378,7 @@ class CLC(_SliceCodec):
     # never calls them.  wire_clm = True applies them the one way their constructor shapes admit: CLM(192) pairs the hyper-latent z with
     # a 192-channel feature of each reference at z's resolution — h_a of that reference's latent, one batched pass — and
     # multi_ref_fusion (192 * (R + 1) -> 256 -> 192) fuses z with the R aligned features.  Encoder side only (forward / compress):
-    # the decoder receives the fused z_hat.  oracle/graph.py restates the same definition; the modules themselves are pinned against
+    # the decoder receives the fused z_hat.  The CPU checker restates the same definition; the modules themselves are pinned against
     # the genuine classes (tests/golden/dormant.npz).
     wire_clm = False
 
