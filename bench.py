@@ -299,6 +299,9 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if os.environ.get("CLC_BENCH_WATCHDOG"):   # debugging aid: dump every thread's Python stack after N seconds (a hung collective / capture)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["CLC_BENCH_WATCHDOG"]), repeat=True, file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
