@@ -168,6 +168,7 @@ BRANCH_STREAMS = False
 # two launches, optionally on forked streams).
 PAIR_SLICES = int(os.environ.get("CLC_PAIR", "1"))   # default on: half the launches of the slice loop, no reliance on hipGraph branch concurrency
 SUPPORT_BUFFER = int(os.environ.get("CLC_SUPPORT_BUFFER", "1"))   # slice loop: one support buffer + one gradient buffer instead of per-slice concatenations (SliceSupport)
+MATERIALIZE_DZ = int(os.environ.get("CLC_MATERIALIZE_DZ", "32768"))   # rows from which a 3x3 layer's activation backward is its own pass (0: always fused into the gradient kernels' loaders)
 QUAD_UNITS = int(os.environ.get("CLC_QUAD_UNITS", "1"))   # paired SWAttens: the ResidualUnits of conv_a and conv_b of both nets in one chain (4 filter sets)
 PAIR_HYPER = int(os.environ.get("CLC_PAIR_HYPER", "1"))   # also pair the mean / scale hyper-synthesis nets (h_mean_s, h_scale_s)
 BRANCH_SLOTS = set(os.environ.get("CLC_BRANCH", "scale").split(","))   # which forks are taken (debug knob)
@@ -624,6 +625,11 @@ class _ConvFn(Function):
         gate_park = (need_res and res_first and not shuffle and act in (ACT_LRELU, ACT_RELU) and fold_out is not None
                      and fold_out.gated and fold_out.can_park())
         fuse = act in (ACT_LRELU, ACT_RELU, ACT_SAVED_DERIV) and not shuffle and (not (need_res and res_first) or gate_park)
+        # Large-map 3x3 layers whose derivative no consumer applied (ActGate): ONE elementwise pass dz = dy * act'(.) and then the
+        # LDS-DMA data- and filter-gradient kernels beat the fused loaders of the register-staged ones (64 -> 64 @ 8x128x128:
+        # 160 + 119 us fused vs 22 + 106 + 102 us)
+        if fuse and MATERIALIZE_DZ and ks == 3 and act != ACT_NONE and not gate_park and dy.shape[0] * dy.shape[2] * dy.shape[3] >= MATERIALIZE_DZ and ctx.needs_input_grad[0]:
+            fuse = False
         one_pass_unshuffle = shuffle and not (need_res and res_first)
         if one_pass_unshuffle:   # PixelShuffle(2) backward and the activation backward in ONE pass over dy
             dz = unshuffle_act_bwd(dy, saved_act if act != ACT_NONE else None, ctx.use_pre, act)
