@@ -217,7 +217,7 @@ def roofline_leg(engine, x, refs):
 
     def kernel_name(fam, variant, shape):
         """the name rocprofv3 --kernel-trace reports for this launch (template arguments from the C ABI's variant id)"""
-        if fam == "conv_wgrad_group":   # one kernel family of a grouped stream-K filter-gradient call (+ its compact / fix-up launches)
+        if fam == "conv_wgrad_group":   # one kernel family of a grouped stream-K filter-gradient call (+ its fix-up launch)
             dma = "true" if str(shape).endswith("dma=1") and wgrad_dma else "false"   # <..., true>: LDS-DMA-staged instantiation
             if variant == 1:
                 return "wgrad_small_kernel"
@@ -247,7 +247,7 @@ def roofline_leg(engine, x, refs):
     total_t = sum(a[1] for a in agg.values())
     total_f = sum(a[0] for a in agg.values())
     # the dominant KERNEL by summed time; a stream-K filter-gradient family competes with its algorithmic FLOPs over the time of its
-    # main kernel + compact + fix-up launches (the bracket cannot separate them; the fix-up is ~1-3 % of it)
+    # main kernel + fix-up launch (the bracket cannot separate them; the fix-up is ~1-3 % of it)
     single = {k: v for k, v in agg.items() if "_kernel<" in k}
     dom = max((single or agg).items(), key=lambda kv: kv[1][1])
     name, (f, t, n, nb) = dom
@@ -275,7 +275,7 @@ def roofline_leg(engine, x, refs):
             "timing_note": "event-bracketed eager step (HIP events cannot be recorded inside a hipGraph on ROCm 7.2), enqueued behind a spin kernel so "
                            "that the launches run back to back as in the graph replay of the timed region; a bracket still adds the timestamp packets' "
                            "own latency to short kernels (event_bracket_overhead_ms is subtracted), so rocprofv3's graph-replay averages "
-                           "(profiles/) read a few % lower; a stream-K filter-gradient family is timed with its compact + fix-up launches",
+                           "(profiles/) read a few % lower; a stream-K filter-gradient family is timed with its fix-up launch",
             "all_mfma_kernels": {"tflops": round(total_f / total_t / 1e12, 2), "ms_per_step": round(total_t * 1e3, 2), "gflop_per_step": round(total_f / 1e9, 1)},
             "per_kernel": table}
 

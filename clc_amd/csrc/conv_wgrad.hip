@@ -647,43 +647,41 @@ void conv_wgrad_sk_kernel(const SKGroup g) {
 }
 
 // Fix-up: adds the partials of every split tile in workgroup order.  grid (256-element chunks of the tile image, kFixY).
-// wgrad_sk_compact_kernel first packs the plan (one entry per workgroup, written by the stream-K kernel) into a list of the
+// Every block first packs the plan (one entry per workgroup, written by the stream-K kernel) into a list of the
 // split tiles' last contributors, in workgroup order; block (x, y) of the fix-up takes list entries y, y + kFixY, ...
 // Per entry the block is 64 float4 columns x 4 groups: group q sums partials q, q+4, ... (4 loads in flight), the groups are
 // combined as (g0+g1)+(g2+g3): a fixed order -> run-to-run reproducible.
 // TAPS = 9: tile image [64][9][64] (+64 bias sums); TAPS = 1: [BM][BN] of one tap (+BM bias sums).
 constexpr int kFixY = 64;
-// one block: the plan's live entries (last-contributor workgroups), ascending, into list[1..], their count into list[0]
-__global__ __launch_bounds__(1024) void wgrad_sk_compact_kernel(const int* __restrict__ plan, int G, int* __restrict__ list) {
-  __shared__ int wave_cnt[16];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  int n_list = 0;
-  for (int base = 0; base < G; base += 1024) {
-    const int w = base + tid;
-    const bool on = w < G && plan[4 * w + 3] != 0;
-    const unsigned long long m = __ballot(on);
-    if (lane == 0) wave_cnt[wv] = __popcll(m);
-    __syncthreads();
-    int off = n_list, tot = 0;
-    for (int q = 0; q < 16; ++q) { if (q < wv) off += wave_cnt[q]; tot += wave_cnt[q]; }
-    if (on) list[1 + off + __popcll(m & ((1ull << lane) - 1ull))] = w;
-    n_list += tot;
-    __syncthreads();
-  }
-  if (tid == 0) list[0] = n_list;
-}
-
 template <int BM, int BN, int TAPS>
 __global__ __launch_bounds__(256) void wgrad_sk_fixup_kernel(const SKGroup g) {
   constexpr int TILE = BM * TAPS * BN;
   __shared__ f32x4 sm[4][64];
+  __shared__ int list[1280];
+  __shared__ int wave_cnt[4];
   const int tid = threadIdx.x;
-  const int* list = g.plan + 4 * 1280;
-  const int n_list = list[0];
+  // the plan's live entries (last-contributor workgroups), ascending: every block packs its own copy (G <= 1280 entries: five
+  // ballot rounds — cheaper than the dispatch of a separate one-block pass, which costs ~4.6 us inside the graph)
+  int n_list = 0;
+  {
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int base = 0; base < g.G; base += 256) {
+      const int w = base + tid;
+      const bool on = w < g.G && g.plan[4 * w + 3] != 0;
+      const unsigned long long m = __ballot(on);
+      if (lane == 0) wave_cnt[wv] = __popcll(m);
+      __syncthreads();
+      int off = n_list, tot = 0;
+      for (int q = 0; q < 4; ++q) { if (q < wv) off += wave_cnt[q]; tot += wave_cnt[q]; }
+      if (on) list[off + __popcll(m & ((1ull << lane) - 1ull))] = w;
+      n_list += tot;
+      __syncthreads();
+    }
+  }
   const int col = tid & 63, grp = tid >> 6;
   const int e = (blockIdx.x * 64 + col) * 4;              // element of the tile image (+ bias tail)
   for (int li = blockIdx.y; li < n_list; li += kFixY) {
-    const int wl = list[1 + li];
+    const int wl = list[li];
     const int idx = g.plan[4 * wl], tile = g.plan[4 * wl + 1], wf = g.plan[4 * wl + 2];
     const WgradParams& p = g.p[idx];
     const int gx = g.gx[idx];
@@ -1118,8 +1116,6 @@ int launch_variant_sk(const Pending* pend, int n, float* region, hipStream_t st)
   hipLaunchKernelGGL((conv_wgrad_sk_kernel<BM, BN, 2, 2, DMA>), dim3(g.G), dim3(256), lds, st, g);
   CLC_LAUNCH_CHECK();
   if (g.G > 1) {
-    hipLaunchKernelGGL(wgrad_sk_compact_kernel, dim3(1), dim3(1024), 0, st, g.plan, g.G, g.plan + 4 * 1280);
-    CLC_LAUNCH_CHECK();
     hipLaunchKernelGGL((wgrad_sk_fixup_kernel<BM, BN, 1>), dim3((BM * BN + BM + 255) / 256, kFixY), dim3(256), 0, st, g);
     CLC_LAUNCH_CHECK();
   }
@@ -1142,8 +1138,6 @@ int launch_taps_sk(const Pending* pend, int n, float* region, hipStream_t st) {
   hipLaunchKernelGGL((conv_wgrad_taps_sk_kernel<TW, DMA>), dim3(g.G), dim3(256), lds, st, g);
   CLC_LAUNCH_CHECK();
   if (g.G > 1) {
-    hipLaunchKernelGGL(wgrad_sk_compact_kernel, dim3(1), dim3(1024), 0, st, g.plan, g.G, g.plan + 4 * 1280);
-    CLC_LAUNCH_CHECK();
     hipLaunchKernelGGL((wgrad_sk_fixup_kernel<64, 64, 9>), dim3((64 * 9 * 64 + 64 + 255) / 256, kFixY), dim3(256), 0, st, g);
     CLC_LAUNCH_CHECK();
   }

@@ -112,7 +112,7 @@ def _flush_target():
 
 def flush_wgrads():
     """Launch everything queued.  Problems wait in one queue PER KERNEL FAMILY (a family's queue is launched as soon as it holds
-    WGRAD_GROUP problems): a flush then costs one stream-K grid (+ compact + fix-up) per family that has work, with full groups,
+    WGRAD_GROUP problems): a flush then costs one stream-K grid (+ fix-up) per family that has work, with full groups,
     instead of one under-filled grid of every family for each 64 problems in arrival order."""
     if not _PENDING and not _PENDING_POST:
         return
