@@ -1,4 +1,5 @@
 #!/bin/bash
+# wave-cycle breakdown (wait / issue / LDS) per kernel of one replayed step: two PMC passes, summarised by tools/pmc_waits.py
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmcw; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/a -o pmc -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-parity > $O/a.log 2>&1 || { echo "pmc a failed"; tail -5 $O/a.log; exit 5; }
