@@ -126,6 +126,43 @@ def test_backward_parity(dev, kind, R, B):
     print(kind, R, "checked", checked, "worst rel err", worst)
 
 
+def test_slice_loop_launch_merging_keeps_the_bits(dev, monkeypatch):
+    """The slice loop's launch-count reductions — four filter sets per launch (CLC_QUAD_UNITS), the support / gradient buffers
+    (CLC_SUPPORT_BUFFER), the separate activation-backward pass of large 3x3 layers (CLC_MATERIALIZE_DZ) — only regroup work: the
+    forward results are bit-identical with and without them, the gradients equal up to fp32 accumulation order."""
+    from clc_amd import ops
+    from clc_amd.train import RateDistortionLoss as PRD
+
+    _, p = _pair("clc", 1, dev)
+    x, refs = _inputs(2, 1)
+    xd, rd = x.to(dev), [r.to(dev) for r in refs]
+
+    def run():
+        p.zero_grad(set_to_none=True)
+        out = p(xd, rd)
+        PRD(0.0067)(out, xd)["loss"].backward()
+        ops.flush_wgrads()
+        torch.cuda.synchronize()
+        return out, {n: q.grad.clone() for n, q in p.named_parameters() if q.grad is not None}
+
+    out1, g1 = run()
+    monkeypatch.setattr(ops, "QUAD_UNITS", 0)
+    monkeypatch.setattr(ops, "SUPPORT_BUFFER", 0)
+    monkeypatch.setattr(ops, "MATERIALIZE_DZ", 0)
+    out0, g0 = run()
+    for k in ("x_hat",):
+        assert torch.equal(out1[k], out0[k]), k
+    for k in ("y", "z"):
+        assert torch.equal(out1["likelihoods"][k], out0["likelihoods"][k]), k
+    assert g1.keys() == g0.keys()
+    worst = 0.0
+    for n in g1:
+        d = g0[n].abs().max().item()
+        if d > 1e-12:
+            worst = max(worst, (g1[n] - g0[n]).abs().max().item() / d)
+    assert worst < 2e-4, worst
+
+
 @pytest.mark.parametrize("R", [1])
 def test_wire_clm_forward_backward_vs_oracle(dev, R):
     """SURVEY 8(f)-4 (an extension, not reference behaviour): wire_clm = True routes the hyper-latent through feature_alignment /
