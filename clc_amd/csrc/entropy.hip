@@ -229,7 +229,6 @@ __device__ void block_reduce_store(float v, float* dst, float* sm) {
 __global__ __launch_bounds__(256) void eb_lik_bwd_kernel(const float* __restrict__ dlik, int lddl, const float* __restrict__ z, int ldz,
                                                        const float* __restrict__ noise, int ldn, const float* __restrict__ quantiles, EBParams P,
                                                        EBGrads G, float* __restrict__ dz, int lddz, long rows, int C, int mode) {
-  __shared__ float sm[256];
   const int ch = blockIdx.x;
   EBChan c;
   eb_load(P, ch, c);
@@ -256,13 +255,45 @@ __global__ __launch_bounds__(256) void eb_lik_bwd_kernel(const float* __restrict
     const float dxl = eb_backward(c, tl, gl, &acc);
     if (dz) dz[r * lddz + ch] = (mode == 0) ? (dxu + dxl) : 0.f;
   }
-  // per-channel parameter gradients: deterministic workgroup reduction
+  // per-channel parameter gradients: deterministic workgroup reduction — the SAME pairwise tree as block_reduce_store (t += t + o,
+  // o = 128 ... 1), but for all accumulators at once: 2 x 9 barriers instead of 58 x 10 (this kernel was 100 us for 24 K elements)
+  __shared__ float red[36][256];
+  __shared__ float tot[72];
+  float flat[72];
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
-    const int fo = eb_f(k + 1), fi = eb_f(k);
-    for (int i = 0; i < fo * fi; ++i) block_reduce_store(acc.m[k][i], &G.m[k][ch * fo * fi + i], sm);
-    for (int i = 0; i < fo; ++i) block_reduce_store(acc.b[k][i], &G.b[k][ch * fo + i], sm);
-    if (k < 4) for (int i = 0; i < fo; ++i) block_reduce_store(acc.f[k][i], &G.f[k][ch * fo + i], sm);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) flat[k * 9 + i] = acc.m[k][i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) flat[45 + k * 3 + i] = acc.b[k][i];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) flat[60 + k * 3 + i] = acc.f[k][i];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int i = 0; i < 36; ++i) red[i][threadIdx.x] = flat[half * 36 + i];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      for (int idx = threadIdx.x; idx < 36 * o; idx += 256) {
+        const int i = idx / o, t = idx - i * o;
+        red[i][t] += red[i][t + o];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x < 36) tot[half * 36 + threadIdx.x] = red[threadIdx.x][0];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int fo = eb_f(k + 1), fi = eb_f(k);
+      for (int i = 0; i < fo * fi; ++i) G.m[k][ch * fo * fi + i] = tot[k * 9 + i];
+      for (int i = 0; i < fo; ++i) G.b[k][ch * fo + i] = tot[45 + k * 3 + i];
+      if (k < 4) for (int i = 0; i < fo; ++i) G.f[k][ch * fo + i] = tot[60 + k * 3 + i];
+    }
   }
 }
 
