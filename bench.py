@@ -183,8 +183,120 @@ def parity_and_codec(dev):
     return parity, codec
 
 
+def _kernel_name(L, r):
+    """the name rocprofv3 --kernel-trace reports for a recorded conv / filter-gradient launch (template arguments from the C ABI's
+    variant id); launches recorded through the proxy keep the name of their C entry point"""
+    fam, variant, shape = r.fam, r.variant, str(r.label)
+    splitk_pf = L.clc_set_tuning(6, 1)
+    L.clc_set_tuning(6, splitk_pf)
+    wgrad_dma = L.clc_set_tuning(9, 1)
+    L.clc_set_tuning(9, wgrad_dma)
+    if fam == "conv_wgrad_group":   # one kernel family of a grouped stream-K filter-gradient call (+ its fix-up launch)
+        dma = "true" if shape.endswith("dma=1") and wgrad_dma else "false"   # <..., true>: LDS-DMA-staged instantiation
+        if variant == 1:
+            return "wgrad_small_kernel"
+        if variant in (64908, 64916, 64932):
+            return f"conv_wgrad_taps_sk_kernel<{variant - 64900}, {dma}>"
+        return f"conv_wgrad_sk_kernel<{variant // 1000}, {variant % 1000}, 2, 2, {dma}>"
+    if fam != "conv_igemm" or variant < (1 << 20):
+        return fam   # conv_direct_small / single (non-deferred) wgrad calls / proxied entry points
+    tr = "true" if shape.startswith("dgrad") else "false"
+    f, bm, bn = (variant >> 20) & 15, (variant >> 3) & 0x1FF, (variant & 7) << 5
+    if f == 3:   # <BN, TR, KW, PF>: 4-wave tiles keep one K-tile in flight, 8-wave ones CLC_TUNE_SPLITK_PF (key 6)
+        kw = (variant >> 16) & 15
+        return f"conv_igemm_splitk_kernel<{bn}, {tr}, {kw}, {1 if kw == 4 or splitk_pf == 1 else 3}>"
+    if f in (4, 5, 6):   # family 5 = the 1x1 instantiation (its own symbol)
+        return (f"conv_igemm_dma2_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}, {1 if f == 5 else 3}, "
+                f"{(variant >> 24) & 3}>")   # (last argument: 1 = squared operand, GDN's norm convolution)
+    return f"conv_igemm{ {1: '', 2: '_dma'}[f]}_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}>"
+
+
+def _replay_ms(fn, reps=20, warm=2):
+    """median wall time (ms, HIP events) of `fn` captured ONCE into a hipGraph and replayed `reps` times — how the timed region runs"""
+    import statistics
+
+    import torch
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(warm):
+            fn()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    g.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return statistics.median(ts), g
+
+
+def transforms_leg(model, x, refs):
+    """The number north_star's target is stated on: the analysis / synthesis transforms (and the reference encoder) on their own —
+    forward + data gradients + filter gradients of g_a, g_s, ref_encoder(+adapter) at the bench batch, EVERY kernel they launch
+    (convolutions, GDN, LayerNorm, window attention, elementwise, grouped stream-K filter gradients and their fix-ups), each captured
+    into a hipGraph and replayed 20x (median).  FLOPs = the algorithmic 2*MAC of the convolutions / linears / attention products
+    launched in that pass (forward + data gradient + filter gradient), counted by clc_amd.ops' launch records."""
+    import torch
+
+    from clc_amd import ops
+
+    CL = torch.channels_last
+    with torch.no_grad():
+        y = model.g_a(model._prep(x))
+    g = torch.Generator(device=x.device).manual_seed(5)
+    y_hat = torch.randn(y.shape, generator=g, device=x.device).contiguous(memory_format=CL).requires_grad_(True)
+    xin = model._prep(x)
+    cases = {"g_a": (lambda: model.g_a(xin)), "g_s": (lambda: model.g_s(y_hat)),
+             "ref_encoder+adapter": (lambda: model._ref(refs))}
+    if refs is None:
+        cases.pop("ref_encoder+adapter")
+    out = {}
+    tot_f = tot_t = 0.0
+    for name, fwd in cases.items():
+        with torch.no_grad():
+            shape = fwd().shape
+        gout = torch.randn(shape, generator=g, device=x.device).contiguous(memory_format=CL)
+
+        def step():
+            y_hat.grad = None
+            o = fwd()
+            torch.autograd.backward([o], [gout])
+            ops.join_side_streams()
+
+        ops.PROFILE = []
+        try:
+            step()
+            torch.cuda.synchronize()
+            flops = sum(r.flops for r in ops.PROFILE)
+            launches = len(ops.PROFILE)
+        finally:
+            ops.PROFILE = None
+        ms, graph = _replay_ms(step)
+        del graph
+        out[name] = {"gflop": round(flops / 1e9, 1), "ms": round(ms, 3), "tflops": round(flops / ms / 1e9, 2), "c_abi_launches": launches}
+        tot_f += flops
+        tot_t += ms
+    out["total"] = {"gflop": round(tot_f / 1e9, 1), "ms": round(tot_t, 3), "tflops": round(tot_f / tot_t / 1e9, 2),
+                    "frac_of_f32_mfma_peak": round(tot_f / tot_t / 1e9 / F32_MFMA_PEAK_TFLOPS, 4), "target_frac": 0.5}
+    out["method"] = ("each sub-network alone: forward + backward (data and filter gradients, all kernels incl. attention / LayerNorm / GDN / "
+                     "elementwise / stream-K fix-ups) captured into one hipGraph, median of 20 replays; FLOPs = algorithmic 2*MAC x (fwd + dgrad + wgrad)")
+    return out
+
+
 def roofline_leg(engine, x, refs):
-    """One eager (non-graph) step with every conv / wgrad launch bracketed by HIP events on its launch stream."""
+    """One eager (non-graph) step with every launch through the C ABI bracketed by HIP events on its launch stream (per-kernel table,
+    dominant kernel, in-step attribution to the sub-networks); then the dominant kernel's launches re-issued inside a hipGraph and
+    replayed — the way the timed region runs them — for `roofline.achieved`."""
     import torch
 
     from clc_amd import lib as _clib
@@ -210,47 +322,43 @@ def roofline_leg(engine, x, refs):
     finally:
         ops.PROFILE = None
     _L = _clib.load()
-    splitk_pf = _L.clc_set_tuning(6, 1)
-    _L.clc_set_tuning(6, splitk_pf)
-    wgrad_dma = _L.clc_set_tuning(9, 1)
-    _L.clc_set_tuning(9, wgrad_dma)
-
-    def kernel_name(fam, variant, shape):
-        """the name rocprofv3 --kernel-trace reports for this launch (template arguments from the C ABI's variant id)"""
-        if fam == "conv_wgrad_group":   # one kernel family of a grouped stream-K filter-gradient call (+ its fix-up launch)
-            dma = "true" if str(shape).endswith("dma=1") and wgrad_dma else "false"   # <..., true>: LDS-DMA-staged instantiation
-            if variant == 1:
-                return "wgrad_small_kernel"
-            if variant in (64908, 64916, 64932):
-                return f"conv_wgrad_taps_sk_kernel<{variant - 64900}, {dma}>"
-            return f"conv_wgrad_sk_kernel<{variant // 1000}, {variant % 1000}, 2, 2, {dma}>"
-        if fam != "conv_igemm" or variant < (1 << 20):
-            return fam   # conv_direct_small / single (non-deferred) wgrad calls
-        tr = "true" if str(shape).startswith("dgrad") else "false"
-        f, bm, bn = (variant >> 20) & 15, (variant >> 3) & 0x1FF, (variant & 7) << 5
-        if f == 3:   # <BN, TR, KW, PF>: 4-wave tiles keep one K-tile in flight, 8-wave ones CLC_TUNE_SPLITK_PF (key 6)
-            kw = (variant >> 16) & 15
-            return f"conv_igemm_splitk_kernel<{bn}, {tr}, {kw}, {1 if kw == 4 or splitk_pf == 1 else 3}>"
-        if f in (4, 5):   # family 5 = the 1x1 instantiation (its own symbol)
-            return (f"conv_igemm_dma2_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}, {1 if f == 5 else 3}, "
-                    f"{(variant >> 24) & 3}>")   # (last argument: 1 = squared operand, GDN's norm convolution)
-        return f"conv_igemm{ {1: '', 2: '_dma'}[f]}_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}>"
-
-    agg = {}
-    for fam, variant, flops, e0, e1, *rest in rec:
-        key = kernel_name(fam, variant, rest[0] if rest else "")
-        a = agg.setdefault(key, [0.0, 0.0, 0, 0.0])
-        a[0] += flops
-        a[1] += max(e0.elapsed_time(e1) * 1e-3 - empty, 1e-7)
+    agg, by_owner = {}, {}
+    for r in rec:
+        key = _kernel_name(_L, r)
+        t = max(r.ms() * 1e-3 - empty, 1e-7)
+        a = agg.setdefault(key, [0.0, 0.0, 0, 0.0, []])
+        a[0] += r.flops
+        a[1] += t
         a[2] += 1
-        a[3] += rest[1] if len(rest) > 1 else 0.0
-    total_t = sum(a[1] for a in agg.values())
-    total_f = sum(a[0] for a in agg.values())
+        a[3] += r.nbytes or 0.0
+        a[4].append(r)
+        # in-step attribution: a grouped filter-gradient launch is split over the owners of its problems by FLOP share
+        shares = r.owner_flops if r.owner_flops else {r.owner: max(r.flops, 1.0)}
+        tot = sum(shares.values())
+        for ow, fl in shares.items():
+            o = by_owner.setdefault(ow, [0.0, 0.0, 0])
+            o[0] += (fl if r.owner_flops or r.flops else 0.0)
+            o[1] += t * fl / tot
+            o[2] += 1
+    mfma = {k: v for k, v in agg.items() if v[0] > 0}
+    total_t = sum(a[1] for a in mfma.values())
+    total_f = sum(a[0] for a in mfma.values())
     # the dominant KERNEL by summed time; a stream-K filter-gradient family competes with its algorithmic FLOPs over the time of its
     # main kernel + fix-up launch (the bracket cannot separate them; the fix-up is ~1-3 % of it)
     single = {k: v for k, v in agg.items() if "_kernel<" in k}
     dom = max((single or agg).items(), key=lambda kv: kv[1][1])
-    name, (f, t, n, nb) = dom
+    name, (f, t_eager, n, nb, recs) = dom
+    # ... timed the way the timed region runs it: its launches of this step re-issued in order inside ONE hipGraph, replayed 20x
+    relaunch = [r.relaunch for r in recs if r.relaunch is not None]
+    t_replay = None
+    if len(relaunch) == n:
+        def again():
+            for fn in relaunch:
+                fn()
+        ms, graph = _replay_ms(again)
+        del graph
+        t_replay = ms * 1e-3
+    t = t_replay if t_replay is not None else t_eager
     # the 1x1 / linear instantiation (..., 1>) moves ~50 FLOP per byte on 128-channel layers — under the f32 ridge once the residual and
     # saved-activation streams are counted — so its roofline is HBM; everything else is MFMA
     hbm_bound = name.startswith("conv_igemm_dma2_kernel") and (name.endswith(", 1, 0>") or name.endswith(", 1, 1>")) and nb > 0
@@ -259,24 +367,37 @@ def roofline_leg(engine, x, refs):
     # HBM-side bytes per launch of that kernel from the committed PMC passes (separate `rocprofv3 --pmc FETCH_SIZE` /
     # `--pmc WRITE_SIZE` runs of this same command, gfx950 FETCH_SIZE correction applied: tools/pmc_traffic.py); null when the
     # file does not list the kernel
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as fh:
-            k = json.load(fh)["kernels"].get(name)
-        if k and k["launches_per_step"]:
-            traffic = round((k["fetch_bytes_per_step"] + k["write_bytes_per_step"]) / k["launches_per_step"])
-    except (OSError, KeyError, ValueError):
-        traffic = None
-    table = {k: {"launches": v[2], "gflop": round(v[0] / 1e9, 2), "ms": round(v[1] * 1e3, 3), "tflops": round(v[0] / v[1] / 1e12, 2),
+    traffic, traffic_source = None, None
+    for cand in ("r3_pmc_traffic.json", "r2_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", cand)) as fh:
+                k = json.load(fh)["kernels"].get(name)
+            if k and k["launches_per_step"]:
+                traffic = round((k["fetch_bytes_per_step"] + k["write_bytes_per_step"]) / k["launches_per_step"])
+                traffic_source = f"profiles/{cand} (committed PMC passes of this command, not measured in this run)"
+                break
+        except (OSError, KeyError, ValueError):
+            continue
+    table = {k: {"launches": v[2], "gflop": round(v[0] / 1e9, 2), "ms": round(v[1] * 1e3, 3),
+                 **({"tflops": round(v[0] / v[1] / 1e12, 2)} if v[0] else {}),
                  **({"algorithmic_gb_per_s": round(v[3] / v[1] / 1e9, 1)} if v[3] else {})} for k, v in agg.items()}
+    owners = {ow: {"launches": v[2], "gflop": round(v[0] / 1e9, 1), "ms": round(v[1] * 1e3, 3), "tflops": round(v[0] / v[1] / 1e12, 2)}
+              for ow, v in by_owner.items()}
+    tr = [v for ow, v in by_owner.items() if ow in ("g_a", "g_s", "ref_encoder")]
+    if tr:
+        ff, tt = sum(v[0] for v in tr), sum(v[1] for v in tr)
+        owners["transforms"] = {"gflop": round(ff / 1e9, 1), "ms": round(tt * 1e3, 3), "tflops": round(ff / tt / 1e12, 2),
+                                "frac_of_f32_mfma_peak": round(ff / tt / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
     return {"bound": "hbm" if hbm_bound else "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s" if hbm_bound else "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic,
-            "launches_per_step": n, "avg_launch_ms": round(t / n * 1e3, 4), "event_bracket_overhead_ms": round(empty * 1e3, 5),
-            "timing_note": "event-bracketed eager step (HIP events cannot be recorded inside a hipGraph on ROCm 7.2), enqueued behind a spin kernel so "
-                           "that the launches run back to back as in the graph replay of the timed region; a bracket still adds the timestamp packets' "
-                           "own latency to short kernels (event_bracket_overhead_ms is subtracted), so rocprofv3's graph-replay averages "
-                           "(profiles/) read a few % lower; a stream-K filter-gradient family is timed with its fix-up launch",
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "launches_per_step": n, "avg_launch_ms": round(t / n * 1e3, 4),
+            "avg_launch_ms_eager_bracketed": round(t_eager / n * 1e3, 4), "event_bracket_overhead_ms": round(empty * 1e3, 5),
+            "timing_note": ("achieved / avg_launch_ms: this kernel's launches of one step (stream-K family: main grid + fix-up) re-issued in order inside "
+                            "one hipGraph, median of 20 replays — comparable with rocprofv3's graph-replay averages in profiles/.  per_kernel / "
+                            "in_step_by_owner: one eager step with every C-ABI launch bracketed by HIP events (they cannot be recorded inside a "
+                            "hipGraph on ROCm 7.2), enqueued behind a spin kernel; brackets read 5-15 % long on a loaded box"),
             "all_mfma_kernels": {"tflops": round(total_f / total_t / 1e12, 2), "ms_per_step": round(total_t * 1e3, 2), "gflop_per_step": round(total_f / 1e9, 1)},
+            "in_step_by_owner": owners,
             "per_kernel": table}
 
 
@@ -375,6 +496,8 @@ def main():
     }
     if not args.no_roofline:  # every rank runs it (the eager step contains the gradient all-reduce); rank 0 reports
         result["roofline"] = roofline_leg(engine, x, refs)
+        if rank == 0 and world == 1:
+            result["roofline"]["transforms"] = transforms_leg(model, x, refs)
     if rank == 0:
         if world == 1 and not args.no_parity:
             result["parity"], result["codec"] = parity_and_codec(dev)

@@ -18,6 +18,7 @@ enum { CLC_TUNE_DMA_LOOP = 0 /* 1: conv_igemm_dma_kernel, 2: conv_igemm_dma2_ker
        CLC_TUNE_1X1_TILE = 7 /* large-map 1x1 convolutions with at most this many K-tiles use the 128x64 tile (0: off) */,
        CLC_TUNE_XCD_MAP = 8 /* dma2 conv kernel: channel tiles of a pixel tile back to back on one XCD: 0 off, 1 = 1x1 layers, 2 = all */,
        CLC_TUNE_WGRAD_DMA = 9 /* filter-gradient tile kernels: LDS-DMA staging for problems without operand arithmetic */,
+       CLC_TUNE_RING = 10 /* conv_igemm_dma3_kernel (more operand bytes in flight), bit field: see launch_dma23_t */,
        CLC_TUNE_COUNT = 16 };
 extern int clc_tuning[CLC_TUNE_COUNT];
 
@@ -37,6 +38,19 @@ extern int clc_tuning[CLC_TUNE_COUNT];
       return -2;                                                        \
     }                                                                   \
   } while (0)
+
+// hipFuncSetAttribute is a per-DEVICE setting: a once-flag per (call site, device), so that a process driving several GPUs
+// (nn.DataParallel replicas, /root/reference/train_CLC.py:472-473) opts every one of them in
+struct PerDeviceOnce {
+  bool done[32] = {};
+  bool first() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 32) return true;
+    if (done[d]) return false;
+    done[d] = true;
+    return true;
+  }
+};
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

@@ -709,6 +709,228 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv_igemm_dma2_kernel with MORE OPERAND BYTES IN FLIGHT (same tiles, same K order, same MFMA sequence -> same bits).
+// dma2 keeps exactly one K-tile in flight per workgroup and drains it with `s_waitcnt vmcnt(0)` before every barrier; with 2-3
+// workgroups per CU that is 24-64 KB of loads per CU, and only during part of each workgroup's life — too little to cover the
+// HBM latency of the whole chip (Little: 6 TB/s x ~2 us = ~47 KB per CU, all the time).  Two forms (NSA = A-tile ring slots):
+//   NSA = 2  "early": the FIRST TWO K-tiles are issued back to back before the first wait (a 1x1 layer with 64 input channels has
+//            two K-tiles in all: its whole operand is in flight at once), after that tile it+2 is issued as soon as the barrier
+//            has freed tile it's slot.  LDS as dma2 (3 workgroups per CU on the 128x64 tile).
+//   NSA = 3  "ring": A tiles (gathered pixels: HBM / Infinity Cache) in a 3-slot ring, issued TWO iterations ahead; B tiles (the
+//            filter: L2-resident) stay double-buffered, issued one iteration ahead but BEFORE the A pieces, so that one counted
+//            `s_waitcnt vmcnt(A_P)` — everything but the newest A tile — retires both operands of the next tile (the vector
+//            memory counter is in issue order).  128x128 tile: 48 + 32 = 80 KB -> still two workgroups per CU.
+// Barriers are raw s_barrier (a __syncthreads() would make hipcc drain the DMA queue: LDS-DMA is a pending LDS write on vmcnt).
+template <int BM, int BN, int WM, int WN, bool TR, int KS, int OP, int NSA>
+__global__ __launch_bounds__(64 * WM * WN, (64 * WM * WN) >= 512 ? 4 : ((64 * WM * WN) >= 256 ? 2 : 4))
+void conv_igemm_dma3_kernel(const ConvParams p) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_P = BM * 8 / NT, B_P = BN * 8 / NT;
+  static_assert(TM >= 1 && TN >= 1 && A_P * NT == BM * 8 && B_P * NT == BN * 8, "tile");
+  static_assert(NSA == 2 || NSA == 3, "ring depth");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                      // [NSA][BM][BK], slot-swizzled
+  float* Bs = smem + NSA * BM * BK;      // [2][BN][BK]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  int bxm = blockIdx.x, bym = blockIdx.y;
+  if (p.xcd_map) {   // (see conv_igemm_dma2_kernel)
+    const int L = blockIdx.x + gridDim.x * blockIdx.y, c = L & 7, j = L >> 3;
+    bym = j % (int)gridDim.y;
+    bxm = (j / (int)gridDim.y) * 8 + c;
+  }
+  const int m0 = bxm * BM, n0 = bym * BN;
+  const int cls = blockIdx.z, ph = cls >> 1, pw = cls & 1;
+  const bool half = p.transposed && p.stride == 2;
+  const int DH = half ? p.OH / 2 : p.OH, DW = half ? p.OW / 2 : p.OW;
+  const TapGrid tg = KS == 1 ? TapGrid{0, 0, 1, 1, 1} : make_taps(p, ph, pw);
+
+  const int fset = p.group_rows ? min(m0 / p.group_rows, 3) : 0;
+  const float* wsel = fset == 0 ? p.w : (fset == 1 ? p.w2 : (fset == 2 ? p.w3 : p.w4));
+  const float* bsel = fset == 0 ? p.bias : (fset == 1 ? p.bias2 : (fset == 2 ? p.bias3 : p.bias4));
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wsel), 0, p.w_bytes, 0x00020000);
+
+  constexpr int sgn = TR ? -1 : 1;
+  unsigned a_base[A_P], a_mask[A_P], b_base[B_P];
+  int a_c4[A_P], b_c4[B_P];
+  bool b_ok[B_P];
+#pragma unroll
+  for (int i = 0; i < A_P; ++i) {
+    const int r = (tid + i * NT) >> 3;
+    const RowState rs = make_row<TR>(p, m0 + r, DH, DW, ph, pw);
+    a_c4[i] = ((tid & 7) ^ ((r >> 1) & 7)) * 4;
+    int oy, ox;
+    if (TR) { const int sh = p.stride - 1; oy = (rs.y0 - tg.kh0) >> sh; ox = (rs.x0 - tg.kw0) >> sh; }
+    else { oy = rs.y0 + tg.kh0; ox = rs.x0 + tg.kw0; }
+    unsigned mask = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int iy = oy + sgn * j, ix = ox + sgn * q;
+        const bool ok = rs.ok && j < tg.nkh && q < tg.nkw && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        mask |= ok ? (1u << (j * 3 + q)) : 0u;
+      }
+    a_mask[i] = mask;
+    a_base[i] = ((unsigned)(rs.base + oy * p.W + ox) * (unsigned)p.ldx + (unsigned)a_c4[i]) * 4u;
+  }
+#pragma unroll
+  for (int i = 0; i < B_P; ++i) {
+    const int r = (tid + i * NT) >> 3;
+    const int co = n0 + r;
+    b_ok[i] = co < p.Cout;
+    b_c4[i] = ((tid & 7) ^ ((r >> 1) & 7)) * 4;
+    b_base[i] = ((unsigned)co * (unsigned)p.ldw + (unsigned)b_c4[i]) * 4u;
+  }
+  const int wave_row = wave * 8;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int total = tg.nkh * tg.nkw * p.kc_tiles;
+  // two fetch cursors run ahead of the compute index: A by NSA - 1 tiles, B by one
+  struct Cur { int tj, ti, kc, n; };
+  auto step = [&](Cur& c) {   // branch-free
+    const int kc1 = c.kc + 1;
+    const bool w1 = kc1 == p.kc_tiles;
+    c.kc = w1 ? 0 : kc1;
+    const int ti1 = c.ti + (w1 ? 1 : 0);
+    const bool w2 = ti1 == tg.nkw;
+    c.ti = w2 ? 0 : ti1;
+    c.tj += w2 ? 1 : 0;
+    ++c.n;
+  };
+  auto dma_a = [&](int slot, const Cur& c) {
+    const bool en = c.n < total;
+    const unsigned bit = 1u << (c.tj * 3 + c.ti);
+    const int cleft = p.Cin - c.kc * BK;
+    const unsigned delta = (unsigned)(sgn * (c.tj * p.W + c.ti) * p.ldx + c.kc * BK) * 4u;
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) {
+      const bool ok = en && (a_mask[i] & bit) != 0u && a_c4[i] < cleft;
+      dma16(xr, As + (slot * BM + wave_row + i * (NT / 8)) * BK, ok ? a_base[i] + delta : kOOB);
+    }
+  };
+  auto dma_b = [&](int slot, const Cur& c) {
+    const bool en = c.n < total;
+    const int cleft = p.Cin - c.kc * BK;
+    const int kh = tg.kh0 + tg.step * c.tj, kw = tg.kw0 + tg.step * c.ti;
+    const unsigned delta = (unsigned)((kh * p.ks + kw) * p.Cin + c.kc * BK) * 4u;
+#pragma unroll
+    for (int i = 0; i < B_P; ++i) {
+      const bool ok = en && b_ok[i] && b_c4[i] < cleft;
+      dma16(wr, Bs + (slot * BN + wave_row + i * (NT / 8)) * BK, ok ? b_base[i] + delta : kOOB);
+    }
+  };
+  const int lr = lane & 31, hh = lane >> 5, sw = (lr >> 1) & 7;
+  int fo[4];
+#pragma unroll
+  for (int t8 = 0; t8 < 4; ++t8) fo[t8] = ((2 * t8 + hh) ^ sw) * 4;
+  f32x4 af[2][TM], bf[2][TN];
+  auto read_frag = [&](int sa, int sb, int t8, f32x4 (&a)[TM], f32x4 (&b)[TN]) {
+    const float* Ab = As + (sa * BM + wm * (BM / WM) + lr) * BK + fo[t8];
+    const float* Bb = Bs + (sb * BN + wn * (BN / WN) + lr) * BK + fo[t8];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * BK);
+      if (OP == 1) a[i] = a[i] * a[i];
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * BK);
+  };
+  auto mfma_group = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) {
+#pragma unroll
+    for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][ss], b[j][ss], acc[i][j], 0, 0, 0);
+  };
+  auto tile_mfmas = [&](int sa, int sb) {   // (group 0's fragments are already in af[0] / bf[0])
+    read_frag(sa, sb, 1, af[1], bf[1]);
+    mfma_group(af[0], bf[0]);
+    read_frag(sa, sb, 2, af[0], bf[0]);
+    mfma_group(af[1], bf[1]);
+    read_frag(sa, sb, 3, af[1], bf[1]);
+    mfma_group(af[0], bf[0]);
+    mfma_group(af[1], bf[1]);
+  };
+
+  Cur ca{0, 0, 0, 0}, cb{0, 0, 0, 0};
+  if constexpr (NSA == 2) {
+    dma_a(0, ca); dma_b(0, cb); step(ca); step(cb);
+    dma_a(1, ca); dma_b(1, cb); step(ca); step(cb);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_P + B_P) : "memory");   // tile 0 has landed; tile 1 stays in flight
+    __builtin_amdgcn_s_barrier();
+    read_frag(0, 0, 0, af[0], bf[0]);
+    for (int it = 0; it < total; ++it) {
+      const int buf = it & 1;
+      tile_mfmas(buf, buf);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // tile it + 1 (issued an iteration ago) has landed
+      __builtin_amdgcn_s_barrier();                                    // ... for everyone, and nobody reads tile it any more
+      dma_a(buf, ca); dma_b(buf, cb); step(ca); step(cb);              // tile it + 2 into the slot just freed
+      read_frag(buf ^ 1, buf ^ 1, 0, af[0], bf[0]);
+    }
+  } else {
+    dma_a(0, ca); step(ca);
+    dma_b(0, cb); step(cb);
+    dma_a(1, ca); step(ca);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_P) : "memory");         // A0, B0 have landed; A1 stays in flight
+    __builtin_amdgcn_s_barrier();
+    int sa = 0, sa2 = 2;   // A slot of tile it / of tile it + 2
+    for (int it = 0; it < total; ++it) {
+      const int sb = it & 1;
+      dma_b(sb ^ 1, cb); step(cb);                                     // B(it + 1): its slot held tile it - 1, read before the barrier
+      dma_a(sa2, ca); step(ca);                                        // A(it + 2): likewise
+      read_frag(sa, sb, 0, af[0], bf[0]);
+      tile_mfmas(sa, sb);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_P) : "memory");       // all but A(it + 2): A(it + 1) and B(it + 1) have landed
+      __builtin_amdgcn_s_barrier();
+      sa = sa == 2 ? 0 : sa + 1;
+      sa2 = sa2 == 2 ? 0 : sa2 + 1;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill pieces past the last tile
+  __builtin_amdgcn_s_barrier();
+
+  constexpr int LDC = BN + 4;
+  float* Cs = smem;   // [BM][LDC]
+  {
+    const int col = lane & 31, rhalf = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          Cs[(wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf) * LDC + wn * (BN / WN) + j * 32 + col] = acc[i][j][r];
+  }
+  __syncthreads();
+  if (p.vec_epi) {   // block-uniform
+    for (int e = tid; e < BM * BN / 4; e += NT) {
+      const int row = e / (BN / 4), cc = (e - row * (BN / 4)) * 4;
+      const int m = m0 + row, co = n0 + cc;
+      if (m < p.M && co < p.Cout) epilogue_store4(p, bsel, *reinterpret_cast<const f32x4*>(Cs + row * LDC + cc), m, co, DH, DW, ph, pw);
+    }
+    return;
+  }
+  for (int e = tid; e < BM * BN; e += NT) {
+    const int row = e / BN, cc = e - row * BN;
+    const int m = m0 + row, co = n0 + cc;
+    if (m < p.M && co < p.Cout) epilogue_store(p, Cs[row * LDC + cc], bsel ? bsel[co] : 0.f, m, co, DH, DW, ph, pw);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Small maps (<= 16x16 per image): latency, not MFMA rate, is what matters (a 64->64 3x3 at 8x16x16 is 0.15 GFLOP).
 // One 32 x BN output tile per workgroup of KW = 8 waves; wave w owns K-tiles w, w+8, ... and loads its MFMA fragments
 // STRAIGHT from global memory into registers in operand layout (lane (i,h) needs 4 consecutive k of its own row i:
@@ -840,10 +1062,9 @@ int launch_t(const ConvParams& p, int classes, hipStream_t st) {
   dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, classes);
   const size_t lds = (size_t)2 * (BM + BN) * LD * sizeof(float);
   static_assert(BM * (BN + 4) <= 2 * (BM + BN) * LD, "C tile must fit in the operand tiles' LDS");
-  static bool attr_set = false;  // >64 KiB of dynamic LDS needs an explicit opt-in (first call happens before any graph capture)
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;  // >64 KiB of dynamic LDS needs an explicit opt-in (first call happens before any graph capture)
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, TR>), grid, dim3(64 * WM * WN), lds, st, p);
   CLC_LAUNCH_CHECK();
@@ -854,10 +1075,9 @@ int launch_dma_t(const ConvParams& p, int classes, hipStream_t st) {
   dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, classes);
   constexpr size_t lds_ab = (size_t)2 * (BM + BN) * BK * sizeof(float), lds_c = (size_t)BM * (BN + 4) * sizeof(float);
   constexpr size_t lds = lds_ab > lds_c ? lds_ab : lds_c;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<BM, BN, WM, WN, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, TR>), grid, dim3(64 * WM * WN), lds, st, p);
   CLC_LAUNCH_CHECK();
@@ -868,10 +1088,9 @@ int launch_dma2_t(const ConvParams& p, int classes, hipStream_t st) {
   dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, classes);
   constexpr size_t lds_ab = (size_t)2 * (BM + BN) * BK * sizeof(float), lds_c = (size_t)BM * (BN + 4) * sizeof(float);
   constexpr size_t lds = lds_ab > lds_c ? lds_ab : lds_c;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma2_kernel<BM, BN, WM, WN, TR, KS, OP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   ConvParams q = p;
   const int xm = clc_tuning[CLC_TUNE_XCD_MAP];
@@ -880,16 +1099,42 @@ int launch_dma2_t(const ConvParams& p, int classes, hipStream_t st) {
   CLC_LAUNCH_CHECK();
   return ((KS == 1 ? 5 : 4) << 20) | (OP << 24) | (WM << 16) | (WN << 12) | (BM << 3) | (BN >> 5);  // family 4 / 5 = conv_igemm_dma2_kernel<BM,BN,WM,WN,TR,3 / 1,OP>
 }
+template <int BM, int BN, int WM, int WN, bool TR, int KS, int OP, int NSA>
+int launch_dma3_t(const ConvParams& p, int classes, hipStream_t st) {
+  dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, classes);
+  constexpr size_t lds_ab = (size_t)(NSA * BM + 2 * BN) * BK * sizeof(float), lds_c = (size_t)BM * (BN + 4) * sizeof(float);
+  constexpr size_t lds = lds_ab > lds_c ? lds_ab : lds_c;
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma3_kernel<BM, BN, WM, WN, TR, KS, OP, NSA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  ConvParams q = p;
+  const int xm = clc_tuning[CLC_TUNE_XCD_MAP];
+  q.xcd_map = grid.y > 1 && grid.x % 8 == 0 && (xm == 2 || (xm == 1 && KS == 1));
+  hipLaunchKernelGGL((conv_igemm_dma3_kernel<BM, BN, WM, WN, TR, KS, OP, NSA>), grid, dim3(64 * WM * WN), lds, st, q);
+  CLC_LAUNCH_CHECK();
+  // family 6 / 7 = conv_igemm_dma3_kernel<BM,BN,WM,WN,TR,3 / 1,OP,NSA>; bit 26 set = NSA 3
+  return ((KS == 1 ? 7 : 6) << 20) | (OP << 24) | ((NSA == 3 ? 1 : 0) << 26) | (WM << 16) | (WN << 12) | (BM << 3) | (BN >> 5);
+}
+// CLC_TUNE_RING (key 10), bit field: 1 = 1x1 layers on the "early" form, 2 = 3x3 layers on the A-ring form, 4 = 1x1 layers on the
+// A-ring form (wins over bit 1), 8 = 3x3 layers on the "early" form
+template <int BM, int BN, int WM, int WN, bool TR, int KS, int OP>
+int launch_dma23_t(const ConvParams& p, int classes, hipStream_t st) {
+  const int ring = clc_tuning[CLC_TUNE_RING];
+  if (KS == 1 ? (ring & 4) : (ring & 2)) return launch_dma3_t<BM, BN, WM, WN, TR, KS, OP, 3>(p, classes, st);
+  if (KS == 1 ? (ring & 1) : (ring & 8)) return launch_dma3_t<BM, BN, WM, WN, TR, KS, OP, 2>(p, classes, st);
+  return launch_dma2_t<BM, BN, WM, WN, TR, KS, OP>(p, classes, st);
+}
 template <int BM, int BN, int WM, int WN>
 int launch(const ConvParams& p, int classes, hipStream_t st) {
   static const int use_dma = getenv("CLC_DMA") ? atoi(getenv("CLC_DMA")) : 1;   // CLC_DMA=0: register staging everywhere (A/B knob)
   static const int dma_small = getenv("CLC_DMA_SMALL") ? atoi(getenv("CLC_DMA_SMALL")) : 1;
   if (use_dma && p.in_op == CLC_IN_SQUARE && p.xs == nullptr && p.ks == 1 && p.stride == 1 && (BM >= 128 || dma_small) && clc_tuning[CLC_TUNE_DMA_LOOP] == 2)
-    return p.transposed ? launch_dma2_t<BM, BN, WM, WN, true, 1, 1>(p, classes, st) : launch_dma2_t<BM, BN, WM, WN, false, 1, 1>(p, classes, st);
+    return p.transposed ? launch_dma23_t<BM, BN, WM, WN, true, 1, 1>(p, classes, st) : launch_dma23_t<BM, BN, WM, WN, false, 1, 1>(p, classes, st);
   if (use_dma && p.in_op == CLC_IN_NONE && p.xs == nullptr && (BM >= 128 || dma_small) && clc_tuning[CLC_TUNE_DMA_LOOP] == 2)
     return p.ks == 1 && p.stride == 1
-               ? (p.transposed ? launch_dma2_t<BM, BN, WM, WN, true, 1>(p, classes, st) : launch_dma2_t<BM, BN, WM, WN, false, 1>(p, classes, st))
-               : (p.transposed ? launch_dma2_t<BM, BN, WM, WN, true, 3>(p, classes, st) : launch_dma2_t<BM, BN, WM, WN, false, 3>(p, classes, st));
+               ? (p.transposed ? launch_dma23_t<BM, BN, WM, WN, true, 1, 0>(p, classes, st) : launch_dma23_t<BM, BN, WM, WN, false, 1, 0>(p, classes, st))
+               : (p.transposed ? launch_dma23_t<BM, BN, WM, WN, true, 3, 0>(p, classes, st) : launch_dma23_t<BM, BN, WM, WN, false, 3, 0>(p, classes, st));
   if (use_dma && p.in_op == CLC_IN_NONE && p.xs == nullptr && (BM >= 128 || dma_small))   // no input prologue -> the tiles can go straight to LDS
     return p.transposed ? launch_dma_t<BM, BN, WM, WN, true>(p, classes, st) : launch_dma_t<BM, BN, WM, WN, false>(p, classes, st);
   return p.transposed ? launch_t<BM, BN, WM, WN, true>(p, classes, st) : launch_t<BM, BN, WM, WN, false>(p, classes, st);
@@ -899,10 +1144,9 @@ template <int BN, bool TR, int KW, int PF>
 int launch_splitk_t(const ConvParams& p, int classes, hipStream_t st) {
   dim3 grid((p.M + 31) / 32, (p.Cout + BN - 1) / BN, classes);
   const size_t lds = (size_t)KW * (BN / 32) * 16 * 64 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_splitk_kernel<BN, TR, KW, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   hipLaunchKernelGGL((conv_igemm_splitk_kernel<BN, TR, KW, PF>), grid, dim3(64 * KW), lds, st, p);
   CLC_LAUNCH_CHECK();

@@ -923,7 +923,9 @@ extern "C" size_t clc_conv2d_wgrad_workspace_bytes(const clc_wgrad_desc* d) {
 namespace {
 
 // validates one descriptor and fills the kernel parameters for its plan
-int prepare(const clc_wgrad_desc* d, Plan& pl, WgradParams& p) {
+// sk: the problem is part of a stream-K group (partial tiles live in the group workspace: no per-problem slabs, except on the
+// small-Cin split path)
+int prepare(const clc_wgrad_desc* d, Plan& pl, WgradParams& p, bool sk = false) {
   CLC_CHECK(d && d->x && d->dy && d->dw, "clc_conv2d_wgrad: null pointer");
   CLC_CHECK(d->ks == 1 || d->ks == 3, "clc_conv2d_wgrad: ks must be 1 or 3");
   CLC_CHECK(d->stride == 1 || d->stride == 2, "clc_conv2d_wgrad: stride must be 1 or 2");
@@ -931,8 +933,9 @@ int prepare(const clc_wgrad_desc* d, Plan& pl, WgradParams& p) {
             "clc_conv2d_wgrad: output dims inconsistent");
   CLC_CHECK(d->ldx >= d->Cin && d->lddy >= d->Cout, "clc_conv2d_wgrad: ld too small");
   CLC_CHECK((long)d->N * d->H * d->W < (1l << 31) && (long)d->N * d->OH * d->OW < (1l << 31), "clc_conv2d_wgrad: too many pixels");
-  CLC_CHECK(d->workspace && d->workspace_bytes >= clc_conv2d_wgrad_workspace_bytes(d), "clc_conv2d_wgrad: workspace too small");
   pl = make_plan(d);
+  if (!(sk && clc_tuning[CLC_TUNE_WGRAD_STREAMK] && !pl.small))
+    CLC_CHECK(d->workspace && d->workspace_bytes >= clc_conv2d_wgrad_workspace_bytes(d), "clc_conv2d_wgrad: workspace too small");
   const int T = d->ks * d->ks;
   const size_t wsz = (size_t)d->Cout * T * d->Cin;
   p.x = d->x; p.dy = d->dy;
@@ -1007,11 +1010,10 @@ int launch_taps(const Pending* pend, int n, hipStream_t st) {
   if (g.count == 0) return 0;
   constexpr int XP = (32 / TW + 2) * (TW + 2);
   const size_t lds = (size_t)2 * (32 * 64 + XP * 64) * sizeof(float);
-  static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in (first call happens before any graph capture)
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;   // > 64 KiB of dynamic LDS needs the opt-in (first call happens before any graph capture)
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_taps_kernel<TW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_taps_grouped_kernel<TW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   if (g.count == 1) {
     const int last = g.wg_end[0] / (g.gx[0] * g.gy[0]);
@@ -1106,7 +1108,7 @@ inline bool dma_ok(const Pending& e) { return clc_tuning[CLC_TUNE_WGRAD_DMA] && 
 
 template <int BM, int BN, bool DMA>
 int launch_variant_sk(const Pending* pend, int n, float* region, hipStream_t st) {
-  static SKGroup g;   // (host staging of the kernel argument; launches are issued by one host thread per process)
+  static thread_local SKGroup g;   // (host staging of the kernel argument; launches are issued by one host thread per process)
   constexpr int slot = (int)sk_slot_floats(BM * BN, BM);
   if (!sk_collect(pend, n, g, region, slot, kCUs * sk_wg_per_cu(BM, BN), 16, [](const Pending& e) { return !e.pl.taps && e.pl.bm == BM && e.pl.bn == BN && dma_ok(e) == DMA; },
                   [](const Pending& e, int& gx, int& gy, int& T) {
@@ -1124,16 +1126,15 @@ int launch_variant_sk(const Pending* pend, int n, float* region, hipStream_t st)
 
 template <int TW, bool DMA>
 int launch_taps_sk(const Pending* pend, int n, float* region, hipStream_t st) {
-  static SKGroup g;
+  static thread_local SKGroup g;
   constexpr int slot = (int)sk_slot_floats(64 * 9 * 64, 64);
   if (!sk_collect(pend, n, g, region, slot, kCUs * 2, 4, [](const Pending& e) { return e.pl.taps == TW && dma_ok(e) == DMA; },
                   [](const Pending& e, int& gx, int& gy, int& T) { gx = e.pl.nci; gy = (e.d->Cout + 63) / 64; T = e.p.K >> 5; })) return 0;
   constexpr int XP = (32 / TW + 2) * (TW + 2);
   const size_t lds = (size_t)2 * (32 * 64 + XP * 64) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_taps_sk_kernel<TW, DMA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   hipLaunchKernelGGL((conv_wgrad_taps_sk_kernel<TW, DMA>), dim3(g.G), dim3(256), lds, st, g);
   CLC_LAUNCH_CHECK();
@@ -1235,6 +1236,12 @@ extern "C" int clc_conv2d_wgrad_variant(const clc_wgrad_desc* d) {
 
 extern "C" size_t clc_conv2d_wgrad_group_workspace_bytes(void) { return sk_total_floats() * sizeof(float); }
 
+extern "C" size_t clc_conv2d_wgrad_sk_workspace_bytes(const clc_wgrad_desc* d) {
+  if (!d) return 0;
+  if (clc_tuning[CLC_TUNE_WGRAD_STREAMK] && !make_plan(d).small) return 0;   // partial tiles go to the group workspace
+  return clc_conv2d_wgrad_workspace_bytes(d);
+}
+
 extern "C" int clc_conv2d_wgrad_batched_sk(const clc_wgrad_desc* descs, int count, void* group_workspace, size_t group_workspace_bytes,
                                           clc_stream_t stream) {
   CLC_CHECK(descs && count >= 0, "clc_conv2d_wgrad_batched_sk: bad arguments");
@@ -1248,10 +1255,10 @@ extern "C" int clc_conv2d_wgrad_batched_sk(const clc_wgrad_desc* descs, int coun
     // two problems that write the same gradient buffer (a filter applied twice) must not share a launch
     bool clash = n == kMaxGroup;
     for (int j = 0; j < n && !clash; ++j)
-      clash = pend[j].d->dw == d->dw || (d->dbias && pend[j].d->dbias == d->dbias) || pend[j].d->workspace == d->workspace;
+      clash = pend[j].d->dw == d->dw || (d->dbias && pend[j].d->dbias == d->dbias) || (d->workspace && pend[j].d->workspace == d->workspace);
     if (clash && (rc = flush_sk(pend, n, (float*)group_workspace, (hipStream_t)stream)) < 0) return rc;
     pend[n].d = d;
-    if ((rc = prepare(d, pend[n].pl, pend[n].p)) < 0) return rc;
+    if ((rc = prepare(d, pend[n].pl, pend[n].p, true)) < 0) return rc;
     ++n;
   }
   return flush_sk(pend, n, (float*)group_workspace, (hipStream_t)stream);

@@ -70,6 +70,7 @@ SIGNATURES = {
     "clc_conv2d_wgrad": (_i, [C.POINTER(WgradDesc), fp]),
     "clc_conv2d_wgrad_batched": (_i, [C.POINTER(WgradDesc), _i, fp]),
     "clc_conv2d_wgrad_group_workspace_bytes": (_sz, []),
+    "clc_conv2d_wgrad_sk_workspace_bytes": (_sz, [C.POINTER(WgradDesc)]),
     "clc_conv2d_wgrad_variant": (_i, [C.POINTER(WgradDesc)]),
     "clc_conv2d_wgrad_batched_sk": (_i, [C.POINTER(WgradDesc), _i, fp, _sz, fp]),
     "clc_filter_transpose": (_i, [fp, fp, _i, _i, _i, fp]),

@@ -237,8 +237,15 @@ class _SliceCodec(CompressionModel):
 
     def forward(self, x, ref_frames=None):
         x = self._prep(x)
+        prof = ops.PROFILE is not None   # bench.py's roofline leg: launches are tagged with the sub-network they belong to
+        if prof:
+            ops.set_owner("ref_encoder")
         ref_features = self._ref(ref_frames)
+        if prof:
+            ops.set_owner("g_a")
         y = self.g_a(x)
+        if prof:
+            ops.set_owner("other")
         if getattr(self, "_keep_boundary", False):
             # outputs of the analysis transform / reference branch: where clc_amd.train.TrainEngine cuts the backward pass in two
             # so that the gradient exchange of everything downstream overlaps the backward of these two encoders
@@ -251,7 +258,10 @@ class _SliceCodec(CompressionModel):
         sup = y_buf = None
         rows = z_hat.shape[0] * z_hat.shape[2] * z_hat.shape[3]
         if (ops.SUPPORT_BUFFER and ops.PAIR_SLICES and ops.PAIR_HYPER and rows % 128 == 0 and z_hat.shape[0] % 2 == 0
-                and (y.shape[0] * y.shape[2] * y.shape[3]) % 128 == 0 and 0 <= self.max_support_slices <= self.num_slices):
+                and (y.shape[0] * y.shape[2] * y.shape[3]) % 128 == 0
+                # (the shared gradient buffer relies on the slices running backward strictly last-to-first, which autograd's dependencies
+                #  only enforce when every slice reads its predecessor: ops.SliceSupport)
+                and self.num_slices - 1 <= self.max_support_slices <= self.num_slices):
             both = self._hyper_synthesis(z_hat, stacked=True)
             if tuple(both.shape[2:]) == tuple(y.shape[2:]):
                 sup = ops.SliceSupport(both, self.max_support_slices, S)
@@ -276,7 +286,11 @@ class _SliceCodec(CompressionModel):
             if sup is not None and i < sup.n:
                 sup.add(i, y_hat_slices[-1])
         y_hat = ops.gather_channels(y_buf, y_hat_slices) if y_buf is not None else torch.cat(y_hat_slices, dim=1)
+        if prof:
+            ops.set_owner("g_s")
         x_hat = self.g_s(ops.flush_point(y_hat))
+        if prof:
+            ops.set_owner("other")
         return {"x_hat": x_hat,
                 "likelihoods": {"y": torch.cat(y_lik, dim=1), "z": z_likelihoods},
                 "para": {"means": torch.cat(mus, dim=1), "scales": torch.cat(scales, dim=1), "y": y}}

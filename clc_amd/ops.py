@@ -31,51 +31,106 @@ CL = torch.channels_last
 #     ~4.4 us of cross-queue marker latency in front of EVERY kernel that follows an event record, and the branches barely
 #     overlap (tools/graph_fork_probe.py; bench: 1 graph queue 216 img/s vs 4 queues 210) — a linear graph is faster;
 #   * on a side stream (CLC_WGRAD_STREAM=1), concurrent with the data-gradient chain: the better choice for eager execution.
-# Tensors a deferred launch still reads are kept alive in _KEEPALIVE until join_side_streams().
+# Tensors a deferred launch still reads are kept alive in the device state's `keepalive` until join_side_streams().
 WGRAD_DEFER = False
-WGRAD_STREAM = None
-_KEEPALIVE = []
+
+
+class _DeviceState:
+    """Everything mutable that the deferred machinery keeps between ops, ONE instance PER DEVICE.
+
+    The reference's in-tree multi-GPU mode is nn.DataParallel (/root/reference/train_CLC.py:74-79, 472-473): one process, one forward
+    thread per GPU, and the autograd engine's own worker thread per GPU for the backward.  Queues that were module globals would be
+    shared by those threads; keyed by device they are touched by one thread at a time (a replica's forward thread, then its device's
+    backward thread), which is all the ordering they need.  (Per-THREAD state would be wrong: loss.backward() runs the CUDA nodes on
+    the engine's device thread while join_side_streams() is called from the caller's.)"""
+
+    __slots__ = ("pending", "pending_flop", "pending_streams", "pending_post", "last_defer_vid", "pending_reduce", "keepalive",
+                 "branch_pool", "wgrad_stream", "group_ws")
+
+    def __init__(self):
+        self.pending = {}            # kernel-family id -> [(descriptor, keep-alive tuple)]
+        self.pending_flop = 0.0
+        self.pending_streams = {}    # streams that queued a problem since the last flush (their work must be ordered before the launch)
+        self.pending_post = {}       # kernel-family id -> callables run right after that family's launch, on its stream
+        self.last_defer_vid = 0      # family of the problem queued last (a post hook registers itself under it)
+        self.pending_reduce = []
+        self.keepalive = []          # tensors a deferred / cross-stream launch still reads, until join_side_streams()
+        self.branch_pool = {}
+        self.wgrad_stream = None     # side stream of the filter gradients (CLC_WGRAD_STREAM=1), else None
+        self.group_ws = {}           # None / "capture" -> [stream-K partial-tile workspace (642 MiB), stream that used it last]
+
+
+_STATES = {}
+
+
+def _S() -> _DeviceState:
+    dev = torch.cuda.current_device()
+    st = _STATES.get(dev)
+    if st is None:
+        st = _STATES.setdefault(dev, _DeviceState())   # (setdefault: two replica threads may arrive here together)
+    return st
 
 
 def enable_wgrad_stream(enable=True):
-    """Turn on deferred, grouped filter gradients (and the side stream when CLC_WGRAD_STREAM=1)."""
-    global WGRAD_STREAM, WGRAD_DEFER
+    """Turn on deferred, grouped filter gradients (and the side stream when CLC_WGRAD_STREAM=1) — the TrainEngine's mode."""
+    global WGRAD_DEFER
     WGRAD_DEFER = bool(enable)
-    WGRAD_STREAM = torch.cuda.Stream() if (enable and os.environ.get("CLC_WGRAD_STREAM", "0") == "1") else None
+    _S().wgrad_stream = torch.cuda.Stream() if (enable and os.environ.get("CLC_WGRAD_STREAM", "0") == "1") else None
 
 
 WGRAD_GROUP = int(os.environ.get("CLC_WGRAD_GROUP", "64"))             # problems per grouped launch (library cap: 64)
 # ... or as soon as this much work is queued.  Default: effectively never (flush by count).
 WGRAD_FLUSH_GFLOP = float(os.environ.get("CLC_WGRAD_FLUSH_GFLOP", "1000"))
-_PENDING = {}           # kernel-family id -> [(descriptor, keep-alive tuple)]
-_PENDING_FLOP = [0.0]
-_PENDING_STREAMS = {}   # streams that queued a problem since the last flush (their work must be ordered before the launch)
-_PENDING_POST = {}      # kernel-family id -> callables run right after that family's launch, on its stream (consumers of deferred temporaries)
-_LAST_DEFER_VID = [0]   # family of the problem queued last (a post hook registers itself under it)
-
-
-_GROUP_WS = {}   # stream id -> persistent partial-tile workspace of the stream-K grouped filter-gradient launches
 
 
 def _group_ws():
-    """(ptr, bytes) of this stream's stream-K workspace (launches on one stream are ordered, so one buffer serves them all)."""
-    key = (torch.cuda.current_device(), _stream())
-    ws = _GROUP_WS.get(key)
-    if ws is None:
+    """(ptr, bytes) of this device's stream-K workspace.  Launches on one stream are ordered; when the launching stream changes
+    (warm-up stream -> training stream, main stream <-> filter-gradient side stream) the new stream first waits for the old one.
+    The buffer is allocated OUTSIDE hipGraph capture (TrainEngine's eager warm-up steps come first); a capture that meets no
+    buffer gets a private one that lives in the graph's pool, under its own key, and is never handed to eager launches."""
+    tab = _S().group_ws
+    cur = torch.cuda.current_stream()
+    capturing = torch.cuda.is_current_stream_capturing()
+    ent = tab.get(None)
+    if ent is None:
         nbytes = _L().clc_conv2d_wgrad_group_workspace_bytes()
-        ws = _GROUP_WS[key] = torch.empty((nbytes + 3) // 4, device="cuda", dtype=torch.float32)
+        if capturing:
+            ent = tab.get("capture")
+            if ent is None:
+                ent = tab["capture"] = [torch.empty((nbytes + 3) // 4, device="cuda", dtype=torch.float32), cur]
+        else:
+            ent = tab[None] = [torch.empty((nbytes + 3) // 4, device="cuda", dtype=torch.float32), cur]
+    ws, last = ent
+    if last.cuda_stream != cur.cuda_stream:
+        # (a capturing stream cannot wait on work recorded outside its capture: the eager predecessor has long been synchronised
+        # by then — TrainEngine.step synchronises between warm-up and capture)
+        if not capturing or _is_capturing(last):
+            cur.wait_stream(last)
+        ent[1] = cur
     return ws.data_ptr(), ws.numel() * 4
+
+
+def _is_capturing(stream):
+    with torch.cuda.stream(stream):
+        return torch.cuda.is_current_stream_capturing()
+
+
+def release_workspaces():
+    """Teardown hook: drop the stream-K workspaces, branch-stream pools and queues of every device of this process (re-created on
+    demand).  Call it only between steps: queued filter gradients are dropped with their queues."""
+    _STATES.clear()
 
 
 def _launch_wgrad_group(arr, n):
     wp, wb = _group_ws()
-    _lib.check(_L().clc_conv2d_wgrad_batched_sk(arr, n, wp, wb, _stream()), "clc_conv2d_wgrad_batched_sk")
+    _lib.check(_lib.load().clc_conv2d_wgrad_batched_sk(arr, n, wp, wb, _stream()), "clc_conv2d_wgrad_batched_sk")
 
 
 def _flush_family(vid, target):
     """launch the queued problems of ONE kernel family (clc_conv2d_wgrad_variant id) as a stream-K group, then its post hooks"""
-    items = _PENDING.pop(vid, [])
-    posts = _PENDING_POST.pop(vid, [])
+    S = _S()
+    items = S.pending.pop(vid, [])
+    posts = S.pending_post.pop(vid, [])
     with torch.cuda.stream(target):
         if items:
             arr = (_lib.WgradDesc * len(items))(*[d for d, _ in items])
@@ -84,29 +139,36 @@ def _flush_family(vid, target):
             else:   # bracketed by events and credited with its problems' algorithmic FLOPs (bench.py's roofline leg)
                 # one bracket per KERNEL: the C side runs a family's LDS-DMA-staged problems (no fused activation derivative on dy, no
                 # squared input) and the register-staged rest as two launches — the same split here, one call each
-                parts = ([d for d, _ in items if not d.dys and d.in_op == IN_NONE], [d for d, _ in items if d.dys or d.in_op != IN_NONE])
-                for staged_by_dma, ds in zip((True, False), parts):
-                    if not ds:
+                parts = ([it for it in items if not it[0].dys and it[0].in_op == IN_NONE], [it for it in items if it[0].dys or it[0].in_op != IN_NONE])
+                dfl = lambda d: 2.0 * d.N * d.OH * d.OW * d.ks * d.ks * d.Cin * d.Cout
+                for staged_by_dma, its in zip((True, False), parts):
+                    if not its:
                         continue
+                    ds = [d for d, _ in its]
                     sub = (_lib.WgradDesc * len(ds))(*ds)
-                    fl = sum(2.0 * d.N * d.OH * d.OW * d.ks * d.ks * d.Cin * d.Cout for d in ds)
+                    fl = sum(dfl(d) for d in ds)
+                    by_owner = {}
+                    for d, k in its:
+                        by_owner[k[-1]] = by_owner.get(k[-1], 0.0) + dfl(d)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     _launch_wgrad_group(sub, len(ds))
                     e1.record()
-                    PROFILE.append(("conv_wgrad_group", vid, fl, e0, e1, f"{len(ds)} problems dma={int(staged_by_dma)}"))
+                    PROFILE.append(ProfRec("conv_wgrad_group", vid, fl, e0, e1, f"{len(ds)} problems dma={int(staged_by_dma)}", owner_flops=by_owner,
+                                           relaunch=(lambda sub=sub, n=len(ds), keep=[k for _, k in its]: _launch_wgrad_group(sub, n))))
         for fn in posts:
             fn()
-    _KEEPALIVE.append([k for _, k in items])
+    S.keepalive.append([k for _, k in items])
 
 
 def _flush_target():
+    S = _S()
     cur = torch.cuda.current_stream()
-    target = WGRAD_STREAM if WGRAD_STREAM is not None else cur
-    for sid, st in _PENDING_STREAMS.items():   # the operands were produced on these streams
+    target = S.wgrad_stream if S.wgrad_stream is not None else cur
+    for sid, st in S.pending_streams.items():   # the operands were produced on these streams
         if sid != target.cuda_stream:
             target.wait_stream(st)
-    _PENDING_STREAMS.clear()
+    S.pending_streams.clear()
     return target
 
 
@@ -114,19 +176,19 @@ def flush_wgrads():
     """Launch everything queued.  Problems wait in one queue PER KERNEL FAMILY (a family's queue is launched as soon as it holds
     WGRAD_GROUP problems): a flush then costs one stream-K grid (+ fix-up) per family that has work, with full groups,
     instead of one under-filled grid of every family for each 64 problems in arrival order."""
-    if not _PENDING and not _PENDING_POST:
+    S = _S()
+    if not S.pending and not S.pending_post:
         return
     target = _flush_target()
-    for vid in sorted(set(_PENDING) | set(_PENDING_POST)):
+    for vid in sorted(set(S.pending) | set(S.pending_post)):
         _flush_family(vid, target)
-    _PENDING_FLOP[0] = 0.0
+    S.pending_flop = 0.0
 
 
 # Deferred parameter-gradient reductions (LayerNorm gamma/beta, relative-position bias): the backward kernels leave their
 # per-block partial rows in their workspaces and ONE clc_partial_reduce_batched call per step sums them into the gradient
 # arena (join_side_streams) — instead of a 5-16 us reduce launch behind each of the ~110 backward kernels.
 DEFER_REDUCTIONS = False
-_PENDING_REDUCE = []
 
 
 def enable_deferred_reductions(enable=True):
@@ -139,24 +201,26 @@ def defer_reduce(partial, nblocks, n, out0, out1, split, offset=0):
     e = _lib.ReduceEntry()
     e.partial, e.nblocks, e.n = partial.data_ptr() + 4 * int(offset), int(nblocks), int(n)
     e.out0, e.out1, e.split, e.accumulate = out0.data_ptr(), (out1.data_ptr() if out1 is not None else None), int(split), 1
-    _PENDING_REDUCE.append((e, (partial, out0, out1)))
+    _S().pending_reduce.append((e, (partial, out0, out1)))
 
 
 def flush_reductions():
-    if not _PENDING_REDUCE:
+    S = _S()
+    if not S.pending_reduce:
         return
-    arr = (_lib.ReduceEntry * len(_PENDING_REDUCE))(*[e for e, _ in _PENDING_REDUCE])
-    _lib.check(_L().clc_partial_reduce_batched(arr, len(_PENDING_REDUCE), _stream()), "clc_partial_reduce_batched")
-    _KEEPALIVE.append([k for _, k in _PENDING_REDUCE])
-    _PENDING_REDUCE.clear()
+    arr = (_lib.ReduceEntry * len(S.pending_reduce))(*[e for e, _ in S.pending_reduce])
+    _lib.check(_L().clc_partial_reduce_batched(arr, len(S.pending_reduce), _stream()), "clc_partial_reduce_batched")
+    S.keepalive.append([k for _, k in S.pending_reduce])
+    S.pending_reduce.clear()
 
 
 def join_side_streams():
     flush_wgrads()
-    if WGRAD_STREAM is not None:
-        torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
+    S = _S()
+    if S.wgrad_stream is not None:
+        torch.cuda.current_stream().wait_stream(S.wgrad_stream)
     flush_reductions()
-    _KEEPALIVE.clear()
+    S.keepalive.clear()
 
 
 # Branch streams: independent sub-graphs of the latency-bound 16x16 slice loop (mean vs scale parameter nets, the
@@ -172,7 +236,6 @@ MATERIALIZE_DZ = int(os.environ.get("CLC_MATERIALIZE_DZ", "32768"))   # rows fro
 QUAD_UNITS = int(os.environ.get("CLC_QUAD_UNITS", "1"))   # paired SWAttens: the ResidualUnits of conv_a and conv_b of both nets in one chain (4 filter sets)
 PAIR_HYPER = int(os.environ.get("CLC_PAIR_HYPER", "1"))   # also pair the mean / scale hyper-synthesis nets (h_mean_s, h_scale_s)
 BRANCH_SLOTS = set(os.environ.get("CLC_BRANCH", "scale").split(","))   # which forks are taken (debug knob)
-_BRANCH_POOL = {}
 
 
 def enable_branch_streams(enable=True):
@@ -186,9 +249,10 @@ class fork:
     def __init__(self, slot, inputs):
         self.parent = torch.cuda.current_stream()
         key = (self.parent.cuda_stream, slot)
-        if key not in _BRANCH_POOL:
-            _BRANCH_POOL[key] = torch.cuda.Stream()
-        self.stream = _BRANCH_POOL[key]
+        pool = _S().branch_pool
+        if key not in pool:
+            pool[key] = torch.cuda.Stream()
+        self.stream = pool[key]
         self.inputs = [t for t in inputs if t is not None]
 
     def __enter__(self):
@@ -196,7 +260,7 @@ class fork:
         # tensors crossing streams are kept alive until the end of the step (ops.join_side_streams) instead of
         # record_stream(): every later use of a branch stream starts with wait_stream(parent), which orders any reuse of
         # their memory after the consumers — and record_stream's deferred events crash hipGraph capture_end (ROCm 7.2)
-        _KEEPALIVE.append(self.inputs)
+        _S().keepalive.append(self.inputs)
         self.ctx = torch.cuda.stream(self.stream)
         self.ctx.__enter__()
         return self
@@ -207,7 +271,7 @@ class fork:
 
     def join(self, *outputs):
         self.parent.wait_stream(self.stream)
-        _KEEPALIVE.append(outputs)
+        _S().keepalive.append(outputs)
 
 
 class GradFold:
@@ -277,13 +341,92 @@ class GradSlots:
         return self.buf[:, off:off + n]
 
 
-# when set to a list, every conv / wgrad launch is bracketed by HIP events on the launch stream and recorded as
-# (kernel family, tile-variant id, algorithmic FLOPs, start event, end event) — used by bench.py's roofline leg
+# When set to a list, EVERY launch through the C ABI is bracketed by HIP events on the launch stream and recorded as a ProfRec
+# (bench.py's roofline leg, tools/profile_shapes.py): convolutions / filter gradients with their tile-variant id, algorithmic FLOPs
+# and bytes (recorded at their call sites), everything else (LayerNorm, attention, elementwise, optimizer ...) through the
+# _ProfiledLib proxy under the name of its C entry point.
 PROFILE = None
+PROFILE_OWNER = "other"   # which sub-network the launches belong to: the model sets it forward, every Function restores it backward
+
+
+class ProfRec:
+    __slots__ = ("fam", "variant", "flops", "e0", "e1", "label", "nbytes", "owner", "owner_flops", "relaunch")
+
+    def __init__(self, fam, variant, flops, e0, e1, label="", nbytes=0.0, owner=None, owner_flops=None, relaunch=None):
+        self.fam, self.variant, self.flops, self.e0, self.e1, self.label, self.nbytes = fam, variant, flops, e0, e1, label, nbytes
+        self.owner = PROFILE_OWNER if owner is None else owner
+        self.owner_flops = owner_flops    # grouped launches: {owner: FLOPs} of the problems inside
+        self.relaunch = relaunch          # re-issues the same launch (same descriptors, operands kept alive): graph-replay timing
+
+    def ms(self):
+        return self.e0.elapsed_time(self.e1)
+
+
+def set_owner(name):
+    global PROFILE_OWNER
+    PROFILE_OWNER = name
+
+
+def _own(ctx):
+    """forward: remember the owning sub-network for this node's backward (profiling only)"""
+    if PROFILE is not None:
+        ctx.owner = PROFILE_OWNER
+
+
+def _reown(ctx):
+    if PROFILE is not None:
+        set_owner(getattr(ctx, "owner", "other"))
+
+
+_PROF_HINT = [0.0, ""]   # algorithmic FLOPs / label of the NEXT proxied launch (set by the op that knows them)
+
+
+def _prof_hint(flops=0.0, label=""):
+    if PROFILE is not None:
+        _PROF_HINT[0], _PROF_HINT[1] = float(flops), label
+
+
+class _ProfiledLib:
+    """libclc_hip.so with every launching entry point bracketed by HIP events (PROFILE mode only)."""
+
+    _NO_LAUNCH = ("clc_last_error", "clc_version", "clc_set_tuning", "clc_conv2d_wgrad_variant", "clc_optim_chunk_elems", "clc_gauss_lik_partials",
+                  "clc_ssim_init", "clc_pmf_to_quantized_cdf")
+
+    def __init__(self, L):
+        self._lib_ = L
+        self._cache = {}
+
+    def __getattr__(self, name):
+        f = self._cache.get(name)
+        if f is not None:
+            return f
+        raw = getattr(self._lib_, name)
+        if name.endswith(("_bytes", "_blocks")) or name.startswith("clc_rans") or name in self._NO_LAUNCH:
+            f = raw
+        else:
+            def f(*a, _raw=raw, _name=name):
+                if PROFILE is None:
+                    return _raw(*a)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = _raw(*a)
+                e1.record()
+                PROFILE.append(ProfRec(_name, 0, _PROF_HINT[0], e0, e1, _PROF_HINT[1]))
+                _PROF_HINT[0], _PROF_HINT[1] = 0.0, ""
+                return rc
+        self._cache[name] = f
+        return f
+
+
+_PLIB = [None]
 
 
 def _L():
-    return _lib.load()
+    if PROFILE is None:
+        return _lib.load()
+    if _PLIB[0] is None:
+        _PLIB[0] = _ProfiledLib(_lib.load())
+    return _PLIB[0]
 
 
 def _stream():
@@ -401,22 +544,22 @@ def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_
         d.xs, d.ldxs, d.xs_act, d.xs_pre = xsp, ldxs, xs_act, int(xs_pre)
         keep.append(xs_t)
     if PROFILE is None:
-        _lib.check(_L().clc_conv2d(C.byref(d), _stream()), "clc_conv2d")
+        _lib.check(_lib.load().clc_conv2d(C.byref(d), _stream()), "clc_conv2d")
     else:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        variant = _lib.check(_L().clc_conv2d(C.byref(d), _stream()), "clc_conv2d")
+        variant = _lib.check(_lib.load().clc_conv2d(C.byref(d), _stream()), "clc_conv2d")
         e1.record()
         pix = N * H * W if transposed else N * OH * OW
         opix = N * OH * OW
         # algorithmic HBM bytes of the launch: operand read once, result written once, every epilogue tensor once
         nbytes = 4.0 * (N * H * W * Cin + Cout * ks * ks * Cin
                         + opix * Cout * (1 + (res is not None) + (mul is not None) + (y_pre is not None) + (out_gate is not None)))
-        PROFILE.append(("conv_igemm" if variant != 1 else "conv_direct_small", variant, 2.0 * pix * ks * ks * Cin * Cout, e0, e1,
-                        f"{'dgrad' if transposed else 'fwd'} {Cin}->{Cout} k{ks} s{stride} {N}x{H}x{W}" + (" +actbwd" if xs is not None else "")
-                        + "".join(t for t, on in ((" b", bias is not None), (f" a{act}", act != ACT_NONE), (" res", res is not None), (" mul", mul is not None),
-                                                  (" pre", y_pre is not None), (" rg", res_gate is not None), (" og", out_gate is not None), (" w2", w2 is not None and wx is None), (" w4", wx is not None)) if on),
-                        nbytes))
+        PROFILE.append(ProfRec("conv_igemm" if variant != 1 else "conv_direct_small", variant, 2.0 * pix * ks * ks * Cin * Cout, e0, e1,
+                               f"{'dgrad' if transposed else 'fwd'} {Cin}->{Cout} k{ks} s{stride} {N}x{H}x{W}" + (" +actbwd" if xs is not None else "")
+                               + "".join(t for t, on in ((" b", bias is not None), (f" a{act}", act != ACT_NONE), (" res", res is not None), (" mul", mul is not None),
+                                                         (" pre", y_pre is not None), (" rg", res_gate is not None), (" og", out_gate is not None), (" w2", w2 is not None and wx is None), (" w4", wx is not None)) if on),
+                               nbytes, relaunch=(lambda d=d, keep=keep: _lib.load().clc_conv2d(C.byref(d), _stream()))))
     return out
 
 
@@ -469,33 +612,37 @@ def wgrad_raw(x, dy, *, ks, stride, pad, Cout, Cin, want_bias, in_op=IN_NONE, dw
     if dys is not None:   # fused activation backward: dy <- dy * act'(dys)
         dys_t, dysp, *_r, lddys = nhwc(dys)
         d.dys, d.lddys, d.dys_act, d.dys_pre = dysp, lddys, dys_act, int(dys_pre)
-    nbytes = _L().clc_conv2d_wgrad_workspace_bytes(C.byref(d))
-    ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
-    d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+    # grouped (stream-K) launches keep their partial tiles in the device's group workspace: only the small-Cin split path still
+    # needs per-problem slabs there
+    grouped = _collect or defer
+    nbytes = (_L().clc_conv2d_wgrad_sk_workspace_bytes if grouped else _L().clc_conv2d_wgrad_workspace_bytes)(C.byref(d))
+    ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32) if nbytes else None
+    d.workspace, d.workspace_bytes = (ws.data_ptr() if ws is not None else None), nbytes
     if _collect:
         return d, (x, dy, dys_t, dw, db, ws)
     if defer:
+        S = _S()
         cur = torch.cuda.current_stream()   # the operands are produced on this stream: ordered before the launch at flush time
-        _PENDING_STREAMS[cur.cuda_stream] = cur
+        S.pending_streams[cur.cuda_stream] = cur
         vid = _L().clc_conv2d_wgrad_variant(C.byref(d))
-        _LAST_DEFER_VID[0] = vid
-        q = _PENDING.setdefault(vid, [])
-        q.append((d, (x, dy, dys_t, dw, db, ws)))
-        _PENDING_FLOP[0] += 2.0 * N * OH * OW * ks * ks * Cin * Cout
-        if _PENDING_FLOP[0] >= WGRAD_FLUSH_GFLOP * 1e9:
+        S.last_defer_vid = vid
+        q = S.pending.setdefault(vid, [])
+        q.append((d, (x, dy, dys_t, dw, db, ws, PROFILE_OWNER)))   # (last entry: owning sub-network, profiling only)
+        S.pending_flop += 2.0 * N * OH * OW * ks * ks * Cin * Cout
+        if S.pending_flop >= WGRAD_FLUSH_GFLOP * 1e9:
             flush_wgrads()
         elif len(q) >= WGRAD_GROUP:
             _flush_family(vid, _flush_target())
         return None, None
     if PROFILE is None:
-        _lib.check(_L().clc_conv2d_wgrad(C.byref(d), _stream()), "clc_conv2d_wgrad")
+        _lib.check(_lib.load().clc_conv2d_wgrad(C.byref(d), _stream()), "clc_conv2d_wgrad")
     else:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        variant = _lib.check(_L().clc_conv2d_wgrad(C.byref(d), _stream()), "clc_conv2d_wgrad")
+        variant = _lib.check(_lib.load().clc_conv2d_wgrad(C.byref(d), _stream()), "clc_conv2d_wgrad")
         e1.record()
-        PROFILE.append(("conv_wgrad" if variant != 1 else "wgrad_small", variant, 2.0 * N * OH * OW * ks * ks * Cin * Cout, e0, e1,
-                        f"wgrad {Cin}->{Cout} k{ks} s{stride} {N}x{H}x{W}"))
+        PROFILE.append(ProfRec("conv_wgrad" if variant != 1 else "wgrad_small", variant, 2.0 * N * OH * OW * ks * ks * Cin * Cout, e0, e1,
+                               f"wgrad {Cin}->{Cout} k{ks} s{stride} {N}x{H}x{W}"))
     return (None, None) if direct else (dw, db)
 
 
@@ -543,6 +690,7 @@ class _ConvFn(Function):
     @staticmethod
     def forward(ctx, x, w, b, res, ks, stride, act, res_scale, shuffle, res_first, w2=None, b2=None, fold_in=None, fold_out=None, out_buf=None,
                 grad_slot=None, park_dx=None, gate_in=None, gate_out=None, w3=None, b3=None, w4=None, b4=None):
+        _own(ctx)
         if x.dim() != 4 or x.shape[1] != w.shape[1]:
             # (the kernels take Cin from the activation: a mismatch would walk off the end of the filter buffer)
             raise _lib.ClcError(f"conv2d: input {tuple(x.shape)} does not match the filter {tuple(w.shape)} (expected {w.shape[1]} input channels)")
@@ -592,13 +740,14 @@ class _ConvFn(Function):
         if gw is not None and (gb is not None or not has_b) and to_kernel_weight(w) is w:
             # write straight into the persistent gradient arena (accumulate) — no temporary, no autograd add kernel
             if WGRAD_DEFER and (PROFILE is None or WGRAD_GROUP > 1):
-                if WGRAD_GROUP > 1 or WGRAD_STREAM is None:
+                side = _S().wgrad_stream
+                if WGRAD_GROUP > 1 or side is None:
                     wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb, defer=True, **fw)
                 else:
                     cur = torch.cuda.current_stream()
-                    WGRAD_STREAM.wait_stream(cur)
-                    _KEEPALIVE.append((x, dz, fw.get("dys")))
-                    with torch.cuda.stream(WGRAD_STREAM):
+                    side.wait_stream(cur)
+                    _S().keepalive.append((x, dz, fw.get("dys")))
+                    with torch.cuda.stream(side):
                         wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb, **fw)
             else:
                 wgrad_raw(x, dz, ks=ks, stride=stride, pad=pad, Cout=Cout, Cin=Cin, want_bias=has_b, dw_out=gw, db_out=gb, **fw)
@@ -608,6 +757,7 @@ class _ConvFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _reown(ctx)
         ks, stride, act, res_scale, shuffle, has_b, has_res, res_first = ctx.cfg
         x, w, saved_act = ctx.saved_tensors
         w2, b2 = ctx.pair
@@ -762,7 +912,7 @@ class _FlushPointFn(Function):
 
 
 def flush_point(x):
-    return _FlushPointFn.apply(x) if (WGRAD_DEFER and WGRAD_STREAM is not None and x.requires_grad) else x
+    return _FlushPointFn.apply(x) if (WGRAD_DEFER and x.is_cuda and _S().wgrad_stream is not None and x.requires_grad) else x
 
 
 # ----------------------------------------------------------------------------------- split / chunk
@@ -815,6 +965,14 @@ class _WholeAndFirstHalfFn(Function):
             return _SplitBatchFn.backward_pad(g_half)
         if g_half is not None:
             h = g_whole.shape[0] // 2
+            b = g_whole._base
+            # in place only into memory this node provably holds alone: a fresh tensor, or the channel range torch.cat's backward
+            # narrows out of its gradient for this input (the other ranges go to the other inputs).  Any other view — a GradSlots
+            # range, a batch slice, a reshaped alias — may have further holders: add out of place there.
+            cat_range = (b is not None and b.dim() == 4 and g_whole.dim() == 4 and g_whole.stride() == b.stride()
+                         and g_whole.shape[0] == b.shape[0] and g_whole.shape[2:] == b.shape[2:])
+            if not (b is None or cat_range):
+                g_whole = g_whole.clone(memory_format=CL)
             g_whole[:h] += g_half
         return g_whole
 
@@ -831,6 +989,7 @@ class _SplitFn(Function):
 
     @staticmethod
     def forward(ctx, x, slots, *sizes):
+        _own(ctx)
         ctx.sizes = sizes
         ctx.slots = slots
         ctx.shape = x.shape
@@ -842,6 +1001,7 @@ class _SplitFn(Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        _reown(ctx)
         N, Cc, H, W = ctx.shape
         ref = next(g for g in grads if g is not None)
         buf = ctx.slots.buf if ctx.slots is not None else None
@@ -876,7 +1036,10 @@ class SliceSupport:
     gradient buffer G in its epilogue (GradFold + GradSlots), so the ~100 gradient-accumulation adds autograd would launch for
     the many consumers of the latents and of each support slice collapse to one add per support slice (its two halves).
     Support slice j's gradient is complete once slice j + 1 — its earliest consumer, the last to run backward — has added
-    its share; that node hands it to autograd, and slice 0's node hands over the latents' gradient."""
+    its share; that node hands it to autograd, and slice 0's node hands over the latents' gradient.
+    Requires n_support >= num_slices - 1 (the reference's max_support_slices = num_slices): only then does slice i + 1 read slice
+    i's result, so autograd's dependencies force the last-to-first backward order the shared buffer relies on — the caller
+    (models/clc.py) falls back to per-slice concatenations otherwise."""
 
     def __init__(self, both, n_support, S):
         self.C0, self.S, self.n = both.shape[1], int(S), int(n_support)
@@ -970,6 +1133,7 @@ class _GDNFn(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, res, inverse):
+        _own(ctx)
         N, Cc, H, W = x.shape
         need_grad = any(ctx.needs_input_grad)
         v = new_act(N, Cc, H, W, x) if need_grad else None
@@ -982,6 +1146,7 @@ class _GDNFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _reown(ctx)
         x, g, v = ctx.saved_tensors
         N, Cc, H, W = x.shape
         dy, xx = dense(dy), dense(x)
@@ -1012,6 +1177,7 @@ class _GDNParamFn(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, res, inverse, gamma_bound, beta_bound, pedestal, gamma2=None, beta2=None):
+        _own(ctx)
         N, Cc, H, W = x.shape
         need_grad = any(ctx.needs_input_grad)
         sets = [(gamma, beta)] + ([(gamma2, beta2)] if gamma2 is not None else [])
@@ -1035,6 +1201,7 @@ class _GDNParamFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _reown(ctx)
         x, v, *rest = ctx.saved_tensors
         inverse, has_res, gamma_bound, beta_bound, nset = ctx.cfg
         gms, gts = rest[0::2], rest[1::2]
@@ -1061,8 +1228,8 @@ class _GDNParamFn(Function):
                     def post(gm=gm, beta=beta, dgf=dgf, dbe=dbe, gg=gg, gb=gb):
                         _lib.check(_L().clc_gdn_reparam_bwd(gm.data_ptr(), beta.data_ptr(), Cc, gamma_bound, beta_bound, dgf.data_ptr(),
                                                             dbe.data_ptr(), gg.data_ptr(), gb.data_ptr(), 1, _stream()), "clc_gdn_reparam_bwd")
-                    _PENDING_POST.setdefault(_LAST_DEFER_VID[0], []).append(post)
-                    _KEEPALIVE.append((gm, beta, dgf, dbe))
+                    _S().pending_post.setdefault(_S().last_defer_vid, []).append(post)
+                    _S().keepalive.append((gm, beta, dgf, dbe))
                 else:
                     dgf, dbe = wgrad_raw(xk, dvk, ks=1, stride=1, pad=0, Cout=Cc, Cin=Cc, want_bias=True, in_op=IN_SQUARE)
                     if not direct:
@@ -1091,6 +1258,7 @@ class _LayerNormFn(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, fold_in=None, grad_slot=None, gamma2=None, beta2=None):
+        _own(ctx)
         ctx.grad_slot = grad_slot
         x, xp, N, H, W, Cc, ldx = nhwc(x)
         rows = N * H * W
@@ -1112,6 +1280,7 @@ class _LayerNormFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _reown(ctx)
         x, gamma, mean, rstd = ctx.saved_tensors
         beta, gamma2, beta2 = ctx.refs
         paired = gamma2 is not None
@@ -1167,6 +1336,7 @@ class _WinAttnFn(Function):
 
     @staticmethod
     def forward(ctx, qkv, relbias, heads, ws, shift, relbias2=None):
+        _own(ctx)
         qkv, qp, N, H, W, C3, ldq = nhwc(qkv)
         Cc = C3 // 3
         out = new_act(N, Cc, H, W, qkv)
@@ -1176,6 +1346,7 @@ class _WinAttnFn(Function):
         rbs = [t if t.is_contiguous() else t.contiguous() for t in tabs]
         ctx.rb_params = [t if r is t else None for t, r in zip(tabs, rbs)]
         lp = lse.data_ptr() if need else None
+        _prof_hint(4.0 * N * H * W * ws * ws * Cc, f"winattn fwd C{Cc} h{heads} ws{ws} {N}x{H}x{W}")   # QK^T + PV: 2 x 2 T hd per token and head
         if relbias2 is None:
             _lib.check(_L().clc_winattn_fwd(qp, ldq, rbs[0].data_ptr(), out.data_ptr(), Cc, lp, N, H, W, Cc, heads, ws, int(shift), _stream()), "clc_winattn_fwd")
         else:
@@ -1187,6 +1358,7 @@ class _WinAttnFn(Function):
 
     @staticmethod
     def backward(ctx, dout):
+        _reown(ctx)
         heads, ws, shift, ntab = ctx.cfg
         qkv, out, lse, *rbs = ctx.saved_tensors
         paired = ntab == 2
@@ -1201,6 +1373,7 @@ class _WinAttnFn(Function):
         wsb = torch.empty((nbytes + 3) // 4, device=qkv.device, dtype=torch.float32)
         defer = direct and DEFER_REDUCTIONS
         dp = [None if defer else d.data_ptr() for d in drbs]
+        _prof_hint(8.0 * N * H * W * ws * ws * Cc, f"winattn bwd C{Cc} h{heads} ws{ws} {N}x{H}x{W}")   # (counted as 2 x forward, like the convolutions)
         if not paired:
             _lib.check(_L().clc_winattn_bwd(dop, lddo, qp, ldq, rbs[0].data_ptr(), out.data_ptr(), Cc, lse.data_ptr(), dqkv.data_ptr(), C3,
                                             dp[0], int(direct), N, H, W, Cc, heads, ws, int(shift), wsb.data_ptr(), nbytes, _stream()), "clc_winattn_bwd")
@@ -1231,6 +1404,7 @@ class _GateFn(Function):
 
     @staticmethod
     def forward(ctx, a, b, idn):
+        _own(ctx)
         a, b, idn = dense(a), dense(b), dense(idn)
         out = new_act(*a.shape, a)
         _lib.check(_L().clc_gate_fwd(a.data_ptr(), b.data_ptr(), idn.data_ptr(), out.data_ptr(), a.numel(), _stream()), "clc_gate_fwd")
@@ -1239,6 +1413,7 @@ class _GateFn(Function):
 
     @staticmethod
     def backward(ctx, g):
+        _reown(ctx)
         a, b = ctx.saved_tensors
         g = dense(g)
         da, db = new_act(*a.shape, a), new_act(*a.shape, a)

@@ -208,7 +208,7 @@ class FusedAdamW:
             dst.copy_(src)
 
     def step(self):
-        L, st = _lib.load(), ops._stream()
+        L, st = ops._L(), ops._stream()
         _lib.check(L.clc_adam_tick(self.step_dev.data_ptr(), float(self.betas[0]), float(self.betas[1]), st), "clc_adam_tick")
         sq = None
         if self.max_norm > 0:
@@ -249,7 +249,7 @@ class FilterTransposer:
 
     def refresh(self):
         if self.n:
-            _lib.check(_lib.load().clc_filter_transpose_batched(self.table.data_ptr(), self.n, self.total_tiles, ops._stream()), "clc_filter_transpose_batched")
+            _lib.check(ops._L().clc_filter_transpose_batched(self.table.data_ptr(), self.n, self.total_tiles, ops._stream()), "clc_filter_transpose_batched")
 
 
 class TrainEngine:

@@ -135,6 +135,9 @@ int clc_conv2d_wgrad_batched(const clc_wgrad_desc* descs, int count, clc_stream_
  * which a fix-up launch adds in workgroup order.  Same results as clc_conv2d_wgrad_batched up to summation order; run-to-run
  * reproducible (the ranges depend only on the group's shapes). */
 size_t clc_conv2d_wgrad_group_workspace_bytes(void);
+/* per-problem workspace a problem needs INSIDE clc_conv2d_wgrad_batched_sk: 0 for every plan whose partial tiles live in the
+ * group workspace (d->workspace may then be NULL), clc_conv2d_wgrad_workspace_bytes(d) for the small-Cin split path. */
+size_t clc_conv2d_wgrad_sk_workspace_bytes(const clc_wgrad_desc* d);
 /* kernel family a problem is planned on: 1 = small-Cin VALU kernel, 64900 + TW = all-taps 3x3 kernel (TW = 32 | 16 | 8),
  * BM * 1000 + BN = tap-per-workgroup kernel (same ids clc_conv2d_wgrad returns).  Benchmark tooling: FLOP accounting per kernel. */
 int clc_conv2d_wgrad_variant(const clc_wgrad_desc* d);

@@ -110,3 +110,28 @@ def test_hip_codec_reproduces_reference_streams(dev, name, R):
     enc = p.compress(x, refs) if R else p.compress(x)
     assert list(enc["shape"]) == g["shape"].tolist() and len(enc["strings"][0]) == 1 and len(enc["strings"][1]) == 1
     assert abs(len(enc["strings"][0][0]) - len(ys)) <= 0.01 * len(ys) and abs(len(enc["strings"][1][0]) - len(zs)) <= 0.02 * len(zs) + 8
+    # (5) the transform -> coder hand-off, end to end, symbol by symbol: the symbols / CDF indexes the HIP compress() path derives
+    #     from ITS OWN transforms against the ones the reference's compress() coded (same slice order, same element order).  Only
+    #     rounding-boundary flips may differ (|d symbol| = 1, |d index| = 1) and few of them: a slice-order or layout slip between
+    #     the transforms and the coder would differ almost everywhere.  Bound: 0.1 % of the positions.
+    from clc_amd.entropy_models import GaussianConditional as _GC   # noqa: F401  (documentation: quantize_and_index lives there)
+
+    with torch.no_grad():
+        fwd = p(x, refs) if R else p(x)
+    gc = p.gaussian_conditional
+    hy, hmu, hsc = fwd["para"]["y"], fwd["para"]["means"], fwd["para"]["scales"]
+    hip = [gc.quantize_and_index(a, m, s_) for a, m, s_ in zip(hy.chunk(5, 1), hmu.chunk(5, 1), hsc.chunk(5, 1))]
+    h_sym = torch.cat([q[0].contiguous().reshape(-1) for q in hip]).cpu()
+    h_idx = torch.cat([q[1].contiguous().reshape(-1) for q in hip]).cpu()
+    g_sym = torch.cat([q[0].contiguous().reshape(-1) for q in parts]).cpu()
+    g_idx = torch.cat([q[1].contiguous().reshape(-1) for q in parts]).cpu()
+    n = g_sym.numel()
+    ds, di = (h_sym - g_sym).abs(), (h_idx - g_idx).abs()
+    assert int(ds.max()) <= 1 and int(di.max()) <= 1, (int(ds.max()), int(di.max()))
+    frac_s, frac_i = float((ds > 0).sum()) / n, float((di > 0).sum()) / n
+    print(f"{name}: symbol mismatches {frac_s:.2e}, index mismatches {frac_i:.2e} of {n} positions")
+    assert frac_s <= 1e-3 and frac_i <= 1e-3, (frac_s, frac_i)
+    hz = p.h_a(hy)
+    med = p.entropy_bottleneck._get_medians().reshape(1, -1, 1, 1)
+    dz = (torch.round(hz - med) - torch.round(z - med)).abs()
+    assert int(dz.max()) <= 1 and float((dz > 0).sum()) / dz.numel() <= 2e-3, (int(dz.max()), float((dz > 0).sum()) / dz.numel())

@@ -112,3 +112,34 @@ print("ok", len(done))
 """
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0 and out.stdout.startswith("ok"), out.stderr[-2000:]
+
+
+def test_host_tables_follow_load_state_dict_and_update():
+    """The coder's host copy of the CDF tables (EntropyModel.host_tables, one D2H copy per model instead of CLC_run.py:654-656's
+    .tolist() per call) must not survive a change of the tables: update() replaces the buffers, load_state_dict copies INTO them."""
+    from clc_amd.entropy_models import GaussianConditional
+    from clc_amd.models.clc import get_scale_table
+
+    a = GaussianConditional(None)
+    a.update_scale_table(get_scale_table())
+    cdf_a = a.host_tables()[0].copy()
+    assert a.host_tables()[0] is a.host_tables()[0]            # cached between calls
+    b = GaussianConditional(None)
+    b.update_scale_table(get_scale_table(min=0.2, max=64, levels=64))   # other tables, same shapes? no: narrower -> other width
+    sd = b.state_dict()
+    c = GaussianConditional(None)
+    c.update_scale_table(get_scale_table())
+    before = c.host_tables()
+    assert (before[0] == cdf_a).all()
+    for n in ("_quantized_cdf", "_offset", "_cdf_length", "scale_table"):   # the reference resizes the buffers before loading (CLC_run.py:599-618)
+        getattr(c, n).resize_(sd[n].shape)
+    c.load_state_dict(sd)
+    after = c.host_tables()
+    assert after[0].shape == tuple(sd["_quantized_cdf"].shape) and (after[0] == sd["_quantized_cdf"].numpy()).all()
+    assert (after[1] == sd["_cdf_length"].numpy()).all() and (after[2] == sd["_offset"].numpy()).all()
+    # in-place edit of a buffer (no load_state_dict hook involved): the version counters catch it
+    c._offset.add_(1)
+    assert (c.host_tables()[2] == sd["_offset"].numpy() + 1).all()
+    # update(force) replaces the buffer objects
+    c.update_scale_table(get_scale_table(), force=True)
+    assert (c.host_tables()[0] == cdf_a).all()

@@ -85,9 +85,13 @@ def test_forward_parity_other_shapes(dev):
         assert abs(_psnr(a["x_hat"], x) - _psnr(b["x_hat"].cpu(), x)) <= 0.01
 
 
-def _grad_parity(o, p, tol=5e-3, min_checked=600):
+def _grad_parity(o, p, tol=5e-3, min_checked=600, flips=0):
+    """every parameter gradient of the product vs the oracle's, relative to the gradient's largest element.
+    flips: number of latent elements whose STE-rounded symbol differs between the two runs (round(y - mu) is discontinuous: an
+    argument within float error of .5 lands on either side, and that y_hat element then differs by 1.0).  Each flip perturbs the
+    gradients of the layers downstream of it; with flips > 0 at most 4 * flips parameters may exceed `tol`, none 10 * tol."""
     og = dict(o.named_parameters())
-    checked, worst = 0, 0.0
+    checked, worst, over = 0, 0.0, []
     for n, prm in p.named_parameters():
         go = og[n].grad
         if go is None:
@@ -101,9 +105,19 @@ def _grad_parity(o, p, tol=5e-3, min_checked=600):
         err = (gp - go).abs().max().item() / denom
         worst = max(worst, err)
         checked += 1
-        assert err < tol, f"{n}: grad rel err {err:.3e}"
+        if err >= tol:
+            over.append((n, err))
+        assert err < (10 * tol if flips else tol), f"{n}: grad rel err {err:.3e} (symbol flips: {flips})"
+    assert len(over) <= 4 * flips, (flips, over)
     assert checked > min_checked, checked
     return checked, worst
+
+
+def _symbol_flips(a, b):
+    """positions where round(y - mu) differs between the oracle's and the product's forward (see _grad_parity)"""
+    so = torch.round(a["para"]["y"] - a["para"]["means"])
+    sp = torch.round(b["para"]["y"].cpu() - b["para"]["means"].cpu())
+    return int((so != sp).sum())
 
 
 @pytest.mark.parametrize("kind,R,B", [("clc", 1, 2), ("clc", 3, 2), ("tcm", 0, 2)])
@@ -212,15 +226,19 @@ def test_config1_bs8_train_mode_step_vs_oracle(dev):
     ny = torch.rand((8, 320, 16, 16), generator=g) - 0.5
     nz = torch.rand((8, 192, 4, 4), generator=g) - 0.5
     with _injected_noise(ny, nz, dev):
-        lo = ORD(0.0067)(o(x, refs), x)
+        oo = o(x, refs)
+        lo = ORD(0.0067)(oo, x)
         lo["loss"].backward()
         xd, rd = x.to(dev), [r.to(dev) for r in refs]
-        lp = PRD(0.0067)(p(xd, rd), xd)
+        po = p(xd, rd)
+        lp = PRD(0.0067)(po, xd)
         lp["loss"].backward()
+    flips = _symbol_flips(oo, po)
     for k in ("loss", "bpp_loss", "mse_loss"):
         assert abs(lo[k].item() - lp[k].item()) <= 2e-4 * max(1.0, abs(lo[k].item())), (k, lo[k].item(), lp[k].item())
-    checked, worst = _grad_parity(o, p)
-    print("bs8 train-mode: checked", checked, "worst rel err", worst)
+    assert flips <= 8, flips   # of 655 360 latent elements
+    checked, worst = _grad_parity(o, p, flips=flips)
+    print("bs8 train-mode: checked", checked, "worst rel err", worst, "symbol flips", flips)
 
 
 class _injected_noise:
@@ -397,3 +415,90 @@ def test_train_engine_steps(dev):
     # the graph warm-up steps are rolled back before capture: the i-th replay IS the i-th training step
     assert losses[False][0:6] == losses[True][0:6], (losses[False], losses[True])
     assert min(losses[False][3:]) < losses[False][0], losses[False]
+
+
+def test_config2_bs8_r3_train_mode_step_vs_oracle(dev):
+    """BASELINE configs[2] at its quoted size (CLC lambda 0.025 MSE, 256x256, batch 8, 3 references), TRAIN mode with the noise
+    injected identically on both sides: loss terms and every gradient vs the oracle (VERDICT r2 weak #4: bs2 only before)."""
+    from clc_amd.train import RateDistortionLoss as PRD
+    from oracle.loss import RateDistortionLoss as ORD
+
+    o, p = _pair("clc", 3, dev)
+    o.train()
+    p.train()
+    x, refs = _inputs(8, 3, smooth=False)
+    g = torch.Generator().manual_seed(78)
+    ny = torch.rand((8, 320, 16, 16), generator=g) - 0.5
+    nz = torch.rand((8, 192, 4, 4), generator=g) - 0.5
+    with _injected_noise(ny, nz, dev):
+        oo = o(x, refs)
+        lo = ORD(0.025)(oo, x)
+        lo["loss"].backward()
+        xd, rd = x.to(dev), [r.to(dev) for r in refs]
+        po = p(xd, rd)
+        lp = PRD(0.025)(po, xd)
+        lp["loss"].backward()
+    flips = _symbol_flips(oo, po)
+    for k in ("loss", "bpp_loss", "mse_loss"):
+        assert abs(lo[k].item() - lp[k].item()) <= 2e-4 * max(1.0, abs(lo[k].item())), (k, lo[k].item(), lp[k].item())
+    assert flips <= 8, flips   # of 655 360 latent elements
+    checked, worst = _grad_parity(o, p, flips=flips)
+    print("configs[2] bs8 R=3 train-mode: checked", checked, "worst rel err", worst, "symbol flips", flips)
+
+
+def test_backward_parity_wide_model(dev):
+    """N=128 (train_CLC.py:356's default width): loss terms and every gradient vs the oracle (forward-only before)."""
+    from clc_amd import models as pm
+    from clc_amd.train import RateDistortionLoss as PRD
+    from oracle import graph as og
+    from oracle.loss import RateDistortionLoss as ORD
+    from oracle.recipe import apply_weight_recipe
+
+    o = og.CLC(N=128, num_ref_frames=1).eval()
+    apply_weight_recipe(o, 2)
+    p = pm.CLC(N=128, num_ref_frames=1)
+    p.load_state_dict(o.state_dict())
+    p = p.to(dev).eval()
+    x, refs = _inputs(1, 1)
+    lo = ORD(0.0067)(o(x, refs), x)
+    lo["loss"].backward()
+    xd, rd = x.to(dev), [r.to(dev) for r in refs]
+    lp = PRD(0.0067)(p(xd, rd), xd)
+    lp["loss"].backward()
+    for k in ("loss", "bpp_loss", "mse_loss"):
+        assert abs(lo[k].item() - lp[k].item()) <= 2e-4 * max(1.0, abs(lo[k].item())), (k, lo[k].item(), lp[k].item())
+    checked, worst = _grad_parity(o, p)
+    print("N=128: checked", checked, "worst rel err", worst)
+
+
+def test_max_support_slices_variants(dev):
+    """max_support_slices: the reference sizes every slice net for min(i, 5) support slices (CLC_run.py:402-474), so only 4 and 5
+    (and -1 = all) give consistent channel counts — 4 reads exactly what 5 reads — and anything smaller fails on a channel mismatch
+    in the reference too.  The shared support / gradient buffers (ops.SliceSupport) need every slice to read its predecessor
+    (ADVICE r2): they are enabled for 4 and 5 only; a smaller value raises instead of walking off a filter."""
+    from clc_amd import lib, models as pm
+    from clc_amd.recipe import apply_weight_recipe
+    from clc_amd.train import RateDistortionLoss as PRD
+
+    x, refs = _inputs(2, 1)
+    xd, rd = x.to(dev), [r.to(dev) for r in refs]
+    res = {}
+    for ms in (5, 4, -1):
+        p = pm.CLC(N=64, num_ref_frames=1, max_support_slices=ms)
+        apply_weight_recipe(p, 0)
+        p = p.to(dev).eval()
+        out = PRD(0.0067)(p(xd, rd), xd)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        res[ms] = (out["loss"].item(), {n: q.grad.clone() for n, q in p.named_parameters() if q.grad is not None})
+    assert res[5][0] == res[4][0]
+    for n in res[5][1]:
+        assert torch.equal(res[5][1][n], res[4][1][n]), n
+    # -1 takes the concatenation path (no shared buffers): same forward bits, gradients equal up to accumulation order
+    assert abs(res[5][0] - res[-1][0]) <= 1e-6 * abs(res[5][0])
+    worst = max((res[5][1][n] - res[-1][1][n]).abs().max().item() / max(res[5][1][n].abs().max().item(), 1e-12) for n in res[5][1])
+    assert worst < 2e-4, worst
+    p = pm.CLC(N=64, num_ref_frames=1, max_support_slices=2).to(dev).eval()
+    with pytest.raises(lib.ClcError, match="does not match the filter"):
+        with torch.no_grad():
+            p(xd, rd)

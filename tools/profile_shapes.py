@@ -29,17 +29,16 @@ def main():
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
     agg = {}
-    for fam, variant, flops, e0, e1, shape, *rest in rec:
-        nbytes = rest[0] if rest else 0
-        a = agg.setdefault((shape, variant), [0, 0.0, 0.0, 0.0])
+    for r in rec:
+        a = agg.setdefault((r.label or r.fam, r.variant, r.owner), [0, 0.0, 0.0, 0.0])
         a[0] += 1
-        a[1] += e0.elapsed_time(e1)
-        a[2] += flops
-        a[3] += nbytes or 0
+        a[1] += r.ms()
+        a[2] += r.flops
+        a[3] += r.nbytes or 0
     tot = sum(a[1] for a in agg.values())
-    print(f"total conv-launch time {tot:.2f} ms over {sum(a[0] for a in agg.values())} launches (eager, event-bracketed: includes ~launch gaps)")
-    for (shape, variant), (n, ms, fl, nb) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:90]:
-        print(f"{ms:7.3f} ms  n={n:3d}  {ms / n * 1e3:7.1f} us  {fl / ms / 1e9:6.1f} TF  {nb / ms / 1e6:6.0f} GB/s  v{variant:<6d} {shape}")
+    print(f"total launch time {tot:.2f} ms over {sum(a[0] for a in agg.values())} launches (eager, event-bracketed: includes ~launch gaps)")
+    for (shape, variant, owner), (n, ms, fl, nb) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("ROWS", "120"))]:
+        print(f"{ms:7.3f} ms  n={n:3d}  {ms / n * 1e3:7.1f} us  {fl / ms / 1e9:6.1f} TF  {nb / ms / 1e6:6.0f} GB/s  v{variant:<8d} {owner:11s} {shape}")
 
 
 if __name__ == "__main__":
