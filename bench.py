@@ -205,9 +205,11 @@ def _kernel_name(L, r):
     if f == 3:   # <BN, TR, KW, PF>: 4-wave tiles keep one K-tile in flight, 8-wave ones CLC_TUNE_SPLITK_PF (key 6)
         kw = (variant >> 16) & 15
         return f"conv_igemm_splitk_kernel<{bn}, {tr}, {kw}, {1 if kw == 4 or splitk_pf == 1 else 3}>"
-    if f in (4, 5, 6):   # family 5 = the 1x1 instantiation (its own symbol)
+    if f in (4, 5):   # family 5 = the 1x1 instantiation (its own symbol)
         return (f"conv_igemm_dma2_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}, {1 if f == 5 else 3}, "
                 f"{(variant >> 24) & 3}>")   # (last argument: 1 = squared operand, GDN's norm convolution)
+    if f == 8:        # the persistent pipelined kernel of the large-map 1x1 layers
+        return f"conv_igemm_p1x1_kernel<{(variant >> 24) & 3}>"
     return f"conv_igemm{ {1: '', 2: '_dma'}[f]}_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}>"
 
 
@@ -361,7 +363,7 @@ def roofline_leg(engine, x, refs):
     t = t_replay if t_replay is not None else t_eager
     # the 1x1 / linear instantiation (..., 1>) moves ~50 FLOP per byte on 128-channel layers — under the f32 ridge once the residual and
     # saved-activation streams are counted — so its roofline is HBM; everything else is MFMA
-    hbm_bound = name.startswith("conv_igemm_dma2_kernel") and (name.endswith(", 1, 0>") or name.endswith(", 1, 1>")) and nb > 0
+    hbm_bound = ((name.startswith("conv_igemm_dma2_kernel") and (name.endswith(", 1, 0>") or name.endswith(", 1, 1>"))) or name.startswith("conv_igemm_p1x1_kernel")) and nb > 0
     achieved = (nb / t / 1e9) if hbm_bound else (f / t / 1e12)
     peak = HBM_PEAK_GBS if hbm_bound else F32_MFMA_PEAK_TFLOPS
     # HBM-side bytes per launch of that kernel from the committed PMC passes (separate `rocprofv3 --pmc FETCH_SIZE` /

@@ -18,7 +18,8 @@ enum { CLC_TUNE_DMA_LOOP = 0 /* 1: conv_igemm_dma_kernel, 2: conv_igemm_dma2_ker
        CLC_TUNE_1X1_TILE = 7 /* large-map 1x1 convolutions with at most this many K-tiles use the 128x64 tile (0: off) */,
        CLC_TUNE_XCD_MAP = 8 /* dma2 conv kernel: channel tiles of a pixel tile back to back on one XCD: 0 off, 1 = 1x1 layers, 2 = all */,
        CLC_TUNE_WGRAD_DMA = 9 /* filter-gradient tile kernels: LDS-DMA staging for problems without operand arithmetic */,
-       CLC_TUNE_RING = 10 /* conv_igemm_dma3_kernel (more operand bytes in flight), bit field: see launch_dma23_t */,
+       CLC_TUNE_ABLATE = 12 /* diagnostic: conv_igemm_dma2_kernel without its MFMAs (1) / result stores (2) / operand DMA (4) — wrong results, timing only */,
+       CLC_TUNE_P1X1 = 13 /* large-map 1x1 layers on the persistent pipelined kernel (conv_igemm_p1x1_kernel) */,
        CLC_TUNE_COUNT = 16 };
 extern int clc_tuning[CLC_TUNE_COUNT];
 

@@ -62,6 +62,7 @@ struct ConvParams {
   const float* out_gate; int ldog, og_act, og_pre;   // whole result *= act'(out_gate)
   int xcd_map;                 // conv_igemm_dma2_kernel: workgroups that share a pixel tile run back to back on ONE XCD (see the kernel)
   int dma_place;               // conv_igemm_dma2_kernel: 1 = next tile's DMA pieces at the top of the iteration, 0 = between the MFMA groups
+  int ablate;                  // CLC_TUNE_ABLATE (diagnostic builds of the timing only, results are WRONG): 1 = no MFMAs, 2 = no result stores, 4 = no operand DMA
 };
 
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
@@ -178,35 +179,49 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, float acc, f
 
 // Same arithmetic, element for element, on 4 consecutive channels of one pixel (p.vec_epi: no shuffle, Cout % 4 == 0,
 // every row stride a multiple of 4 floats and every base 16-B aligned): b128 loads / stores instead of dword ones.
-__device__ __forceinline__ void epilogue_store4(const ConvParams& p, const float* bias, f32x4 acc, int m, int co, int DH, int DW, int ph, int pw) {
-  size_t pix;
-  if (p.transposed && p.stride == 2) {
-    const int n = m / (DH * DW), rr = m - n * (DH * DW);
-    const int oy = rr / DW, ox = rr - oy * DW;
-    pix = (size_t)(n * p.OH + 2 * oy + ph) * p.OW + 2 * ox + pw;
-  } else {
-    pix = (size_t)m;
-  }
+// epilogue_math4: the arithmetic alone, on values already in registers (unused operands: anything).
+struct Epi4 { f32x4 y, pre; };
+__device__ __forceinline__ Epi4 epilogue_math4(const ConvParams& p, f32x4 bv, f32x4 acc, f32x4 res_raw, f32x4 rg_raw, f32x4 mul_raw, f32x4 og_raw) {
   f32x4 v = acc;
-  if (bias) { v[0] += bias[co]; v[1] += bias[co + 1]; v[2] += bias[co + 2]; v[3] += bias[co + 3]; }
-  else { v[0] += 0.f; v[1] += 0.f; v[2] += 0.f; v[3] += 0.f; }
+  v[0] += bv[0]; v[1] += bv[1]; v[2] += bv[2]; v[3] += bv[3];
   f32x4 rv = {0.f, 0.f, 0.f, 0.f};
   if (p.res) {
-    rv = p.res_scale * *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + co);
-    if (p.res_gate) rv = rv * act_deriv4(*reinterpret_cast<const f32x4*>(p.res_gate + pix * p.ldg + co), p.rg_act, p.rg_pre);
+    rv = p.res_scale * res_raw;
+    if (p.res_gate) rv = rv * act_deriv4(rg_raw, p.rg_act, p.rg_pre);
   }
   if (p.res && p.res_first) v = v + rv;
-  if (p.y_pre) *reinterpret_cast<f32x4*>(p.y_pre + pix * p.ldp + co) = p.pre_deriv ? act_deriv4(v, p.act, 1) : v;
+  Epi4 o;
+  o.pre = p.pre_deriv ? act_deriv4(v, p.act, 1) : v;
   if (p.norm != CLC_NORM_NONE) {
-    const f32x4 mv = *reinterpret_cast<const f32x4*>(p.mul + pix * p.ldm + co);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = (p.norm == CLC_NORM_GDN) ? mv[q] * rsqrtf(v[q]) : ((p.norm == CLC_NORM_IGDN) ? mv[q] * sqrtf(v[q]) : 2.f * (mv[q] * v[q]));
+    for (int q = 0; q < 4; ++q) v[q] = (p.norm == CLC_NORM_GDN) ? mul_raw[q] * rsqrtf(v[q]) : ((p.norm == CLC_NORM_IGDN) ? mul_raw[q] * sqrtf(v[q]) : 2.f * (mul_raw[q] * v[q]));
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], p.act);
   if (p.res && !p.res_first) v = v + rv;
-  if (p.out_gate) v = v * act_deriv4(*reinterpret_cast<const f32x4*>(p.out_gate + pix * p.ldog + co), p.og_act, p.og_pre);
-  *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + co) = v;
+  if (p.out_gate) v = v * act_deriv4(og_raw, p.og_act, p.og_pre);
+  o.y = v;
+  return o;
+}
+__device__ __forceinline__ size_t epilogue_pixel(const ConvParams& p, int m, int DH, int DW, int ph, int pw) {
+  if (p.transposed && p.stride == 2) {
+    const int n = m / (DH * DW), rr = m - n * (DH * DW);
+    const int oy = rr / DW, ox = rr - oy * DW;
+    return (size_t)(n * p.OH + 2 * oy + ph) * p.OW + 2 * ox + pw;
+  }
+  return (size_t)m;
+}
+__device__ __forceinline__ void epilogue_store4(const ConvParams& p, const float* bias, f32x4 acc, int m, int co, int DH, int DW, int ph, int pw) {
+  const size_t pix = epilogue_pixel(p, m, DH, DW, ph, pw);
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f}, z = {0.f, 0.f, 0.f, 0.f};
+  if (bias) { bv[0] = bias[co]; bv[1] = bias[co + 1]; bv[2] = bias[co + 2]; bv[3] = bias[co + 3]; }
+  const f32x4 rr = p.res ? *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + co) : z;
+  const f32x4 rg = (p.res && p.res_gate) ? *reinterpret_cast<const f32x4*>(p.res_gate + pix * p.ldg + co) : z;
+  const f32x4 mv = p.norm != CLC_NORM_NONE ? *reinterpret_cast<const f32x4*>(p.mul + pix * p.ldm + co) : z;
+  const f32x4 og = p.out_gate ? *reinterpret_cast<const f32x4*>(p.out_gate + pix * p.ldog + co) : z;
+  const Epi4 o = epilogue_math4(p, bv, acc, rr, rg, mv, og);
+  if (p.y_pre) *reinterpret_cast<f32x4*>(p.y_pre + pix * p.ldp + co) = o.pre;
+  *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + co) = o.y;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -602,7 +617,7 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
   // scalar state of the tile being fetched
   unsigned s_bit, s_adelta, s_bdelta; int s_cleft; bool s_en;
   auto set_fetch = [&](bool en) {
-    s_en = en;
+    s_en = en && !(p.ablate & 4);
     s_bit = 1u << (tj * 3 + ti);
     s_cleft = p.Cin - kc * BK;
     s_adelta = (unsigned)(sgn * (tj * p.W + ti) * p.ldx + kc * BK) * 4u;
@@ -648,6 +663,7 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
     for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * BK);
   };
   auto mfma_group = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) {
+    if (p.ablate & 1) { asm volatile("" ::"v"(a[0]), "v"(b[0])); return; }
 #pragma unroll
     for (int ss = 0; ss < 4; ++ss)
 #pragma unroll
@@ -682,6 +698,7 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
   constexpr int LDC = BN + 4;
   float* Cs = smem;   // [BM][LDC]
   __syncthreads();    // every wave's trailing fragment read is done before the tile is overwritten
+  if (p.ablate & 2) { if (acc[0][0][0] == 123.456f) p.y[0] = 1.f; return; }
   {
     const int col = lane & 31, rhalf = 4 * (lane >> 5);
 #pragma unroll
@@ -709,225 +726,243 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv_igemm_dma2_kernel with MORE OPERAND BYTES IN FLIGHT (same tiles, same K order, same MFMA sequence -> same bits).
-// dma2 keeps exactly one K-tile in flight per workgroup and drains it with `s_waitcnt vmcnt(0)` before every barrier; with 2-3
-// workgroups per CU that is 24-64 KB of loads per CU, and only during part of each workgroup's life — too little to cover the
-// HBM latency of the whole chip (Little: 6 TB/s x ~2 us = ~47 KB per CU, all the time).  Two forms (NSA = A-tile ring slots):
-//   NSA = 2  "early": the FIRST TWO K-tiles are issued back to back before the first wait (a 1x1 layer with 64 input channels has
-//            two K-tiles in all: its whole operand is in flight at once), after that tile it+2 is issued as soon as the barrier
-//            has freed tile it's slot.  LDS as dma2 (3 workgroups per CU on the 128x64 tile).
-//   NSA = 3  "ring": A tiles (gathered pixels: HBM / Infinity Cache) in a 3-slot ring, issued TWO iterations ahead; B tiles (the
-//            filter: L2-resident) stay double-buffered, issued one iteration ahead but BEFORE the A pieces, so that one counted
-//            `s_waitcnt vmcnt(A_P)` — everything but the newest A tile — retires both operands of the next tile (the vector
-//            memory counter is in issue order).  128x128 tile: 48 + 32 = 80 KB -> still two workgroups per CU.
-// Barriers are raw s_barrier (a __syncthreads() would make hipcc drain the DMA queue: LDS-DMA is a pending LDS write on vmcnt).
-template <int BM, int BN, int WM, int WN, bool TR, int KS, int OP, int NSA>
-__global__ __launch_bounds__(64 * WM * WN, (64 * WM * WN) >= 512 ? 4 : ((64 * WM * WN) >= 256 ? 2 : 4))
-void conv_igemm_dma3_kernel(const ConvParams p) {
-  constexpr int NT = 64 * WM * WN;
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int A_P = BM * 8 / NT, B_P = BN * 8 / NT;
-  static_assert(TM >= 1 && TN >= 1 && A_P * NT == BM * 8 && B_P * NT == BN * 8, "tile");
-  static_assert(NSA == 2 || NSA == 3, "ring depth");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                      // [NSA][BM][BK], slot-swizzled
-  float* Bs = smem + NSA * BM * BK;      // [2][BN][BK]
-
+// PERSISTENT kernel for the large-map 1x1 convolutions / linears (KS = 1, stride 1; 128 x 64 tiles, 8 waves as 4 x 2).
+// Why (r3 ablation of conv_igemm_dma2_kernel<128,64,4,2,*,1,0> on 64 -> 192 @ 8x128x128, 70.8 us in all): without its MFMAs 54.8,
+// without its result stores 41.0, without its operand DMA 61.2 — and with NONE of the three still 18.3 us.  A tile of these layers is
+// 2-8 K-steps: the per-tile fixed work (row addressing, the first operand latency, the LDS round trip of the C tile, barriers, waiting
+// for the stores to retire before the workgroup's slot is handed on) is as large as the arithmetic, and nothing overlaps with
+// anything: all 768 resident workgroups load, then compute, then store, in step.  Here a workgroup stays resident and walks its tiles
+//   (M-tile mt = blockIdx.x, + gridDim.x, ...) x (all N-tiles of that M-tile, so the A rows are re-read from L2) x (K-steps)
+// as ONE flat sequence of K-steps through a 3-slot LDS ring: the DMA pieces of step s + 2 are issued at the top of step s whatever
+// tile they belong to, so the next tile's operands arrive under this tile's MFMAs and epilogue; the epilogue is per WAVE, straight
+// from the accumulator registers (a 32 x 32 block: 16 dword stores of two 128-B row pieces each) — no C tile in LDS, no barrier,
+// so the two workgroups of a CU (72 KB each) and the waves inside one drift apart instead of marching in phase; result stores are
+// never waited for while the operands they stand in front of (the vector-memory counter is in issue order) are not yet needed.
+// Same K order and MFMA sequence per output element as the tiled kernels -> same bits.
+// Host-side conditions: M % 128 == 0, Cout % 64 == 0, Cin % 4 == 0, kc_tiles >= 2, one filter set, no PixelShuffle store.
+__device__ __forceinline__ void wait_vm(int n) {   // s_waitcnt vmcnt(n) for the handful of counts the persistent kernel uses
+  if (n >= 63) asm volatile("s_waitcnt vmcnt(63) lgkmcnt(0)" ::: "memory");
+  else if (n == 35) asm volatile("s_waitcnt vmcnt(35) lgkmcnt(0)" ::: "memory");
+  else if (n == 19) asm volatile("s_waitcnt vmcnt(19) lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+}
+template <int OP>
+__global__ __launch_bounds__(512, 4)
+void conv_igemm_p1x1_kernel(const ConvParams p, int tiles_m, int tiles_n) {
+  constexpr int BM = 128, BN = 64, NT = 512, NS = 3, SLOT = (BM + BN) * BK;
+  constexpr int P = 3;   // DMA pieces per wave and K-step: 2 of the A tile (16 rows), 1 of the B tile (8 rows)
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [NS][BM + BN][BK], slot-swizzled (see conv_igemm_dma_kernel)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  int bxm = blockIdx.x, bym = blockIdx.y;
-  if (p.xcd_map) {   // (see conv_igemm_dma2_kernel)
-    const int L = blockIdx.x + gridDim.x * blockIdx.y, c = L & 7, j = L >> 3;
-    bym = j % (int)gridDim.y;
-    bxm = (j / (int)gridDim.y) * 8 + c;
-  }
-  const int m0 = bxm * BM, n0 = bym * BN;
-  const int cls = blockIdx.z, ph = cls >> 1, pw = cls & 1;
-  const bool half = p.transposed && p.stride == 2;
-  const int DH = half ? p.OH / 2 : p.OH, DW = half ? p.OW / 2 : p.OW;
-  const TapGrid tg = KS == 1 ? TapGrid{0, 0, 1, 1, 1} : make_taps(p, ph, pw);
-
-  const int fset = p.group_rows ? min(m0 / p.group_rows, 3) : 0;
-  const float* wsel = fset == 0 ? p.w : (fset == 1 ? p.w2 : (fset == 2 ? p.w3 : p.w4));
-  const float* bsel = fset == 0 ? p.bias : (fset == 1 ? p.bias2 : (fset == 2 ? p.bias3 : p.bias4));
+  const int wm = wave >> 1, wn = wave & 1;
+  const int G = gridDim.x;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wsel), 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
 
-  constexpr int sgn = TR ? -1 : 1;
-  unsigned a_base[A_P], a_mask[A_P], b_base[B_P];
-  int a_c4[A_P], b_c4[B_P];
-  bool b_ok[B_P];
+  // per-lane parts of the DMA source offsets (bytes): row r of the tile, 16-B chunk chosen for this lane's LDS slot
+  unsigned a_lane[2], b_lane;
+  int a_c4[2], b_c4;
 #pragma unroll
-  for (int i = 0; i < A_P; ++i) {
+  for (int i = 0; i < 2; ++i) {
     const int r = (tid + i * NT) >> 3;
-    const RowState rs = make_row<TR>(p, m0 + r, DH, DW, ph, pw);
     a_c4[i] = ((tid & 7) ^ ((r >> 1) & 7)) * 4;
-    int oy, ox;
-    if (TR) { const int sh = p.stride - 1; oy = (rs.y0 - tg.kh0) >> sh; ox = (rs.x0 - tg.kw0) >> sh; }
-    else { oy = rs.y0 + tg.kh0; ox = rs.x0 + tg.kw0; }
-    unsigned mask = 0;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int iy = oy + sgn * j, ix = ox + sgn * q;
-        const bool ok = rs.ok && j < tg.nkh && q < tg.nkw && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        mask |= ok ? (1u << (j * 3 + q)) : 0u;
-      }
-    a_mask[i] = mask;
-    a_base[i] = ((unsigned)(rs.base + oy * p.W + ox) * (unsigned)p.ldx + (unsigned)a_c4[i]) * 4u;
+    a_lane[i] = ((unsigned)r * (unsigned)p.ldx + (unsigned)a_c4[i]) * 4u;
   }
-#pragma unroll
-  for (int i = 0; i < B_P; ++i) {
-    const int r = (tid + i * NT) >> 3;
-    const int co = n0 + r;
-    b_ok[i] = co < p.Cout;
-    b_c4[i] = ((tid & 7) ^ ((r >> 1) & 7)) * 4;
-    b_base[i] = ((unsigned)co * (unsigned)p.ldw + (unsigned)b_c4[i]) * 4u;
+  {
+    const int r = tid >> 3;
+    b_c4 = ((tid & 7) ^ ((r >> 1) & 7)) * 4;
+    b_lane = ((unsigned)r * (unsigned)p.ldw + (unsigned)b_c4) * 4u;
   }
   const int wave_row = wave * 8;
+  // the bias vector sits in LDS behind the ring: an epilogue's bias read must not be a vector-memory load (its wait would drain the
+  // DMA pieces in flight: the counter is in issue order)
+  float* bias_s = smem + NS * SLOT;
+  for (int i = tid; i < p.Cout; i += NT) bias_s[i] = p.bias ? p.bias[i] : 0.f;
+  const int my_mt = (tiles_m - (int)blockIdx.x + G - 1) / G;
+  const int total = my_mt * tiles_n * p.kc_tiles;
 
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int total = tg.nkh * tg.nkw * p.kc_tiles;
-  // two fetch cursors run ahead of the compute index: A by NSA - 1 tiles, B by one
-  struct Cur { int tj, ti, kc, n; };
+  struct Cur { int mt, nt, kt, n; };
   auto step = [&](Cur& c) {   // branch-free
-    const int kc1 = c.kc + 1;
-    const bool w1 = kc1 == p.kc_tiles;
-    c.kc = w1 ? 0 : kc1;
-    const int ti1 = c.ti + (w1 ? 1 : 0);
-    const bool w2 = ti1 == tg.nkw;
-    c.ti = w2 ? 0 : ti1;
-    c.tj += w2 ? 1 : 0;
+    const int kt1 = c.kt + 1;
+    const bool w1 = kt1 == p.kc_tiles;
+    c.kt = w1 ? 0 : kt1;
+    const int nt1 = c.nt + (w1 ? 1 : 0);
+    const bool w2 = nt1 == tiles_n;
+    c.nt = w2 ? 0 : nt1;
+    c.mt += w2 ? G : 0;
     ++c.n;
   };
-  auto dma_a = [&](int slot, const Cur& c) {
-    const bool en = c.n < total;
-    const unsigned bit = 1u << (c.tj * 3 + c.ti);
-    const int cleft = p.Cin - c.kc * BK;
-    const unsigned delta = (unsigned)(sgn * (c.tj * p.W + c.ti) * p.ldx + c.kc * BK) * 4u;
+  auto dma = [&](int slot, const Cur& c) {
+    const bool en = c.n < total && !(p.ablate & 4);
+    const int cleft = p.Cin - c.kt * BK;
+    const unsigned ao = ((unsigned)(c.mt * BM) * (unsigned)p.ldx + (unsigned)(c.kt * BK)) * 4u;
+    const unsigned bo = ((unsigned)(c.nt * BN) * (unsigned)p.ldw + (unsigned)(c.kt * BK)) * 4u;
+    float* base = smem + slot * SLOT;
 #pragma unroll
-    for (int i = 0; i < A_P; ++i) {
-      const bool ok = en && (a_mask[i] & bit) != 0u && a_c4[i] < cleft;
-      dma16(xr, As + (slot * BM + wave_row + i * (NT / 8)) * BK, ok ? a_base[i] + delta : kOOB);
-    }
+    for (int i = 0; i < 2; ++i) dma16(xr, base + (wave_row + i * 64) * BK, (en && a_c4[i] < cleft) ? a_lane[i] + ao : kOOB);
+    dma16(wr, base + (BM + wave_row) * BK, (en && b_c4 < cleft) ? b_lane + bo : kOOB);
   };
-  auto dma_b = [&](int slot, const Cur& c) {
-    const bool en = c.n < total;
-    const int cleft = p.Cin - c.kc * BK;
-    const int kh = tg.kh0 + tg.step * c.tj, kw = tg.kw0 + tg.step * c.ti;
-    const unsigned delta = (unsigned)((kh * p.ks + kw) * p.Cin + c.kc * BK) * 4u;
-#pragma unroll
-    for (int i = 0; i < B_P; ++i) {
-      const bool ok = en && b_ok[i] && b_c4[i] < cleft;
-      dma16(wr, Bs + (slot * BN + wave_row + i * (NT / 8)) * BK, ok ? b_base[i] + delta : kOOB);
-    }
-  };
+
   const int lr = lane & 31, hh = lane >> 5, sw = (lr >> 1) & 7;
   int fo[4];
 #pragma unroll
   for (int t8 = 0; t8 < 4; ++t8) fo[t8] = ((2 * t8 + hh) ^ sw) * 4;
-  f32x4 af[2][TM], bf[2][TN];
-  auto read_frag = [&](int sa, int sb, int t8, f32x4 (&a)[TM], f32x4 (&b)[TN]) {
-    const float* Ab = As + (sa * BM + wm * (BM / WM) + lr) * BK + fo[t8];
-    const float* Bb = Bs + (sb * BN + wn * (BN / WN) + lr) * BK + fo[t8];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * BK);
-      if (OP == 1) a[i] = a[i] * a[i];
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * BK);
+  f32x4 af[2], bf[2];
+  auto read_frag = [&](int slot, int t8, f32x4& a, f32x4& b) {
+    const float* base = smem + slot * SLOT;
+    a = *reinterpret_cast<const f32x4*>(base + (wm * 32 + lr) * BK + fo[t8]);
+    if (OP == 1) a = a * a;
+    b = *reinterpret_cast<const f32x4*>(base + (BM + wn * 32 + lr) * BK + fo[t8]);
   };
-  auto mfma_group = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) {
+  f32x16 acc;
 #pragma unroll
-    for (int ss = 0; ss < 4; ++ss)
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  auto mfma4 = [&](const f32x4& a, const f32x4& b) {
+    if (p.ablate & 1) { asm volatile("" ::"v"(a), "v"(b)); return; }
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][ss], b[j][ss], acc[i][j], 0, 0, 0);
-  };
-  auto tile_mfmas = [&](int sa, int sb) {   // (group 0's fragments are already in af[0] / bf[0])
-    read_frag(sa, sb, 1, af[1], bf[1]);
-    mfma_group(af[0], bf[0]);
-    read_frag(sa, sb, 2, af[0], bf[0]);
-    mfma_group(af[1], bf[1]);
-    read_frag(sa, sb, 3, af[1], bf[1]);
-    mfma_group(af[0], bf[0]);
-    mfma_group(af[1], bf[1]);
+    for (int ss = 0; ss < 4; ++ss) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ss], b[ss], acc, 0, 0, 0);
   };
 
-  Cur ca{0, 0, 0, 0}, cb{0, 0, 0, 0};
-  if constexpr (NSA == 2) {
-    dma_a(0, ca); dma_b(0, cb); step(ca); step(cb);
-    dma_a(1, ca); dma_b(1, cb); step(ca); step(cb);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_P + B_P) : "memory");   // tile 0 has landed; tile 1 stays in flight
-    __builtin_amdgcn_s_barrier();
-    read_frag(0, 0, 0, af[0], bf[0]);
-    for (int it = 0; it < total; ++it) {
-      const int buf = it & 1;
-      tile_mfmas(buf, buf);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // tile it + 1 (issued an iteration ago) has landed
-      __builtin_amdgcn_s_barrier();                                    // ... for everyone, and nobody reads tile it any more
-      dma_a(buf, ca); dma_b(buf, cb); step(ca); step(cb);              // tile it + 2 into the slot just freed
-      read_frag(buf ^ 1, buf ^ 1, 0, af[0], bf[0]);
+  // per-wave epilogue of one 32 x 32 block straight from the accumulator: lane (col, h) holds rows (r&3) + 8 (r>>2) + 4 h.
+  // Same arithmetic per element as epilogue_store; organised in whole-block phases (one uniform branch per phase instead of one per
+  // element), addresses = one 32-bit lane offset per tensor and tile + a scalar row offset (SRD buffer accesses), the activation
+  // chosen once per block.
+  const bool has_rg = p.res && p.res_gate, has_mul = p.norm != CLC_NORM_NONE;
+  const int S = p.y_pre ? 32 : 16;   // store instructions of one epilogue
+  auto srd = [](const float* ptr) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, 0x7FFFFFFF, 0x00020000); };
+  const __amdgpu_buffer_rsrc_t y_r = srd(p.y), pre_r = srd(p.y_pre ? p.y_pre : p.y), res_r = srd(p.res ? p.res : p.y),
+                               rg_r = srd(has_rg ? p.res_gate : p.y), mul_r = srd(has_mul ? p.mul : p.y), og_r = srd(p.out_gate ? p.out_gate : p.y);
+  auto ld32 = [](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); };
+  auto st32 = [](float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0); };
+#define CLC_ROWIDX(r) (((r) & 3) + 8 * ((r) >> 2))
+  auto epilogue = [&](int mt, int nt) {
+    const int co = nt * BN + wn * 32 + lr;
+    const float bv = bias_s[co];
+    const unsigned row0 = (unsigned)(mt * BM + wm * 32 + 4 * hh);
+    float v[16], rt[16], tq[16];
+    if (p.res) {   // the residual operand first: its latency runs under the bias / address arithmetic
+      const unsigned o = (row0 * (unsigned)p.ldr + (unsigned)co) * 4u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rt[r] = ld32(res_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldr) * 4u);
     }
-  } else {
-    dma_a(0, ca); step(ca);
-    dma_b(0, cb); step(cb);
-    dma_a(1, ca); step(ca);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_P) : "memory");         // A0, B0 have landed; A1 stays in flight
-    __builtin_amdgcn_s_barrier();
-    int sa = 0, sa2 = 2;   // A slot of tile it / of tile it + 2
-    for (int it = 0; it < total; ++it) {
-      const int sb = it & 1;
-      dma_b(sb ^ 1, cb); step(cb);                                     // B(it + 1): its slot held tile it - 1, read before the barrier
-      dma_a(sa2, ca); step(ca);                                        // A(it + 2): likewise
-      read_frag(sa, sb, 0, af[0], bf[0]);
-      tile_mfmas(sa, sb);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_P) : "memory");       // all but A(it + 2): A(it + 1) and B(it + 1) have landed
-      __builtin_amdgcn_s_barrier();
-      sa = sa == 2 ? 0 : sa + 1;
-      sa2 = sa2 == 2 ? 0 : sa2 + 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[r] + bv;
+    if (p.res) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rt[r] = p.res_scale * rt[r];
+      if (has_rg) {
+        const unsigned o = (row0 * (unsigned)p.ldg + (unsigned)co) * 4u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tq[r] = ld32(rg_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldg) * 4u);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rt[r] *= act_deriv(tq[r], p.rg_act, p.rg_pre);
+      }
+      if (p.res_first) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += rt[r];
+      }
     }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill pieces past the last tile
+    bool act_done = false;
+    if (p.y_pre) {
+      const unsigned o = (row0 * (unsigned)p.ldp + (unsigned)co) * 4u;
+      if (p.pre_deriv && p.act == CLC_ACT_GELU && !has_mul) {
+        // fc1 of the Swin MLPs: gelu'(v) is stored for the backward pass and gelu(v) is the result — one evaluation of the
+        // erf / exp parts for both (the same expressions gelu_f / gelu_grad_f evaluate)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float cdf, pdf;
+          gelu_parts(v[r], cdf, pdf);
+          st32(cdf + v[r] * pdf, pre_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldp) * 4u);
+          v[r] = v[r] * cdf;
+        }
+        act_done = true;
+      } else if (p.pre_deriv) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st32(act_deriv(v[r], p.act, 1), pre_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldp) * 4u);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st32(v[r], pre_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldp) * 4u);
+      }
+    }
+    if (has_mul) {
+      const unsigned o = (row0 * (unsigned)p.ldm + (unsigned)co) * 4u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tq[r] = ld32(mul_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldm) * 4u);
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        v[r] = (p.norm == CLC_NORM_GDN) ? tq[r] * rsqrtf(v[r]) : ((p.norm == CLC_NORM_IGDN) ? tq[r] * sqrtf(v[r]) : 2.f * (tq[r] * v[r]));
+    }
+    switch (act_done ? CLC_ACT_NONE : p.act) {   // (the same functions apply_act dispatches to)
+      case CLC_ACT_LRELU:
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.01f * v[r];
+        break;
+      case CLC_ACT_RELU:
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+        break;
+      case CLC_ACT_GELU:
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = gelu_f(v[r]);
+        break;
+      case CLC_ACT_NONE: break;
+      default:
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = apply_act(v[r], p.act);
+    }
+    if (p.res && !p.res_first) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] += rt[r];
+    }
+    if (p.out_gate) {
+      const unsigned o = (row0 * (unsigned)p.ldog + (unsigned)co) * 4u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tq[r] = ld32(og_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldog) * 4u);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] *= act_deriv(tq[r], p.og_act, p.og_pre);
+    }
+    {
+      const unsigned o = (row0 * (unsigned)p.ldy + (unsigned)co) * 4u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st32(v[r], y_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldy) * 4u);
+    }
+  };
+#undef CLC_ROWIDX
+
+  Cur cf{(int)blockIdx.x, 0, 0, 0}, cc = cf;
+  dma(0, cf); step(cf);
+  dma(1, cf); step(cf);
+  asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");   // step 0 has landed (and the bias vector is written); step 1 stays in flight
   __builtin_amdgcn_s_barrier();
-
-  constexpr int LDC = BN + 4;
-  float* Cs = smem;   // [BM][LDC]
-  {
-    const int col = lane & 31, rhalf = 4 * (lane >> 5);
+  int slot = 0, slot2 = 2, e_prev = 0;
+  for (int s = 0; s < total; ++s) {
+    dma(slot2, cf); step(cf);                         // step s + 2 into the slot step s - 1 was read from (everyone is past that barrier)
+    read_frag(slot, 0, af[0], bf[0]);
+    read_frag(slot, 1, af[1], bf[1]);
+    mfma4(af[0], bf[0]);
+    read_frag(slot, 2, af[0], bf[0]);
+    mfma4(af[1], bf[1]);
+    read_frag(slot, 3, af[1], bf[1]);
+    mfma4(af[0], bf[0]);
+    mfma4(af[1], bf[1]);
+    const bool last = cc.kt == p.kc_tiles - 1;        // block-uniform
+    if (last) {
+      if (!(p.ablate & 2)) epilogue(cc.mt, cc.nt);
+      else if (acc[0] == 123.456f) p.y[0] = 1.f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          Cs[(wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf) * LDC + wn * (BN / WN) + j * 32 + col] = acc[i][j][r];
-  }
-  __syncthreads();
-  if (p.vec_epi) {   // block-uniform
-    for (int e = tid; e < BM * BN / 4; e += NT) {
-      const int row = e / (BN / 4), cc = (e - row * (BN / 4)) * 4;
-      const int m = m0 + row, co = n0 + cc;
-      if (m < p.M && co < p.Cout) epilogue_store4(p, bsel, *reinterpret_cast<const f32x4*>(Cs + row * LDC + cc), m, co, DH, DW, ph, pw);
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     }
-    return;
+    // Step s + 1 (issued at the top of step s - 1) must have landed.  Issued after it: the pieces of step s + 2 and the stores of
+    // the epilogues of steps s - 1 and s, which may stay in flight (an epilogue with operand loads has already waited for everything
+    // older than them).
+    const int e_cur = last ? 1 : 0;
+    wait_vm((p.ablate & 2) ? P : P + S * (e_prev + e_cur));
+    __builtin_amdgcn_s_barrier();
+    e_prev = e_cur;
+    step(cc);
+    slot = slot == 2 ? 0 : slot + 1;
+    slot2 = slot2 == 2 ? 0 : slot2 + 1;
   }
-  for (int e = tid; e < BM * BN; e += NT) {
-    const int row = e / BN, cc = e - row * BN;
-    const int m = m0 + row, co = n0 + cc;
-    if (m < p.M && co < p.Cout) epilogue_store(p, Cs[row * LDC + cc], bsel ? bsel[co] : 0.f, m, co, DH, DW, ph, pw);
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the zero-fill pieces past the last step must not land in a successor's LDS
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1099,42 +1134,44 @@ int launch_dma2_t(const ConvParams& p, int classes, hipStream_t st) {
   CLC_LAUNCH_CHECK();
   return ((KS == 1 ? 5 : 4) << 20) | (OP << 24) | (WM << 16) | (WN << 12) | (BM << 3) | (BN >> 5);  // family 4 / 5 = conv_igemm_dma2_kernel<BM,BN,WM,WN,TR,3 / 1,OP>
 }
-template <int BM, int BN, int WM, int WN, bool TR, int KS, int OP, int NSA>
-int launch_dma3_t(const ConvParams& p, int classes, hipStream_t st) {
-  dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, classes);
-  constexpr size_t lds_ab = (size_t)(NSA * BM + 2 * BN) * BK * sizeof(float), lds_c = (size_t)BM * (BN + 4) * sizeof(float);
-  constexpr size_t lds = lds_ab > lds_c ? lds_ab : lds_c;
+// persistent 1x1 kernel: eligibility + launch; returns 0 when the layer does not qualify (the caller falls through to the tiled kernels)
+int launch_p1x1(const ConvParams& p, int classes, hipStream_t st) {
+  if (!clc_tuning[CLC_TUNE_P1X1] || classes != 1 || p.ks != 1 || p.stride != 1 || p.shuffle || p.group_rows || p.xs) return 0;
+  if (p.M % 128 || p.Cout % 64 || p.kc_tiles < 2 || !(p.in_op == CLC_IN_NONE || p.in_op == CLC_IN_SQUARE)) return 0;
+  const int tiles_m = p.M / 128, tiles_n = p.Cout / 64;
+  {   // 32-bit byte offsets into every epilogue tensor
+    int ldmax = p.ldy;
+    if (p.y_pre && p.ldp > ldmax) ldmax = p.ldp;
+    if (p.res && p.ldr > ldmax) ldmax = p.ldr;
+    if (p.res_gate && p.ldg > ldmax) ldmax = p.ldg;
+    if (p.mul && p.ldm > ldmax) ldmax = p.ldm;
+    if (p.out_gate && p.ldog > ldmax) ldmax = p.ldog;
+    if ((size_t)p.M * (size_t)ldmax * 4 >= (1ull << 31)) return 0;
+  }
+  if (tiles_m < 512) return 0;   // (a workgroup needs several M-tiles to pipeline across: 64x64 maps at batch 8 measured slower)
+  const size_t lds = (size_t)3 * (128 + 64) * BK * sizeof(float) + (size_t)p.Cout * sizeof(float);
+  if (lds > 80 * 1024) return 0;
+  const int grid = tiles_m < 512 ? tiles_m : 512;   // two resident workgroups per CU
   static PerDeviceOnce attr_once;
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma3_kernel<BM, BN, WM, WN, TR, KS, OP, NSA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_p1x1_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_p1x1_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   }
-  ConvParams q = p;
-  const int xm = clc_tuning[CLC_TUNE_XCD_MAP];
-  q.xcd_map = grid.y > 1 && grid.x % 8 == 0 && (xm == 2 || (xm == 1 && KS == 1));
-  hipLaunchKernelGGL((conv_igemm_dma3_kernel<BM, BN, WM, WN, TR, KS, OP, NSA>), grid, dim3(64 * WM * WN), lds, st, q);
+  if (p.in_op == CLC_IN_SQUARE) hipLaunchKernelGGL((conv_igemm_p1x1_kernel<1>), dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n);
+  else hipLaunchKernelGGL((conv_igemm_p1x1_kernel<0>), dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n);
   CLC_LAUNCH_CHECK();
-  // family 6 / 7 = conv_igemm_dma3_kernel<BM,BN,WM,WN,TR,3 / 1,OP,NSA>; bit 26 set = NSA 3
-  return ((KS == 1 ? 7 : 6) << 20) | (OP << 24) | ((NSA == 3 ? 1 : 0) << 26) | (WM << 16) | (WN << 12) | (BM << 3) | (BN >> 5);
-}
-// CLC_TUNE_RING (key 10), bit field: 1 = 1x1 layers on the "early" form, 2 = 3x3 layers on the A-ring form, 4 = 1x1 layers on the
-// A-ring form (wins over bit 1), 8 = 3x3 layers on the "early" form
-template <int BM, int BN, int WM, int WN, bool TR, int KS, int OP>
-int launch_dma23_t(const ConvParams& p, int classes, hipStream_t st) {
-  const int ring = clc_tuning[CLC_TUNE_RING];
-  if (KS == 1 ? (ring & 4) : (ring & 2)) return launch_dma3_t<BM, BN, WM, WN, TR, KS, OP, 3>(p, classes, st);
-  if (KS == 1 ? (ring & 1) : (ring & 8)) return launch_dma3_t<BM, BN, WM, WN, TR, KS, OP, 2>(p, classes, st);
-  return launch_dma2_t<BM, BN, WM, WN, TR, KS, OP>(p, classes, st);
+  return (8 << 20) | ((p.in_op == CLC_IN_SQUARE ? 1 : 0) << 24) | (4 << 16) | (2 << 12) | (128 << 3) | (64 >> 5);   // family 8 = conv_igemm_p1x1_kernel<OP>
 }
 template <int BM, int BN, int WM, int WN>
 int launch(const ConvParams& p, int classes, hipStream_t st) {
   static const int use_dma = getenv("CLC_DMA") ? atoi(getenv("CLC_DMA")) : 1;   // CLC_DMA=0: register staging everywhere (A/B knob)
   static const int dma_small = getenv("CLC_DMA_SMALL") ? atoi(getenv("CLC_DMA_SMALL")) : 1;
   if (use_dma && p.in_op == CLC_IN_SQUARE && p.xs == nullptr && p.ks == 1 && p.stride == 1 && (BM >= 128 || dma_small) && clc_tuning[CLC_TUNE_DMA_LOOP] == 2)
-    return p.transposed ? launch_dma23_t<BM, BN, WM, WN, true, 1, 1>(p, classes, st) : launch_dma23_t<BM, BN, WM, WN, false, 1, 1>(p, classes, st);
+    return p.transposed ? launch_dma2_t<BM, BN, WM, WN, true, 1, 1>(p, classes, st) : launch_dma2_t<BM, BN, WM, WN, false, 1, 1>(p, classes, st);
   if (use_dma && p.in_op == CLC_IN_NONE && p.xs == nullptr && (BM >= 128 || dma_small) && clc_tuning[CLC_TUNE_DMA_LOOP] == 2)
     return p.ks == 1 && p.stride == 1
-               ? (p.transposed ? launch_dma23_t<BM, BN, WM, WN, true, 1, 0>(p, classes, st) : launch_dma23_t<BM, BN, WM, WN, false, 1, 0>(p, classes, st))
-               : (p.transposed ? launch_dma23_t<BM, BN, WM, WN, true, 3, 0>(p, classes, st) : launch_dma23_t<BM, BN, WM, WN, false, 3, 0>(p, classes, st));
+               ? (p.transposed ? launch_dma2_t<BM, BN, WM, WN, true, 1>(p, classes, st) : launch_dma2_t<BM, BN, WM, WN, false, 1>(p, classes, st))
+               : (p.transposed ? launch_dma2_t<BM, BN, WM, WN, true, 3>(p, classes, st) : launch_dma2_t<BM, BN, WM, WN, false, 3>(p, classes, st));
   if (use_dma && p.in_op == CLC_IN_NONE && p.xs == nullptr && (BM >= 128 || dma_small))   // no input prologue -> the tiles can go straight to LDS
     return p.transposed ? launch_dma_t<BM, BN, WM, WN, true>(p, classes, st) : launch_dma_t<BM, BN, WM, WN, false>(p, classes, st);
   return p.transposed ? launch_t<BM, BN, WM, WN, true>(p, classes, st) : launch_t<BM, BN, WM, WN, false>(p, classes, st);
@@ -1301,7 +1338,7 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   p.M = d->N * d->OH * d->OW;
   if (d->transposed && d->stride == 2) { classes = 4; p.M = d->N * (d->OH / 2) * (d->OW / 2); }
   p.w2 = d->w2; p.bias2 = d->bias2; p.group_rows = 0; p.pre_deriv = d->pre_deriv;
-  p.dma_place = clc_tuning[CLC_TUNE_DMA_PLACE]; p.xcd_map = 0;
+  p.dma_place = clc_tuning[CLC_TUNE_DMA_PLACE]; p.xcd_map = 0; p.ablate = clc_tuning[CLC_TUNE_ABLATE];
   p.res_gate = d->res ? d->res_gate : nullptr; p.ldg = d->ldg; p.rg_act = d->res_gate_act; p.rg_pre = d->res_gate_pre;
   p.out_gate = d->out_gate; p.ldog = d->ldog; p.og_act = d->out_gate_act; p.og_pre = d->out_gate_pre;
   CLC_CHECK(!d->out_gate || !d->shuffle, "clc_conv2d: out_gate with shuffle");
@@ -1369,6 +1406,10 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   // 8 waves per tile (4 per SIMD at 2 workgroups/CU): measured +3..15 % over 4 waves on every large-map shape
   // (1x1 128->128 @128^2: 63 -> 73 TF); the summation order per output element does not depend on the wave grid
   // (CLC_TUNE_1X1_TILE: HBM-bound 1x1 layers with few K-tiles on the narrower tile — 48 KB of LDS, three workgroups per CU)
+  if (d->ks == 1 && C > 32 && vec_ok) {   // persistent pipelined kernel (CLC_TUNE_P1X1), where the layer qualifies
+    const int v = launch_p1x1(p, classes, st);
+    if (v) return v;
+  }
   if (clc_tuning[CLC_TUNE_1X1_TILE] && d->ks == 1 && p.kc_tiles <= clc_tuning[CLC_TUNE_1X1_TILE] && C > 32) return launch<128, 64, 4, 2>(p, classes, st);
   if (C % 128 == 0 || C >= 384) return launch<128, 128, 4, 2>(p, classes, st);
   if (C > 32) return launch<128, 64, 4, 2>(p, classes, st);

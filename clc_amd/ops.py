@@ -63,8 +63,14 @@ class _DeviceState:
 _STATES = {}
 
 
+_HAS_GPU = []
+
+
 def _S() -> _DeviceState:
-    dev = torch.cuda.current_device()
+    if not _HAS_GPU:
+        _HAS_GPU.append(torch.cuda.is_available())
+    # (no GPU: the multi-process CPU tests drive TrainEngine's step structure with plain-torch stand-ins — one idle state, key -1)
+    dev = torch.cuda.current_device() if _HAS_GPU[0] else -1
     st = _STATES.get(dev)
     if st is None:
         st = _STATES.setdefault(dev, _DeviceState())   # (setdefault: two replica threads may arrive here together)
