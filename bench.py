@@ -114,9 +114,16 @@ def parity_and_codec(dev):
     p.update(force=True)
     x, r = synthetic_image(1, 256, 256, 100, smooth=True), [synthetic_image(1, 256, 256, 101, smooth=True)]
     xd, rd = x.to(dev), [r[0].to(dev)]
+    import clc_amd
+
     with torch.no_grad():
         a = o(x, r)
         b = p(xd, rd)
+        clc_amd.set_precision("bf16")   # the opt-in reduced-precision mode, for the `reduced_precision` object
+        try:
+            b16 = p(xd, rd)
+        finally:
+            clc_amd.set_precision("f32")
     bpp_o = compute_bpp(a)
     bpp_p = compute_bpp({"x_hat": b["x_hat"].cpu(), "likelihoods": {k: v.cpu() for k, v in b["likelihoods"].items()}})
     psnr = lambda t: -10 * math.log10(torch.mean((t.double().cpu() - x.double()) ** 2).item())
@@ -180,7 +187,9 @@ def parity_and_codec(dev):
              "note": "gpu_*: model.compress()/decompress() (reference surface, eager launches, batch 1, 256x256); gpu_engine_*: clc_amd.codec.CodecEngine "
                      "(hipGraph-captured segments, batch 8, per-image streams coded on 8 host threads), wall time / 8; CPU: oracle transforms + "
                      "pure-Python rANS (the stand-in for CompressAI's coder), one pass"}
-    return parity, codec
+    bpp_16 = compute_bpp({"x_hat": b16["x_hat"].cpu(), "likelihoods": {k: v.cpu() for k, v in b16["likelihoods"].items()}})
+    reduced = {"dbpp": abs(bpp_o - bpp_16), "dpsnr_db": abs(psnr(a["x_hat"]) - psnr(b16["x_hat"]))}
+    return parity, codec, reduced
 
 
 def _kernel_name(L, r):
@@ -403,6 +412,56 @@ def roofline_leg(engine, x, refs):
             "per_kernel": table}
 
 
+def reduced_precision_leg(args, dev, x, refs):
+    """the opt-in bf16-in / f32-accumulate MFMA mode (clc_amd.set_precision("bf16"): the 3x3 convolutions, data and
+    filter gradients of the analysis / synthesis transforms and the reference encoder; everything on the 16x16 latents, the
+    likelihoods, the codec and the optimizer stay f32).  NEVER the headline `value` (narrower arithmetic than the reference's fp32):
+    the same training step timed in that mode, and its gradient error against the f32 mode on one batch."""
+    import torch
+
+    import clc_amd
+    from clc_amd import models
+    from clc_amd.recipe import apply_weight_recipe
+    from clc_amd.train import TrainEngine
+
+    model = models.CLC(N=64, num_ref_frames=args.n_refs)
+    apply_weight_recipe(model, 0)
+    model = model.to(dev).train()
+    eng = TrainEngine(model, lmbda=args.lmbda, lr=1e-4, aux_lr=1e-3, clip_max_norm=1.0, use_graph=not args.no_graph, precision="bf16")
+    for _ in range(max(1, args.warmup)):
+        out = eng.step(x, refs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = eng.step(x, refs)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {"value": args.batch * args.steps / dt, "unit": "images/sec", "ms_per_step": dt / args.steps * 1e3, "dtype": "bf16 operands, f32 accumulate (MFMA "
+           "v_mfma_f32_32x32x16_bf16) in the large-map 3x3 conv / dgrad / wgrad kernels; f32 everywhere else", "final_loss": float(out["loss"].item())}
+    del eng, model
+    # gradient error of the mode: one eval-mode (deterministic rounding) step at batch 2, bf16 vs f32, same weights and inputs
+    xb, rb = x[:2], ([r[:2] for r in refs] if refs is not None else None)
+    grads = {}
+    for mode in ("f32", "bf16"):
+        m = models.CLC(N=64, num_ref_frames=args.n_refs)
+        apply_weight_recipe(m, 0)
+        m = m.to(dev)
+        e = TrainEngine(m, lmbda=args.lmbda, use_graph=False, train_mode=False)
+        clc_amd.set_precision(mode)
+        try:
+            e._discover(xb, rb)
+            e._fwd_bwd(xb, rb)
+        finally:
+            clc_amd.set_precision("f32")
+        torch.cuda.synchronize()
+        grads[mode] = {n: q.grad.clone() for n, q in m.named_parameters() if q.grad is not None}
+        del e, m
+    errs = sorted(((grads["bf16"][n] - g).abs().max().item() / g.abs().max().item()) for n, g in grads["f32"].items() if g.abs().max().item() > 1e-12)
+    res["grad_rel_err"] = {"max": errs[-1], "median": errs[len(errs) // 2], "p99": errs[int(len(errs) * 0.99)],
+                           "definition": "per parameter tensor: max |g_bf16 - g_f32| / max |g_f32|, one eval-mode step at batch 2"}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -417,6 +476,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=0, help="CPU-baseline batch (default: the GPU batch, BASELINE.md §3)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-reduced", action="store_true", help="skip the reduced-precision (bf16 MFMA) leg")
     args = ap.parse_args()
 
     import torch
@@ -501,8 +561,14 @@ def main():
         if rank == 0 and world == 1:
             result["roofline"]["transforms"] = transforms_leg(model, x, refs)
     if rank == 0:
+        reduced_parity = None
         if world == 1 and not args.no_parity:
-            result["parity"], result["codec"] = parity_and_codec(dev)
+            result["parity"], result["codec"], reduced_parity = parity_and_codec(dev)
+        if world == 1 and not args.no_reduced:
+            result["reduced_precision"] = reduced_precision_leg(args, dev, x, refs)
+            if reduced_parity:
+                result["reduced_precision"].update(reduced_parity)
+            result["reduced_precision"]["vs_f32_value"] = result["reduced_precision"]["value"] / result["value"]
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.n_refs, args.cpu_sample_batch or args.batch, args.size)
         print(json.dumps(result), flush=True)

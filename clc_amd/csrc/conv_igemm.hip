@@ -41,6 +41,14 @@ constexpr int LD = 36;   // LDS row stride (floats)
 constexpr unsigned kOOB = 0x80000000u;  // >= num_records of every SRD -> load returns 0
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// 8 f32 -> 8 bf16 (round to nearest even: v_cvt_pk_bf16_f32), the operand format of v_mfma_f32_32x32x16_bf16
+__device__ __forceinline__ bf16x8 pack_bf16(f32x4 lo, f32x4 hi) {
+  bf16x8 r;
+  r[0] = (__bf16)lo[0]; r[1] = (__bf16)lo[1]; r[2] = (__bf16)lo[2]; r[3] = (__bf16)lo[3];
+  r[4] = (__bf16)hi[0]; r[5] = (__bf16)hi[1]; r[6] = (__bf16)hi[2]; r[7] = (__bf16)hi[3];
+  return r;
+}
 
 struct ConvParams {
   const float* x; const float* w; const float* bias; float* y;
@@ -522,7 +530,11 @@ void conv_igemm_dma_kernel(const ConvParams p) {
 //     did not change that).
 // KS = 1: the 1x1 / linear instantiation (one tap: no tap grid, no validity mask; its own symbol, so profiles tell the HBM-bound
 // 1x1 layers from the MFMA-bound 3x3 ones); KS = 3: everything else.
-template <int BM, int BN, int WM, int WN, bool TR, int KS, int OP = 0>
+// BF = true: the opt-in REDUCED-PRECISION mode (the reference's --use-mixed-precision branch, train_CLC.py:143-174):
+// the same f32 tiles in LDS, but two fragment groups (2 x 4 consecutive k per lane) are rounded to bf16 and contracted by ONE
+// v_mfma_f32_32x32x16_bf16 (f32 accumulate) instead of eight f32 MFMAs — 1/16 of the matrix-pipe time; A and B use the same
+// lane -> k assignment, so the contraction is over the same 16 k.  Other bits than the f32 kernels by design.
+template <int BM, int BN, int WM, int WN, bool TR, int KS, int OP = 0, bool BF = false>
 __global__ __launch_bounds__(64 * WM * WN, (64 * WM * WN) >= 512 ? 4 : ((64 * WM * WN) >= 256 ? 2 : 4))
 void conv_igemm_dma2_kernel(const ConvParams p) {
   constexpr int NT = 64 * WM * WN;
@@ -672,7 +684,35 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][ss], b[j][ss], acc[i][j], 0, 0, 0);
   };
+  auto mfma_pair_bf16 = [&](const f32x4 (&a0)[TM], const f32x4 (&b0)[TN], const f32x4 (&a1)[TM], const f32x4 (&b1)[TN]) {
+    if (p.ablate & 1) { asm volatile("" ::"v"(a0[0]), "v"(b0[0]), "v"(a1[0]), "v"(b1[0])); return; }
+    bf16x8 pa[TM], pb[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) pa[i] = pack_bf16(a0[i], a1[i]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) pb[j] = pack_bf16(b0[j], b1[j]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i], pb[j], acc[i][j], 0, 0, 0);
+  };
   read_frag(0, 0, af[0], bf[0]);
+  if constexpr (BF) {
+    for (int it = 0; it < total; ++it) {
+      const int buf = it & 1;
+      advance();
+      set_fetch(it + 1 < total);
+      dma_a(buf ^ 1); dma_b(buf ^ 1);
+      read_frag(buf, 1, af[1], bf[1]);
+      mfma_pair_bf16(af[0], bf[0], af[1], bf[1]);
+      read_frag(buf, 2, af[0], bf[0]);
+      read_frag(buf, 3, af[1], bf[1]);
+      mfma_pair_bf16(af[0], bf[0], af[1], bf[1]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      read_frag(buf ^ 1, 0, af[0], bf[0]);
+    }
+  } else
   for (int it = 0; it < total; ++it) {
     const int buf = it & 1;
     advance();
@@ -1118,21 +1158,21 @@ int launch_dma_t(const ConvParams& p, int classes, hipStream_t st) {
   CLC_LAUNCH_CHECK();
   return (2 << 20) | (WM << 16) | (WN << 12) | (BM << 3) | (BN >> 5);  // family 2 = conv_igemm_dma_kernel<BM,BN,WM,WN>
 }
-template <int BM, int BN, int WM, int WN, bool TR, int KS, int OP = 0>
+template <int BM, int BN, int WM, int WN, bool TR, int KS, int OP = 0, bool BF = false>
 int launch_dma2_t(const ConvParams& p, int classes, hipStream_t st) {
   dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, classes);
   constexpr size_t lds_ab = (size_t)2 * (BM + BN) * BK * sizeof(float), lds_c = (size_t)BM * (BN + 4) * sizeof(float);
   constexpr size_t lds = lds_ab > lds_c ? lds_ab : lds_c;
   static PerDeviceOnce attr_once;
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma2_kernel<BM, BN, WM, WN, TR, KS, OP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma2_kernel<BM, BN, WM, WN, TR, KS, OP, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   ConvParams q = p;
   const int xm = clc_tuning[CLC_TUNE_XCD_MAP];
   q.xcd_map = grid.y > 1 && grid.x % 8 == 0 && (xm == 2 || (xm == 1 && KS == 1));
-  hipLaunchKernelGGL((conv_igemm_dma2_kernel<BM, BN, WM, WN, TR, KS, OP>), grid, dim3(64 * WM * WN), lds, st, q);
+  hipLaunchKernelGGL((conv_igemm_dma2_kernel<BM, BN, WM, WN, TR, KS, OP, BF>), grid, dim3(64 * WM * WN), lds, st, q);
   CLC_LAUNCH_CHECK();
-  return ((KS == 1 ? 5 : 4) << 20) | (OP << 24) | (WM << 16) | (WN << 12) | (BM << 3) | (BN >> 5);  // family 4 / 5 = conv_igemm_dma2_kernel<BM,BN,WM,WN,TR,3 / 1,OP>
+  return ((KS == 1 ? 5 : 4) << 20) | (OP << 24) | ((BF ? 1 : 0) << 26) | (WM << 16) | (WN << 12) | (BM << 3) | (BN >> 5);  // family 4 / 5 = conv_igemm_dma2_kernel<BM,BN,WM,WN,TR,3 / 1,OP>
 }
 // persistent 1x1 kernel: eligibility + launch; returns 0 when the layer does not qualify (the caller falls through to the tiled kernels)
 int launch_p1x1(const ConvParams& p, int classes, hipStream_t st) {
@@ -1171,7 +1211,9 @@ int launch(const ConvParams& p, int classes, hipStream_t st) {
   if (use_dma && p.in_op == CLC_IN_NONE && p.xs == nullptr && (BM >= 128 || dma_small) && clc_tuning[CLC_TUNE_DMA_LOOP] == 2)
     return p.ks == 1 && p.stride == 1
                ? (p.transposed ? launch_dma2_t<BM, BN, WM, WN, true, 1>(p, classes, st) : launch_dma2_t<BM, BN, WM, WN, false, 1>(p, classes, st))
-               : (p.transposed ? launch_dma2_t<BM, BN, WM, WN, true, 3>(p, classes, st) : launch_dma2_t<BM, BN, WM, WN, false, 3>(p, classes, st));
+               : (clc_tuning[CLC_TUNE_BF16]   // reduced-precision mode: the 3x3 layers of the LDS-tiled family (maps larger than 16x16 = the transforms)
+                      ? (p.transposed ? launch_dma2_t<BM, BN, WM, WN, true, 3, 0, true>(p, classes, st) : launch_dma2_t<BM, BN, WM, WN, false, 3, 0, true>(p, classes, st))
+                      : (p.transposed ? launch_dma2_t<BM, BN, WM, WN, true, 3>(p, classes, st) : launch_dma2_t<BM, BN, WM, WN, false, 3>(p, classes, st)));
   if (use_dma && p.in_op == CLC_IN_NONE && p.xs == nullptr && (BM >= 128 || dma_small))   // no input prologue -> the tiles can go straight to LDS
     return p.transposed ? launch_dma_t<BM, BN, WM, WN, true>(p, classes, st) : launch_dma_t<BM, BN, WM, WN, false>(p, classes, st);
   return p.transposed ? launch_t<BM, BN, WM, WN, true>(p, classes, st) : launch_t<BM, BN, WM, WN, false>(p, classes, st);

@@ -57,8 +57,11 @@ struct WgradParams {
 // Where a workgroup's result goes.  mode 0: global [Cout][T][Cin] layout, plain store (a split's slab or the gradient itself);
 // mode 1: same layout, accumulate (single writer per element); mode 2: compact tile image (stream-K partial slot).
 struct OutSpec { float* w; float* b; int mode; };
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int BM, int BN, int WM, int WN, bool DMA = false>
+// BF (with DMA): reduced-precision mode (CLC_TUNE_BF16) — the f32 tiles in LDS are rounded to bf16 at fragment read and 16 k are
+// contracted by one v_mfma_f32_32x32x16_bf16 (f32 accumulate): lane half h supplies k = 16 q + 2 j + h as element j for both operands.
+template <int BM, int BN, int WM, int WN, bool DMA = false, bool BF = false>
 __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, const int by, const int k_begin, const int k_end, const OutSpec o, const int tid) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -201,6 +204,24 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
     if (use_dma && do_bias) bias_from_lds(buf);
     const float* Ab = As + (buf * BK + khalf) * BM + wm * (BM / WM) + li;
     const float* Bb = Bs + (buf * BK + khalf) * BN + wn * (BN / WN) + li;
+    if constexpr (BF) {
+#pragma unroll
+      for (int q = 0; q < BK / 16; ++q) {
+        bf16x8 pa[TM], pb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pa[i][e] = (__bf16)Ab[(16 * q + 2 * e) * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pb[j][e] = (__bf16)Bb[(16 * q + 2 * e) * BN + j * 32];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i], pb[j], acc[i][j], 0, 0, 0);
+      }
+    } else
 #pragma unroll
     for (int ss = 0; ss < BK / 2; ++ss) {
       float af[TM], bf[TN];
@@ -269,7 +290,7 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
 // the (TH+2) x (TW+2) input window are staged in LDS ONCE and the nine taps are nine shifted views of that window:
 // 64 co x (9 taps x 64 ci) outputs per workgroup, wave (wm, wn) = 32 co x 32 ci x 9 taps = 9 MFMA blocks (144 acc
 // registers), 10 ds_read_b32 per 9 MFMAs.  Same slab layout / fixed-order reduce as above.
-template <int TW, bool DMA = false>
+template <int TW, bool DMA = false, bool BF = false>
 __device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int bx, const int by, const int t_begin, const int t_end, const OutSpec o, const int tid) {
   constexpr int TH = 32 / TW, XW = TW + 2, XH = TH + 2, XP = XH * XW;
   constexpr int LTW = TW == 32 ? 5 : (TW == 16 ? 4 : 3);
@@ -381,7 +402,34 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int 
     if (more) { if (DMA) dma_tile(t_begin + kt + 1, buf ^ 1); else load_tile(t_begin + kt + 1); }
     const float* Ab = As + buf * 32 * 64 + wm * 32 + li;
     const float* Xb = Xs + buf * XP * 64 + wn * 32 + li;
-    if (DMA) {
+    if (DMA && BF) {   // reduced-precision mode: 16 k per v_mfma_f32_32x32x16_bf16, lane half h supplies k = 16 q + 2 j + h as element j
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) bias_acc[i] += *reinterpret_cast<const f32x4*>(As + buf * 32 * 64 + (tid + i * 256) * 4);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        bf16x8 pa;
+        const float* xk[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = 16 * q + 2 * e + khalf;
+          pa[e] = (__bf16)Ab[k * 64];
+          xk[e] = Xb + ((k >> LTW) * XW + (k & (TW - 1))) * 64;
+        }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          bf16x8 px[3];
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) px[kw][e] = (__bf16)xk[e][(kh * XW + kw) * 64];
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, px[kw], acc[kh * 3 + kw], 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's pieces have landed
+    } else if (DMA) {
       if (do_bias) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) bias_acc[i] += *reinterpret_cast<const f32x4*>(As + buf * 32 * 64 + (tid + i * 256) * 4);
@@ -600,7 +648,7 @@ __device__ __forceinline__ OutSpec sk_out(const SKGroup& g, const WgradParams& p
   return o;
 }
 
-template <int TW, bool DMA>
+template <int TW, bool DMA, bool BF = false>
 __global__ __launch_bounds__(256, 2)
 void conv_wgrad_taps_sk_kernel(const SKGroup g) {
   const int w = blockIdx.x;
@@ -615,7 +663,7 @@ void conv_wgrad_taps_sk_kernel(const SKGroup g) {
     const WgradParams& p = g.p[sgm.idx];
     const int gx = g.gx[sgm.idx];
     if (!first) __syncthreads();   // the previous segment's LDS tiles / bias reduction are done with
-    wgrad_taps_body<TW, DMA>(p, sgm.tile % gx, sgm.tile / gx, sgm.k0, sgm.k1, sk_out(g, p, sgm, g.T[sgm.idx], w, 64 * 9 * 64), sk_tid());
+    wgrad_taps_body<TW, DMA, BF>(p, sgm.tile % gx, sgm.tile / gx, sgm.k0, sgm.k1, sk_out(g, p, sgm, g.T[sgm.idx], w, 64 * 9 * 64), sk_tid());
     first = false;
     u += sgm.k1 - sgm.k0;
   }
@@ -624,7 +672,7 @@ void conv_wgrad_taps_sk_kernel(const SKGroup g) {
 // resident workgroups per CU the register / LDS budget of each tile shape allows (= the split-K kernels' occupancy)
 constexpr int sk_wg_per_cu(int bm, int bn) { return bm * bn >= 128 * 128 ? 2 : (bm * bn >= 128 * 64 ? 3 : 5); }
 
-template <int BM, int BN, int WM, int WN, bool DMA>
+template <int BM, int BN, int WM, int WN, bool DMA, bool BF = false>
 __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 128 * 128 ? 2 : (BM * BN >= 128 * 64 ? 4 : 6)))
 void conv_wgrad_sk_kernel(const SKGroup g) {
   const int w = blockIdx.x;
@@ -640,7 +688,7 @@ void conv_wgrad_sk_kernel(const SKGroup g) {
     const int gx = g.gx[sgm.idx];
     if (!first) __syncthreads();
     const int ke = sgm.k1 * BK;
-    wgrad_body<BM, BN, WM, WN, DMA>(p, sgm.tile % gx, sgm.tile / gx, sgm.k0 * BK, ke < p.K ? ke : p.K, sk_out(g, p, sgm, g.T[sgm.idx], w, BM * BN), sk_tid());
+    wgrad_body<BM, BN, WM, WN, DMA, BF>(p, sgm.tile % gx, sgm.tile / gx, sgm.k0 * BK, ke < p.K ? ke : p.K, sk_out(g, p, sgm, g.T[sgm.idx], w, BM * BN), sk_tid());
     first = false;
     u += sgm.k1 - sgm.k0;
   }
@@ -1105,17 +1153,20 @@ bool sk_collect(const Pending* pend, int n, SKGroup& g, float* region, int slot_
 
 // problems whose operands need no arithmetic on the way into LDS (no fused activation derivative on dy, no squared input): LDS-DMA staging
 inline bool dma_ok(const Pending& e) { return clc_tuning[CLC_TUNE_WGRAD_DMA] && e.d->dys == nullptr && e.d->in_op == CLC_IN_NONE; }
+// reduced-precision mode (CLC_TUNE_BF16): the LDS-DMA-staged problems of maps larger than 16x16 (= the analysis / synthesis transforms and
+// the reference encoder; the entropy-parameter nets on the 16x16 latents stay f32)
+inline bool bf_ok(const Pending& e) { return clc_tuning[CLC_TUNE_BF16] && dma_ok(e) && (long)e.d->OH * e.d->OW > 256; }
 
-template <int BM, int BN, bool DMA>
+template <int BM, int BN, bool DMA, bool BF = false>
 int launch_variant_sk(const Pending* pend, int n, float* region, hipStream_t st) {
   static thread_local SKGroup g;   // (host staging of the kernel argument; launches are issued by one host thread per process)
   constexpr int slot = (int)sk_slot_floats(BM * BN, BM);
-  if (!sk_collect(pend, n, g, region, slot, kCUs * sk_wg_per_cu(BM, BN), 16, [](const Pending& e) { return !e.pl.taps && e.pl.bm == BM && e.pl.bn == BN && dma_ok(e) == DMA; },
+  if (!sk_collect(pend, n, g, region, slot, kCUs * sk_wg_per_cu(BM, BN), 16, [](const Pending& e) { return !e.pl.taps && e.pl.bm == BM && e.pl.bn == BN && dma_ok(e) == DMA && bf_ok(e) == BF; },
                   [](const Pending& e, int& gx, int& gy, int& T) {
                     gx = e.pl.nci * e.d->ks * e.d->ks; gy = (e.d->Cout + BM - 1) / BM; T = (e.p.K + BK - 1) / BK;
                   })) return 0;
   const size_t lds = (size_t)2 * BK * (BM + BN) * sizeof(float);
-  hipLaunchKernelGGL((conv_wgrad_sk_kernel<BM, BN, 2, 2, DMA>), dim3(g.G), dim3(256), lds, st, g);
+  hipLaunchKernelGGL((conv_wgrad_sk_kernel<BM, BN, 2, 2, DMA, BF>), dim3(g.G), dim3(256), lds, st, g);
   CLC_LAUNCH_CHECK();
   if (g.G > 1) {
     hipLaunchKernelGGL((wgrad_sk_fixup_kernel<BM, BN, 1>), dim3((BM * BN + BM + 255) / 256, kFixY), dim3(256), 0, st, g);
@@ -1124,19 +1175,19 @@ int launch_variant_sk(const Pending* pend, int n, float* region, hipStream_t st)
   return 0;
 }
 
-template <int TW, bool DMA>
+template <int TW, bool DMA, bool BF = false>
 int launch_taps_sk(const Pending* pend, int n, float* region, hipStream_t st) {
   static thread_local SKGroup g;
   constexpr int slot = (int)sk_slot_floats(64 * 9 * 64, 64);
-  if (!sk_collect(pend, n, g, region, slot, kCUs * 2, 4, [](const Pending& e) { return e.pl.taps == TW && dma_ok(e) == DMA; },
+  if (!sk_collect(pend, n, g, region, slot, kCUs * 2, 4, [](const Pending& e) { return e.pl.taps == TW && dma_ok(e) == DMA && bf_ok(e) == BF; },
                   [](const Pending& e, int& gx, int& gy, int& T) { gx = e.pl.nci; gy = (e.d->Cout + 63) / 64; T = e.p.K >> 5; })) return 0;
   constexpr int XP = (32 / TW + 2) * (TW + 2);
   const size_t lds = (size_t)2 * (32 * 64 + XP * 64) * sizeof(float);
   static PerDeviceOnce attr_once;
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_taps_sk_kernel<TW, DMA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_taps_sk_kernel<TW, DMA, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  hipLaunchKernelGGL((conv_wgrad_taps_sk_kernel<TW, DMA>), dim3(g.G), dim3(256), lds, st, g);
+  hipLaunchKernelGGL((conv_wgrad_taps_sk_kernel<TW, DMA, BF>), dim3(g.G), dim3(256), lds, st, g);
   CLC_LAUNCH_CHECK();
   if (g.G > 1) {
     hipLaunchKernelGGL((wgrad_sk_fixup_kernel<64, 64, 9>), dim3((64 * 9 * 64 + 64 + 255) / 256, kFixY), dim3(256), 0, st, g);
@@ -1174,24 +1225,31 @@ int flush_sk(Pending* pend, int& n, float* ws, hipStream_t st) {
   int rc;
   float* r = ws;
   if ((rc = launch_variant_sk<128, 128, true>(pend, n, r, st)) < 0) return rc;    // (the two launches of a family share its region: stream order)
+  if ((rc = launch_variant_sk<128, 128, true, true>(pend, n, r, st)) < 0) return rc;    // (reduced-precision mode: bf16 MFMA)
   if ((rc = launch_variant_sk<128, 128, false>(pend, n, r, st)) < 0) return rc;
   r += kSKRegion[0] + kSKPlanFloats;
   if ((rc = launch_variant_sk<128, 64, true>(pend, n, r, st)) < 0) return rc;    // (the two launches of a family share its region: stream order)
+  if ((rc = launch_variant_sk<128, 64, true, true>(pend, n, r, st)) < 0) return rc;    // (reduced-precision mode: bf16 MFMA)
   if ((rc = launch_variant_sk<128, 64, false>(pend, n, r, st)) < 0) return rc;
   r += kSKRegion[1] + kSKPlanFloats;
   if ((rc = launch_variant_sk<64, 128, true>(pend, n, r, st)) < 0) return rc;    // (the two launches of a family share its region: stream order)
+  if ((rc = launch_variant_sk<64, 128, true, true>(pend, n, r, st)) < 0) return rc;    // (reduced-precision mode: bf16 MFMA)
   if ((rc = launch_variant_sk<64, 128, false>(pend, n, r, st)) < 0) return rc;
   r += kSKRegion[2] + kSKPlanFloats;
   if ((rc = launch_variant_sk<64, 64, true>(pend, n, r, st)) < 0) return rc;    // (the two launches of a family share its region: stream order)
+  if ((rc = launch_variant_sk<64, 64, true, true>(pend, n, r, st)) < 0) return rc;    // (reduced-precision mode: bf16 MFMA)
   if ((rc = launch_variant_sk<64, 64, false>(pend, n, r, st)) < 0) return rc;
   r += kSKRegion[3] + kSKPlanFloats;
   if ((rc = launch_taps_sk<32, true>(pend, n, r, st)) < 0) return rc;
+  if ((rc = launch_taps_sk<32, true, true>(pend, n, r, st)) < 0) return rc;
   if ((rc = launch_taps_sk<32, false>(pend, n, r, st)) < 0) return rc;
   r += kSKRegion[4] + kSKPlanFloats;
   if ((rc = launch_taps_sk<16, true>(pend, n, r, st)) < 0) return rc;
+  if ((rc = launch_taps_sk<16, true, true>(pend, n, r, st)) < 0) return rc;
   if ((rc = launch_taps_sk<16, false>(pend, n, r, st)) < 0) return rc;
   r += kSKRegion[5] + kSKPlanFloats;
   if ((rc = launch_taps_sk<8, true>(pend, n, r, st)) < 0) return rc;
+  if ((rc = launch_taps_sk<8, true, true>(pend, n, r, st)) < 0) return rc;
   if ((rc = launch_taps_sk<8, false>(pend, n, r, st)) < 0) return rc;
   n = 0;
   return 0;

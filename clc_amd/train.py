@@ -263,9 +263,14 @@ class TrainEngine:
 
     def __init__(self, model: nn.Module, lmbda: float, loss_type: str = "mse", lr: float = 1e-4, aux_lr: float = 1e-3,
                  clip_max_norm: float = 1.0, use_graph: bool = True, with_optimizer: bool = True, train_mode: bool = True, side_stream: bool = True,
-                 criterion=None, optimizer_factory=None):
+                 criterion=None, optimizer_factory=None, precision: Optional[str] = None):
         """criterion / optimizer_factory: replaceable parts (defaults: the reference's RD loss and the fused HIP AdamW) — the
-        multi-process CPU test drives the step structure with plain-torch stand-ins."""
+        multi-process CPU test drives the step structure with plain-torch stand-ins.
+        precision: None (leave the process-wide setting alone), "f32" or "bf16" — clc_amd.set_precision() is applied around every step
+        of this engine (the captured hipGraph keeps the kernels it was captured with)."""
+        if precision not in (None, "f32", "bf16"):
+            raise ValueError("precision must be None, 'f32' or 'bf16'")
+        self.precision = precision
         self.model, self.criterion = model, (criterion or RateDistortionLoss(lmbda, loss_type))
         self._make_opt = optimizer_factory or (lambda params, lr, max_norm: FusedAdamW(params, lr=lr, max_norm=max_norm))
         self.lr, self.aux_lr, self.clip = lr, aux_lr, clip_max_norm
@@ -390,6 +395,17 @@ class TrainEngine:
         return (tuple(x.shape), None if refs is None else tuple(tuple(r.shape) for r in refs))
 
     def step(self, x, refs=None):
+        if self.precision is None:
+            return self._step(x, refs)
+        from . import set_precision
+
+        old = set_precision(self.precision)
+        try:
+            return self._step(x, refs)
+        finally:
+            set_precision(old)
+
+    def _step(self, x, refs=None):
         refs = list(refs) if refs is not None else None
         if self.opt is None:
             self._discover(x, refs)

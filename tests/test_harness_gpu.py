@@ -392,3 +392,71 @@ def test_checkpoint_loading_and_rd_sweep(dev, tmp_path):
     assert abs(results[1]["bitrate"] - by_hand["avg_bpp"]) < 1e-12 and abs(results[1]["psnr"] - by_hand["avg_psnr"]) < 1e-9
     assert rows[2][1] == f"{by_hand['avg_bpp']:.4f}" and rows[2][2] == f"{by_hand['avg_psnr']:.2f}"
     assert results[0]["bitrate"] != results[1]["bitrate"]
+
+
+def test_reduced_precision_mode_bf16(dev):
+    """SURVEY 8(f)-4, second half: the opt-in reduced-precision mode (bf16-in / f32-accumulate MFMA in the convolutions of the
+    analysis / synthesis transforms and the reference encoder — the counterpart of train_CLC.py:143-174's autocast branch).
+    Stated here, at BASELINE configs[1]'s model on the seeded 256x256 image: |d bpp| and |d PSNR| of the bf16-mode forward against
+    the CPU oracle (f32), and the gradient error of one bf16-mode training step against the f32-mode step.
+    Bars for THIS mode (it is not the parity mode): |d bpp| <= 2e-2, |d PSNR| <= 0.3 dB, per-parameter gradient error <= 10 % of
+    the gradient's largest element for all but a handful of parameters; the mode must actually change the bits (it ran)."""
+    import clc_amd
+    from clc_amd import models as pm
+    from clc_amd.recipe import apply_weight_recipe, synthetic_image
+    from clc_amd.train import RateDistortionLoss, TrainEngine
+    from oracle import graph as og
+    from oracle.loss import compute_bpp
+
+    o = og.CLC(N=64, num_ref_frames=1).eval()
+    apply_weight_recipe(o, 0)
+    p = pm.CLC(N=64, num_ref_frames=1)
+    p.load_state_dict(o.state_dict())
+    p = p.to(dev).eval()
+    x, r = synthetic_image(1, 256, 256, 100, smooth=True), [synthetic_image(1, 256, 256, 101, smooth=True)]
+    xd, rd = x.to(dev), [r[0].to(dev)]
+    psnr = lambda t: -10 * math.log10(torch.mean((t.double().cpu() - x.double()) ** 2).item())
+    with torch.no_grad():
+        a = o(x, r)
+        f32 = p(xd, rd)
+        assert clc_amd.set_precision("bf16") == "f32"
+        try:
+            b16 = p(xd, rd)
+        finally:
+            clc_amd.set_precision("f32")
+        again = p(xd, rd)
+    assert clc_amd.get_precision() == "f32"
+    assert torch.equal(again["x_hat"], f32["x_hat"]), "leaving the mode must restore the f32 kernels"
+    assert not torch.equal(b16["x_hat"], f32["x_hat"]), "the bf16 mode did not change anything: did it run?"
+    cb = lambda out: compute_bpp({"x_hat": out["x_hat"].cpu(), "likelihoods": {k: v.cpu() for k, v in out["likelihoods"].items()}})
+    dbpp, dpsnr = abs(cb(b16) - compute_bpp(a)), abs(psnr(b16["x_hat"]) - psnr(a["x_hat"]))
+    print(f"bf16 mode vs oracle: |d bpp| = {dbpp:.2e}, |d PSNR| = {dpsnr:.3f} dB  (f32 mode: {abs(cb(f32) - compute_bpp(a)):.1e}, {abs(psnr(f32['x_hat']) - psnr(a['x_hat'])):.1e})")
+    assert dbpp <= 2e-2 and dpsnr <= 0.3, (dbpp, dpsnr)
+
+    # gradients of one training step, bf16 mode vs f32 mode (same weights, same batch, deterministic rounding)
+    xb = synthetic_image(2, 256, 256, 7, smooth=True).to(dev)
+    rb = [synthetic_image(2, 256, 256, 8, smooth=True).to(dev)]
+    grads = {}
+    for mode in ("f32", "bf16"):
+        m = pm.CLC(N=64, num_ref_frames=1)
+        apply_weight_recipe(m, 0)
+        m = m.to(dev)
+        eng = TrainEngine(m, lmbda=0.0067, use_graph=False, train_mode=False, precision=mode)
+        clc_amd.set_precision(mode)
+        try:
+            eng._discover(xb, rb)
+            out = eng._fwd_bwd(xb, rb)
+        finally:
+            clc_amd.set_precision("f32")
+        torch.cuda.synchronize()
+        grads[mode] = ({n: q.grad.clone() for n, q in m.named_parameters() if q.grad is not None}, out["loss"].item())
+    assert abs(grads["bf16"][1] - grads["f32"][1]) <= 2e-2 * abs(grads["f32"][1])
+    errs = []
+    for n, g in grads["f32"][0].items():
+        d = g.abs().max().item()
+        if d > 1e-12:
+            errs.append(((grads["bf16"][0][n] - g).abs().max().item() / d, n))
+    errs.sort(reverse=True)
+    worst, med = errs[0][0], errs[len(errs) // 2][0]
+    print(f"bf16 vs f32 gradients: worst {worst:.3f} ({errs[0][1]}), median {med:.2e}, > 10 %: {sum(e > 0.1 for e, _ in errs)} of {len(errs)}")
+    assert med < 2e-2 and sum(e > 0.1 for e, _ in errs) <= len(errs) // 50, errs[:10]
