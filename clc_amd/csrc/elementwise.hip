@@ -405,6 +405,50 @@ __global__ void scaled_diff_kernel(const float* __restrict__ a, const float* __r
 
 }  // namespace
 
+
+// ---- pooling (the reference-retrieval feature extractor, /root/reference/dataloader_ref_cluster.py:41-44, dataloader_CLC.py:250-256) ----
+// nn.MaxPool2d(ks, stride, pad) on a pixel-major tensor: one thread per (output pixel, 4 channels); padding = -inf
+__global__ void maxpool2d_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int H, int W, int C, int ks, int stride, int pad,
+                                 int OH, int OW, long total) {
+  const int c4n = C >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const long pix = i / c4n;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), n = (int)(pix / ((long)OW * OH));
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int kh = 0; kh < ks; ++kh) {
+      const int iy = oy * stride - pad + kh;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int kw = 0; kw < ks; ++kw) {
+        const int ix = ox * stride - pad + kw;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)(n * H + iy) * W + ix) * ldx + c);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[q] = fmaxf(m[q], v[q]);
+      }
+    }
+    *reinterpret_cast<f32x4*>(y + (size_t)pix * ldy + c) = m;
+  }
+}
+// F.adaptive_avg_pool2d / F.adaptive_max_pool2d to L x L: bin (i, j) covers rows floor(i H / L) .. ceil((i+1) H / L) - 1 (PyTorch's rule);
+// out [N][C][L][L] (NCHW order, as the reference flattens it: h.view(N, -1)); the average sums its bin in row-major order
+__global__ void adaptive_pool_kernel(const float* __restrict__ x, int ldx, float* __restrict__ out, int H, int W, int C, int L, int is_max, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long r = i / C;
+    const int j = (int)(r % L), bi = (int)((r / L) % L), n = (int)(r / ((long)L * L));
+    const int y0 = (bi * H) / L, y1 = ((bi + 1) * H + L - 1) / L, x0 = (j * W) / L, x1 = ((j + 1) * W + L - 1) / L;
+    float acc = is_max ? -INFINITY : 0.f;
+    for (int yy = y0; yy < y1; ++yy)
+      for (int xx = x0; xx < x1; ++xx) {
+        const float v = x[((size_t)(n * H + yy) * W + xx) * ldx + c];
+        acc = is_max ? fmaxf(acc, v) : acc + v;
+      }
+    if (!is_max) acc = acc / (float)((y1 - y0) * (x1 - x0));
+    out[(((size_t)n * C + c) * L + bi) * L + j] = acc;
+  }
+}
+
 #define ST ((hipStream_t)stream)
 
 extern "C" int clc_log2_sum_partials(const float* x, int ld, long rows, int C, float* partials, int n_partials, clc_stream_t stream) {
@@ -685,6 +729,22 @@ extern "C" int clc_sum_partials(const float* partials, int n, float scale, float
 extern "C" int clc_sqdiff_partials(const float* a, const float* b, long n, float* partials, int n_partials, clc_stream_t stream) {
   CLC_CHECK(a && b && partials && n > 0 && n_partials > 0 && n_partials <= kMaxBlocks, "clc_sqdiff_partials: bad args");
   hipLaunchKernelGGL(sqdiff_partials_kernel, dim3(n_partials), dim3(256), 0, ST, a, b, n, partials);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int clc_maxpool2d(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int ks, int stride, int pad, int OH, int OW, clc_stream_t stream) {
+  CLC_CHECK(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y), "clc_maxpool2d: bad args (C, ld multiples of 4)");
+  CLC_CHECK(ks > 0 && stride > 0 && pad >= 0 && 2 * pad <= ks && OH == (H + 2 * pad - ks) / stride + 1 && OW == (W + 2 * pad - ks) / stride + 1, "clc_maxpool2d: output dims");
+  const long total = (long)N * OH * OW * (C / 4);
+  hipLaunchKernelGGL(maxpool2d_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ST, x, ldx, y, ldy, H, W, C, ks, stride, pad, OH, OW, total);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int clc_adaptive_pool2d(const float* x, int ldx, float* out, int N, int H, int W, int C, int L, int is_max, clc_stream_t stream) {
+  CLC_CHECK(x && out && N > 0 && H > 0 && W > 0 && C > 0 && L > 0 && L <= H && L <= W && ldx >= C, "clc_adaptive_pool2d: bad args");
+  const long total = (long)N * L * L * C;
+  hipLaunchKernelGGL(adaptive_pool_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ST, x, ldx, out, H, W, C, L, is_max, total);
   CLC_LAUNCH_CHECK();
   return 0;
 }

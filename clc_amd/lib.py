@@ -129,6 +129,8 @@ SIGNATURES = {
     "clc_ssim_scale_fwd": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, _f, fp, fp, _sz, fp]),
     "clc_ssim_scale_bwd": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, _sz, fp]),
     "clc_avgpool2": (_i, [fp, _i, fp, _i, _i, _i, _i, fp]),
+    "clc_maxpool2d": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, fp]),
+    "clc_adaptive_pool2d": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, _i, fp]),
     "clc_optim_chunk_elems": (_i, []),
     "clc_grad_sqnorm_partials": (_i, [fp, fp, _i, fp, fp]),
     "clc_adamw_step": (_i, [fp, fp, _i, fp, _f, fp, _d, _d, _f, _f, fp, fp]),

@@ -104,7 +104,30 @@ class ReferenceIndex:
         _, idx = self.kneighbors(q_features, n_refs)
         return [[self.feature_to_key[int(j)] for j in row] for row in idx.cpu()]
 
-    def query_images(self, images: Sequence, n_refs: Optional[int] = None):
+    def query_images(self, images, n_refs: Optional[int] = None, rotated: bool = False):
+        """Reference frames for a whole BATCH of query images in one pass: features (the extractor: e.g. clc_amd.features.ResNet50Features
+        [+ PCAProjection]) and exact k-nearest-neighbour search, where the reference runs one ResNet50 forward and one ball-tree query per
+        sample inside __getitem__ (dataloader_ref_cluster.py:149-180).
+        images: [N, 3, H, W] normalised tensor (or a sequence the extractor accepts one by one).
+        rotated: dataloader_CLC.py:186-200's variant — a second query with the image rotated by 90 degrees, neighbours of both merged as
+        np.unique(concatenate)[:n_refs] (sorted by INDEX, as the reference does)."""
         if self.extractor is None:
-            raise ValueError("no feature extractor was given (the reference's pretrained ResNet50 weights are not reachable here)")
-        return self.query(torch.stack([torch.as_tensor(self.extractor(im)) for im in images]), n_refs)
+            raise ValueError("no feature extractor was given: pass extractor=clc_amd.features.ResNet50Features() (load torchvision's "
+                             "resnet50 state_dict into it; the pretrained file is not reachable from this build)")
+        k = int(n_refs or self.n_refs)
+
+        def feats(x):
+            if torch.is_tensor(x) and x.dim() == 4:
+                return torch.as_tensor(self.extractor(x.to(self.device)))
+            return torch.stack([torch.as_tensor(self.extractor(im)) for im in x])
+
+        _, idx = self.kneighbors(feats(images), k)
+        if not rotated:
+            return [[self.feature_to_key[int(j)] for j in row] for row in idx.cpu()]
+        rot = torch.rot90(images, 1, dims=(2, 3)) if torch.is_tensor(images) else [torch.rot90(torch.as_tensor(im), 1, dims=(-2, -1)) for im in images]
+        _, idx2 = self.kneighbors(feats(rot), k)
+        out = []
+        for a, b in zip(idx.cpu().numpy(), idx2.cpu().numpy()):
+            merged = np.unique(np.concatenate([a, b]))[:k]
+            out.append([self.feature_to_key[int(j)] for j in merged])
+        return out

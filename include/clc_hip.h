@@ -382,6 +382,15 @@ long clc_rans_decoder_decode(clc_rans_decoder* d, const int32_t* indexes, long n
 void clc_rans_decoder_destroy(clc_rans_decoder* d);
 int clc_pmf_to_quantized_cdf(const float* pmf, int n, int precision, int32_t* cdf_out /* n+1 */);  /* HOST */
 
+/* ---- reference-retrieval feature extractor: the pooling layers of torchvision's ResNet50 as the reference uses it ----
+ * clc_maxpool2d        nn.MaxPool2d(ks, stride, pad) of resnet50.maxpool (/root/reference/dataloader_ref_cluster.py:41-44, dataloader_CLC.py:275),
+ *                      pixel-major in / out, C and the leading dimensions multiples of 4.
+ * clc_adaptive_pool2d  F.adaptive_avg_pool2d(x, (1, 1)) (resnet50.avgpool) and the spatial-pyramid levels
+ *                      F.adaptive_max_pool2d(x, (L, L)), L = 1, 2, 4 (/root/reference/dataloader_CLC.py:250-256, 282-286); out = [N][C][L][L]
+ *                      floats in NCHW order (the order h.view(N, -1) flattens). */
+int clc_maxpool2d(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int ks, int stride, int pad, int OH, int OW, clc_stream_t stream);
+int clc_adaptive_pool2d(const float* x, int ldx, float* out, int N, int H, int W, int C, int L, int is_max, clc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
