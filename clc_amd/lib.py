@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libclc_hip.so")
+LIB_PATH = os.environ.get("CLC_LIB_PATH") or os.path.join(_HERE, "libclc_hip.so")   # (CLC_LIB_PATH: A/B of two builds on one GPU box)
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU, ACT_HALFTANH, ACT_SIGMOID, ACT_SAVED_DERIV = 0, 1, 2, 3, 4, 5, 6
 IN_NONE, IN_SQUARE = 0, 1

@@ -1,4 +1,5 @@
 #!/bin/bash
+set -u -o pipefail
 # A/B of CLC_TUNING settings on the step rate:  bash tools/gpu_ab.sh "9:0" "9:1" ...   (each setting measured twice, interleaved)
 mkdir -p gpurun_out
 for rep in 1 2; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+set -u -o pipefail
 # the other BASELINE configs' step rates (not the headline line): configs[2] = n_refs 3 @ 256^2 bs8; configs[4]'s shape = 512^2 bs4 n_refs 3
 mkdir -p gpurun_out
 for cfg in "--n-refs 3" "--n-refs 3 --size 512 --batch 4" "--n-refs 1 --size 512 --batch 4" "--no-graph"; do

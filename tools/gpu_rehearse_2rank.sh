@@ -1,4 +1,5 @@
 #!/bin/bash
+set -u -o pipefail
 mkdir -p gpurun_out
 # 2-rank rehearsal of the multi-GPU step structure on ONE device (gloo exchange): both ranks must finish, report 2 ranks, and
 # (same seed-per-rank data) end with finite losses.  (The gloo exchange of the 282 MB gradient arena through the host takes seconds per step: 3 steps.)

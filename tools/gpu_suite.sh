@@ -1,4 +1,5 @@
 #!/bin/bash
+set -u -o pipefail
 # One GPU-box visit: the -m gpu parity suite, then (unless a step was killed) the headline bench and the conv micro-benchmarks.
 # usage: tools/gpu_suite.sh <tag> [pytest-args...]
 tag=${1:-run}; shift

@@ -1,4 +1,5 @@
 #!/bin/bash
+set -u -o pipefail
 # PMC passes over the conv micro-benchmark (one shape): wave-cycle breakdown, MFMA busy, clock, LDS conflicts.
 # usage (GPU box): bash tools/pmc_conv.sh <shape-name> <outdir>
 set -e

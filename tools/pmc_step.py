@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel clock and MFMA utilisation of one hipGraph-replayed training step from a rocprofv3 PMC pass:
-    rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d DIR -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline
+    rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d DIR -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-parity --no-reduced
     python tools/pmc_step.py DIR/.../pmc_counter_collection.csv [OUT.md]
 clock        = GRBM_GUI_ACTIVE / 8 XCDs / duration          (MI355X_MICROARCH.md "DVFS give-back": reads high below ~0.3 ms)
 MFMA busy %  = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)   (fraction of the kernel's cycles its matrix pipes were busy)
