@@ -70,6 +70,7 @@ struct ConvParams {
   const float* out_gate; int ldog, og_act, og_pre;   // whole result *= act'(out_gate)
   int xcd_map;                 // conv_igemm_dma2_kernel: workgroups that share a pixel tile run back to back on ONE XCD (see the kernel)
   int dma_place;               // conv_igemm_dma2_kernel: 1 = next tile's DMA pieces at the top of the iteration, 0 = between the MFMA groups
+  int reg_epi;                 // conv_igemm_dma2_kernel: per-wave register epilogue (epilogue_regs) instead of the C tile through LDS
   int ablate;                  // CLC_TUNE_ABLATE (diagnostic builds of the timing only, results are WRONG): 1 = no MFMAs, 2 = no result stores, 4 = no operand DMA
 };
 
@@ -230,6 +231,130 @@ __device__ __forceinline__ void epilogue_store4(const ConvParams& p, const float
   const Epi4 o = epilogue_math4(p, bv, acc, rr, rg, mv, og);
   if (p.y_pre) *reinterpret_cast<f32x4*>(p.y_pre + pix * p.ldp + co) = o.pre;
   *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + co) = o.y;
+}
+
+// Per-WAVE epilogue of one 32 x 32 accumulator block straight from the registers: lane (col = lane & 31, h = lane >> 5) holds rows
+// (r&3) + 8 (r>>2) + 4 h, r = 0..15.  Same arithmetic per element as epilogue_store; organised in whole-block phases (one uniform
+// branch per phase instead of one per element), addresses = one 32-bit lane offset per tensor + a scalar row offset (SRD buffer
+// accesses, 16 dword stores of two 128-B row pieces each), the activation chosen once per block.  Rows are output pixels row0 + ...
+// (no PixelShuffle / stride-2 data-gradient pixel mapping: the callers check), every tensor addressable with 32-bit byte offsets.
+struct RegEpi {
+  __amdgpu_buffer_rsrc_t y_r, pre_r, res_r, rg_r, mul_r, og_r;
+  bool has_rg, has_mul;
+};
+__device__ __forceinline__ RegEpi make_reg_epi(const ConvParams& p) {
+  auto srd = [](const float* ptr) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, 0x7FFFFFFF, 0x00020000); };
+  RegEpi e;
+  e.has_rg = p.res && p.res_gate;
+  e.has_mul = p.norm != CLC_NORM_NONE;
+  e.y_r = srd(p.y); e.pre_r = srd(p.y_pre ? p.y_pre : p.y); e.res_r = srd(p.res ? p.res : p.y);
+  e.rg_r = srd(e.has_rg ? p.res_gate : p.y); e.mul_r = srd(e.has_mul ? p.mul : p.y); e.og_r = srd(p.out_gate ? p.out_gate : p.y);
+  return e;
+}
+#define CLC_ROWIDX(r) (((r) & 3) + 8 * ((r) >> 2))
+__device__ __forceinline__ void epilogue_regs(const ConvParams& p, const RegEpi& e, const f32x16& acc, float bv, unsigned row0 /* incl. 4 h */, int co) {
+  auto ld32 = [](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); };
+  auto st32 = [](float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0); };
+  const bool has_rg = e.has_rg, has_mul = e.has_mul;
+  float v[16], rt[16], tq[16];
+  if (p.res) {   // the residual operand first: its latency runs under the bias / address arithmetic
+    const unsigned o = (row0 * (unsigned)p.ldr + (unsigned)co) * 4u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rt[r] = ld32(e.res_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldr) * 4u);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = acc[r] + bv;
+  if (p.res) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rt[r] = p.res_scale * rt[r];
+    if (has_rg) {
+      const unsigned o = (row0 * (unsigned)p.ldg + (unsigned)co) * 4u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tq[r] = ld32(e.rg_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldg) * 4u);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rt[r] *= act_deriv(tq[r], p.rg_act, p.rg_pre);
+    }
+    if (p.res_first) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] += rt[r];
+    }
+  }
+  bool act_done = false;
+  if (p.y_pre) {
+    const unsigned o = (row0 * (unsigned)p.ldp + (unsigned)co) * 4u;
+    if (p.pre_deriv && p.act == CLC_ACT_GELU && !has_mul) {
+      // fc1 of the Swin MLPs: gelu'(v) is stored for the backward pass and gelu(v) is the result — one evaluation of the
+      // erf / exp parts for both (the same expressions gelu_f / gelu_grad_f evaluate)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float cdf, pdf;
+        gelu_parts(v[r], cdf, pdf);
+        st32(cdf + v[r] * pdf, e.pre_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldp) * 4u);
+        v[r] = v[r] * cdf;
+      }
+      act_done = true;
+    } else if (p.pre_deriv) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st32(act_deriv(v[r], p.act, 1), e.pre_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldp) * 4u);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st32(v[r], e.pre_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldp) * 4u);
+    }
+  }
+  if (has_mul) {
+    const unsigned o = (row0 * (unsigned)p.ldm + (unsigned)co) * 4u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tq[r] = ld32(e.mul_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldm) * 4u);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      v[r] = (p.norm == CLC_NORM_GDN) ? tq[r] * rsqrtf(v[r]) : ((p.norm == CLC_NORM_IGDN) ? tq[r] * sqrtf(v[r]) : 2.f * (tq[r] * v[r]));
+  }
+  switch (act_done ? CLC_ACT_NONE : p.act) {   // (the same functions apply_act dispatches to)
+    case CLC_ACT_LRELU:
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.01f * v[r];
+      break;
+    case CLC_ACT_RELU:
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+      break;
+    case CLC_ACT_GELU:
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = gelu_f(v[r]);
+      break;
+    case CLC_ACT_NONE: break;
+    default:
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = apply_act(v[r], p.act);
+  }
+  if (p.res && !p.res_first) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] += rt[r];
+  }
+  if (p.out_gate) {
+    const unsigned o = (row0 * (unsigned)p.ldog + (unsigned)co) * 4u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tq[r] = ld32(e.og_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldog) * 4u);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] *= act_deriv(tq[r], p.og_act, p.og_pre);
+  }
+  {
+    const unsigned o = (row0 * (unsigned)p.ldy + (unsigned)co) * 4u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st32(v[r], e.y_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldy) * 4u);
+  }
+}
+#undef CLC_ROWIDX
+// host side: may this launch use epilogue_regs?  (32-bit byte offsets into every epilogue tensor, whole tiles, plain pixel rows)
+static bool reg_epi_ok(const ConvParams& p, int BM, int BN) {
+  if (!p.vec_epi || p.shuffle || (p.transposed && p.stride == 2) || p.M % BM || p.Cout % BN) return false;
+  int ldmax = p.ldy;
+  if (p.y_pre && p.ldp > ldmax) ldmax = p.ldp;
+  if (p.res && p.ldr > ldmax) ldmax = p.ldr;
+  if (p.res_gate && p.ldg > ldmax) ldmax = p.ldg;
+  if (p.mul && p.ldm > ldmax) ldmax = p.ldm;
+  if (p.out_gate && p.ldog > ldmax) ldmax = p.ldog;
+  return (size_t)p.M * (size_t)ldmax * 4 < (1ull << 31);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -735,10 +860,21 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
     read_frag(buf ^ 1, 0, af[0], bf[0]);                // (after the last tile: a harmless read of the zero-filled buffer)
   }
 
+  if (p.ablate & 2) { if (acc[0][0][0] == 123.456f) p.y[0] = 1.f; return; }
+  if (p.reg_epi) {   // block-uniform (host: reg_epi_ok): every wave stores its own 32 x 32 blocks, no C tile in LDS, no barrier
+    const RegEpi re = make_reg_epi(p);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int co = n0 + wn * (BN / WN) + j * 32 + lr;
+        epilogue_regs(p, re, acc[i][j], bsel ? bsel[co] : 0.f, (unsigned)(m0 + wm * (BM / WM) + i * 32 + 4 * hh), co);
+      }
+    return;
+  }
   constexpr int LDC = BN + 4;
   float* Cs = smem;   // [BM][LDC]
   __syncthreads();    // every wave's trailing fragment read is done before the tile is overwritten
-  if (p.ablate & 2) { if (acc[0][0][0] == 123.456f) p.y[0] = 1.f; return; }
   {
     const int col = lane & 31, rhalf = 4 * (lane >> 5);
 #pragma unroll
@@ -862,111 +998,14 @@ void conv_igemm_p1x1_kernel(const ConvParams p, int tiles_m, int tiles_n) {
     for (int ss = 0; ss < 4; ++ss) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ss], b[ss], acc, 0, 0, 0);
   };
 
-  // per-wave epilogue of one 32 x 32 block straight from the accumulator: lane (col, h) holds rows (r&3) + 8 (r>>2) + 4 h.
-  // Same arithmetic per element as epilogue_store; organised in whole-block phases (one uniform branch per phase instead of one per
-  // element), addresses = one 32-bit lane offset per tensor and tile + a scalar row offset (SRD buffer accesses), the activation
-  // chosen once per block.
-  const bool has_rg = p.res && p.res_gate, has_mul = p.norm != CLC_NORM_NONE;
+  // per-wave epilogue straight from the accumulator registers (epilogue_regs)
+  const RegEpi re = make_reg_epi(p);
   const int S = p.y_pre ? 32 : 16;   // store instructions of one epilogue
-  auto srd = [](const float* ptr) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, 0x7FFFFFFF, 0x00020000); };
-  const __amdgpu_buffer_rsrc_t y_r = srd(p.y), pre_r = srd(p.y_pre ? p.y_pre : p.y), res_r = srd(p.res ? p.res : p.y),
-                               rg_r = srd(has_rg ? p.res_gate : p.y), mul_r = srd(has_mul ? p.mul : p.y), og_r = srd(p.out_gate ? p.out_gate : p.y);
-  auto ld32 = [](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); };
-  auto st32 = [](float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0); };
-#define CLC_ROWIDX(r) (((r) & 3) + 8 * ((r) >> 2))
   auto epilogue = [&](int mt, int nt) {
     const int co = nt * BN + wn * 32 + lr;
-    const float bv = bias_s[co];
-    const unsigned row0 = (unsigned)(mt * BM + wm * 32 + 4 * hh);
-    float v[16], rt[16], tq[16];
-    if (p.res) {   // the residual operand first: its latency runs under the bias / address arithmetic
-      const unsigned o = (row0 * (unsigned)p.ldr + (unsigned)co) * 4u;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) rt[r] = ld32(res_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldr) * 4u);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = acc[r] + bv;
-    if (p.res) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) rt[r] = p.res_scale * rt[r];
-      if (has_rg) {
-        const unsigned o = (row0 * (unsigned)p.ldg + (unsigned)co) * 4u;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tq[r] = ld32(rg_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldg) * 4u);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rt[r] *= act_deriv(tq[r], p.rg_act, p.rg_pre);
-      }
-      if (p.res_first) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] += rt[r];
-      }
-    }
-    bool act_done = false;
-    if (p.y_pre) {
-      const unsigned o = (row0 * (unsigned)p.ldp + (unsigned)co) * 4u;
-      if (p.pre_deriv && p.act == CLC_ACT_GELU && !has_mul) {
-        // fc1 of the Swin MLPs: gelu'(v) is stored for the backward pass and gelu(v) is the result — one evaluation of the
-        // erf / exp parts for both (the same expressions gelu_f / gelu_grad_f evaluate)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float cdf, pdf;
-          gelu_parts(v[r], cdf, pdf);
-          st32(cdf + v[r] * pdf, pre_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldp) * 4u);
-          v[r] = v[r] * cdf;
-        }
-        act_done = true;
-      } else if (p.pre_deriv) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st32(act_deriv(v[r], p.act, 1), pre_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldp) * 4u);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st32(v[r], pre_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldp) * 4u);
-      }
-    }
-    if (has_mul) {
-      const unsigned o = (row0 * (unsigned)p.ldm + (unsigned)co) * 4u;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tq[r] = ld32(mul_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldm) * 4u);
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        v[r] = (p.norm == CLC_NORM_GDN) ? tq[r] * rsqrtf(v[r]) : ((p.norm == CLC_NORM_IGDN) ? tq[r] * sqrtf(v[r]) : 2.f * (tq[r] * v[r]));
-    }
-    switch (act_done ? CLC_ACT_NONE : p.act) {   // (the same functions apply_act dispatches to)
-      case CLC_ACT_LRELU:
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.01f * v[r];
-        break;
-      case CLC_ACT_RELU:
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-        break;
-      case CLC_ACT_GELU:
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = gelu_f(v[r]);
-        break;
-      case CLC_ACT_NONE: break;
-      default:
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = apply_act(v[r], p.act);
-    }
-    if (p.res && !p.res_first) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] += rt[r];
-    }
-    if (p.out_gate) {
-      const unsigned o = (row0 * (unsigned)p.ldog + (unsigned)co) * 4u;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tq[r] = ld32(og_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldog) * 4u);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] *= act_deriv(tq[r], p.og_act, p.og_pre);
-    }
-    {
-      const unsigned o = (row0 * (unsigned)p.ldy + (unsigned)co) * 4u;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st32(v[r], y_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldy) * 4u);
-    }
+    epilogue_regs(p, re, acc, bias_s[co], (unsigned)(mt * BM + wm * 32 + 4 * hh), co);
   };
-#undef CLC_ROWIDX
+
 
   Cur cf{(int)blockIdx.x, 0, 0, 0}, cc = cf;
   dma(0, cf); step(cf);
@@ -1170,6 +1209,7 @@ int launch_dma2_t(const ConvParams& p, int classes, hipStream_t st) {
   ConvParams q = p;
   const int xm = clc_tuning[CLC_TUNE_XCD_MAP];
   q.xcd_map = grid.y > 1 && grid.x % 8 == 0 && (xm == 2 || (xm == 1 && KS == 1));
+  q.reg_epi = clc_tuning[CLC_TUNE_REG_EPI] && reg_epi_ok(p, BM, BN);
   hipLaunchKernelGGL((conv_igemm_dma2_kernel<BM, BN, WM, WN, TR, KS, OP, BF>), grid, dim3(64 * WM * WN), lds, st, q);
   CLC_LAUNCH_CHECK();
   return ((KS == 1 ? 5 : 4) << 20) | (OP << 24) | ((BF ? 1 : 0) << 26) | (WM << 16) | (WN << 12) | (BM << 3) | (BN >> 5);  // family 4 / 5 = conv_igemm_dma2_kernel<BM,BN,WM,WN,TR,3 / 1,OP>
@@ -1179,16 +1219,8 @@ int launch_p1x1(const ConvParams& p, int classes, hipStream_t st) {
   if (!clc_tuning[CLC_TUNE_P1X1] || classes != 1 || p.ks != 1 || p.stride != 1 || p.shuffle || p.group_rows || p.xs) return 0;
   if (p.M % 128 || p.Cout % 64 || p.kc_tiles < 2 || !(p.in_op == CLC_IN_NONE || p.in_op == CLC_IN_SQUARE)) return 0;
   const int tiles_m = p.M / 128, tiles_n = p.Cout / 64;
-  {   // 32-bit byte offsets into every epilogue tensor
-    int ldmax = p.ldy;
-    if (p.y_pre && p.ldp > ldmax) ldmax = p.ldp;
-    if (p.res && p.ldr > ldmax) ldmax = p.ldr;
-    if (p.res_gate && p.ldg > ldmax) ldmax = p.ldg;
-    if (p.mul && p.ldm > ldmax) ldmax = p.ldm;
-    if (p.out_gate && p.ldog > ldmax) ldmax = p.ldog;
-    if ((size_t)p.M * (size_t)ldmax * 4 >= (1ull << 31)) return 0;
-  }
-  if (tiles_m < 512) return 0;   // (a workgroup needs several M-tiles to pipeline across: 64x64 maps at batch 8 measured slower)
+  if (!reg_epi_ok(p, 128, 64)) return 0;
+  if (tiles_m < (clc_tuning[CLC_TUNE_P1X1] >= 2 ? 256 : 512)) return 0;   // (a workgroup needs several M-tiles to pipeline across)
   const size_t lds = (size_t)3 * (128 + 64) * BK * sizeof(float) + (size_t)p.Cout * sizeof(float);
   if (lds > 80 * 1024) return 0;
   const int grid = tiles_m < 512 ? tiles_m : 512;   // two resident workgroups per CU
@@ -1380,7 +1412,7 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   p.M = d->N * d->OH * d->OW;
   if (d->transposed && d->stride == 2) { classes = 4; p.M = d->N * (d->OH / 2) * (d->OW / 2); }
   p.w2 = d->w2; p.bias2 = d->bias2; p.group_rows = 0; p.pre_deriv = d->pre_deriv;
-  p.dma_place = clc_tuning[CLC_TUNE_DMA_PLACE]; p.xcd_map = 0; p.ablate = clc_tuning[CLC_TUNE_ABLATE];
+  p.dma_place = clc_tuning[CLC_TUNE_DMA_PLACE]; p.xcd_map = 0; p.ablate = clc_tuning[CLC_TUNE_ABLATE]; p.reg_epi = 0;
   p.res_gate = d->res ? d->res_gate : nullptr; p.ldg = d->ldg; p.rg_act = d->res_gate_act; p.rg_pre = d->res_gate_pre;
   p.out_gate = d->out_gate; p.ldog = d->ldog; p.og_act = d->out_gate_act; p.og_pre = d->out_gate_pre;
   CLC_CHECK(!d->out_gate || !d->shuffle, "clc_conv2d: out_gate with shuffle");
