@@ -1,0 +1,25 @@
+"""Multi-GPU readiness without multi-GPU hardware (SURVEY 8(e), configs[3]): two ranks on ONE MI355X over gloo, real kernels, the real
+three-graph step (A1 | exchange | A2 | exchange | B), identical shards -> bit-identical to the 1-rank run of the same structure.
+The ranks are CHILD processes (torch.distributed.run), launched before they touch the GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_on_one_device_reproduce_the_single_rank_run(dev, tmp_path):
+    ref = str(tmp_path / "ref.json")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    a = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rehearse_2rank.py"), "--single", ref, "--steps", "2"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert a.returncode == 0, a.stderr[-2000:]
+    b = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+                        os.path.join(ROOT, "tools", "rehearse_2rank.py"), "--check", ref, "--steps", "2"], capture_output=True, text=True, timeout=500, env=env, cwd=ROOT)
+    assert b.returncode == 0, (b.stdout[-1500:], b.stderr[-2500:])
+    line = next(l for l in b.stdout.splitlines() if l.startswith("REHEARSAL "))
+    rep = json.loads(line[len("REHEARSAL "):])
+    assert rep["ranks"] == 2 and rep["bit_identical_to_1rank"] and rep["ranks_agree"] and len(rep["losses_2rank"]) == 2
