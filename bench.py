@@ -205,8 +205,8 @@ def _kernel_name(L, r):
         if variant == 1:
             return "wgrad_small_kernel"
         if variant in (64908, 64916, 64932):
-            return f"conv_wgrad_taps_sk_kernel<{variant - 64900}, {dma}>"
-        return f"conv_wgrad_sk_kernel<{variant // 1000}, {variant % 1000}, 2, 2, {dma}>"
+            return f"conv_wgrad_taps_sk_kernel<{variant - 64900}, {dma}, false>"   # (last argument: the bf16-MFMA instantiation of the reduced-precision mode)
+        return f"conv_wgrad_sk_kernel<{variant // 1000}, {variant % 1000}, 2, 2, {dma}, false>"
     if fam != "conv_igemm" or variant < (1 << 20):
         return fam   # conv_direct_small / single (non-deferred) wgrad calls / proxied entry points
     tr = "true" if shape.startswith("dgrad") else "false"
@@ -216,7 +216,7 @@ def _kernel_name(L, r):
         return f"conv_igemm_splitk_kernel<{bn}, {tr}, {kw}, {1 if kw == 4 or splitk_pf == 1 else 3}>"
     if f in (4, 5):   # family 5 = the 1x1 instantiation (its own symbol)
         return (f"conv_igemm_dma2_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}, {1 if f == 5 else 3}, "
-                f"{(variant >> 24) & 3}>")   # (last argument: 1 = squared operand, GDN's norm convolution)
+                f"{(variant >> 24) & 3}, {'true' if (variant >> 26) & 1 else 'false'}>")   # (..., OP: 1 = squared operand (GDN's norm convolution), BF: bf16 MFMA)
     if f == 8:        # the persistent pipelined kernel of the large-map 1x1 layers
         return f"conv_igemm_p1x1_kernel<{(variant >> 24) & 3}>"
     return f"conv_igemm{ {1: '', 2: '_dma'}[f]}_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}>"
@@ -372,14 +372,14 @@ def roofline_leg(engine, x, refs):
     t = t_replay if t_replay is not None else t_eager
     # the 1x1 / linear instantiation (..., 1>) moves ~50 FLOP per byte on 128-channel layers — under the f32 ridge once the residual and
     # saved-activation streams are counted — so its roofline is HBM; everything else is MFMA
-    hbm_bound = ((name.startswith("conv_igemm_dma2_kernel") and (name.endswith(", 1, 0>") or name.endswith(", 1, 1>"))) or name.startswith("conv_igemm_p1x1_kernel")) and nb > 0
+    hbm_bound = ((name.startswith("conv_igemm_dma2_kernel") and (", 1, 0, " in name or ", 1, 1, " in name)) or name.startswith("conv_igemm_p1x1_kernel")) and nb > 0
     achieved = (nb / t / 1e9) if hbm_bound else (f / t / 1e12)
     peak = HBM_PEAK_GBS if hbm_bound else F32_MFMA_PEAK_TFLOPS
     # HBM-side bytes per launch of that kernel from the committed PMC passes (separate `rocprofv3 --pmc FETCH_SIZE` /
     # `--pmc WRITE_SIZE` runs of this same command, gfx950 FETCH_SIZE correction applied: tools/pmc_traffic.py); null when the
     # file does not list the kernel
     traffic, traffic_source = None, None
-    for cand in ("r3_pmc_traffic.json", "r2_pmc_traffic.json"):
+    for cand in ("r3_pmc_traffic.json",):
         try:
             with open(os.path.join(ROOT, "profiles", cand)) as fh:
                 k = json.load(fh)["kernels"].get(name)

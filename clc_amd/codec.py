@@ -37,25 +37,33 @@ MAGIC = b"CLC1"
 # ------------------------------------------------------------------------------------------------ container
 
 
+KERNEL_CONFIG_TAG = 3   # bumped whenever the kernels of the context model change their summation order (the decoder must re-derive the
+                        # encoder's float means / scales bit for bit: decode with the build that encoded, or one carrying the same tag)
+
+
 def pack(strings, shape, image_hw, n_refs: int = 0, model_id: int = 0) -> bytes:
     """One image: header + z stream + y stream.
-    header (little endian): magic 'CLC1' | u8 version=1 | u8 model_id | u8 n_refs | u8 reserved | u16 H | u16 W (original image) |
-    u16 zh | u16 zw (hyper-latent shape = `shape`) | u32 len(y) | u32 len(z)."""
+    header (little endian): magic 'CLC1' | u8 version=1 | u8 model_id | u8 n_refs | u8 kernel-config tag | u16 H | u16 W (original image) |
+    u16 zh | u16 zw (hyper-latent shape = `shape`) | u32 len(y) | u32 len(z).
+    The tag records which generation of context-model kernels encoded the image: the slice loop is autoregressive through the
+    arithmetic decoder, so the decoder only stays in sync when it reproduces the encoder's means / scales bit for bit (the
+    reference has the same property across devices and library versions; it records nothing)."""
     y, z = strings[0][0], strings[1][0]
-    return MAGIC + struct.pack("<BBBBHHHHII", 1, model_id, n_refs, 0, image_hw[0], image_hw[1], int(shape[0]), int(shape[1]), len(y), len(z)) + z + y
+    return MAGIC + struct.pack("<BBBBHHHHII", 1, model_id, n_refs, KERNEL_CONFIG_TAG, image_hw[0], image_hw[1], int(shape[0]), int(shape[1]), len(y), len(z)) + z + y
 
 
 def unpack(blob: bytes):
     """-> (strings, shape, meta) as decompress() takes them."""
-    if blob[:4] != MAGIC:
-        raise ValueError("not a CLC1 container")
-    ver, model_id, n_refs, _r, H, W, zh, zw, ny, nz = struct.unpack("<BBBBHHHHII", blob[4:24])
+    if len(blob) < 24 or blob[:4] != MAGIC:
+        raise ValueError("not a CLC1 container (shorter than its 24-byte header, or wrong magic)")
+    ver, model_id, n_refs, tag, H, W, zh, zw, ny, nz = struct.unpack("<BBBBHHHHII", blob[4:24])
     if ver != 1:
         raise ValueError(f"unsupported container version {ver}")
     if len(blob) != 24 + ny + nz:
         raise ValueError("truncated / oversized container")
     z, y = blob[24:24 + nz], blob[24 + nz:24 + nz + ny]
-    return [[y], [z]], torch.Size([zh, zw]), {"image_hw": (H, W), "n_refs": n_refs, "model_id": model_id}
+    return [[y], [z]], torch.Size([zh, zw]), {"image_hw": (H, W), "n_refs": n_refs, "model_id": model_id, "kernel_config_tag": tag,
+                                              "same_kernel_config": tag in (0, KERNEL_CONFIG_TAG)}
 
 
 def write_file(path, strings, shape, image_hw, n_refs=0, model_id=0):
@@ -86,7 +94,29 @@ class CodecEngine:
         self.pool = ThreadPoolExecutor(max_workers=max(1, threads))
         self._enc = {}
         self._dec = {}
+        self.zc = int(model.entropy_bottleneck.channels)   # hyper-latent channels (192 in the reference configuration)
         model.update()   # CDF tables (no-op when present)
+
+    def close(self):
+        """Release the coder threads and the captured plans (graphs, their memory pools, pinned host buffers)."""
+        if self.pool is not None:
+            self.pool.shutdown(wait=True)
+            self.pool = None
+        self._enc.clear()
+        self._dec.clear()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ---------------------------------------------------------------- shared pieces
     def _sig(self, x, refs):
@@ -147,8 +177,8 @@ class CodecEngine:
         pl.graph, (pl.packed, pl.zshape) = self._capture(run)
         pl.run = run
         pl.host = torch.empty(pl.packed.shape, dtype=torch.int32).pin_memory()
-        pl.ny = (pl.packed.shape[1] - 192 * pl.zshape[0] * pl.zshape[1]) // 2
-        C = 192
+        pl.ny = (pl.packed.shape[1] - self.zc * pl.zshape[0] * pl.zshape[1]) // 2
+        C = self.zc
         pl.zidx = np.ascontiguousarray(np.broadcast_to(np.arange(C, dtype=np.int32).reshape(C, 1, 1), (C,) + pl.zshape)).reshape(-1)
         return pl
 
@@ -190,9 +220,9 @@ class CodecEngine:
         S = m.num_slices
         pl = _Plan()
         pl.refs = [r.clone() for r in refs] if refs is not None else None
-        pl.z_in = torch.zeros((B, 192) + tuple(zshape), dtype=torch.int32, device=dev)
+        pl.z_in = torch.zeros((B, self.zc) + tuple(zshape), dtype=torch.int32, device=dev)
         yh, yw = zshape[0] * 4, zshape[1] * 4
-        Cs = m.M // S if hasattr(m, "M") else 320 // S
+        Cs = m.M // S
         pl.rv_in = [torch.zeros((B, Cs, yh, yw), dtype=torch.int32, device=dev) for _ in range(S)]
         pl.z_host = torch.empty(pl.z_in.shape, dtype=torch.int32).pin_memory()
         pl.rv_host = [torch.empty(t.shape, dtype=torch.int32).pin_memory() for t in pl.rv_in]
@@ -259,7 +289,7 @@ class CodecEngine:
                 d.copy_(r, non_blocking=True)
         gcdf, gln, goff = m.gaussian_conditional.host_tables()
         ecdf, eln, eoff = m.entropy_bottleneck.host_tables()
-        C = 192
+        C = self.zc
         zidx = np.ascontiguousarray(np.broadcast_to(np.arange(C, dtype=np.int32).reshape(C, 1, 1), (C,) + zshape)).reshape(-1)
         zh = pl.z_host.numpy()
 

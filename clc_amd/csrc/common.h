@@ -19,6 +19,7 @@ enum { CLC_TUNE_DMA_LOOP = 0 /* 1: conv_igemm_dma_kernel, 2: conv_igemm_dma2_ker
        CLC_TUNE_XCD_MAP = 8 /* dma2 conv kernel: channel tiles of a pixel tile back to back on one XCD: 0 off, 1 = 1x1 layers, 2 = all */,
        CLC_TUNE_WGRAD_DMA = 9 /* filter-gradient tile kernels: LDS-DMA staging for problems without operand arithmetic */,
        CLC_TUNE_REG_EPI = 10 /* conv_igemm_dma2_kernel: per-wave register epilogue where the launch qualifies */,
+       CLC_TUNE_DGRAD_SPLITK = 11 /* data gradients on the 64x64 tile whose grid under-fills the chip: K split over 2-4 workgroups + finish launch */,
        CLC_TUNE_ABLATE = 12 /* diagnostic: conv_igemm_dma2_kernel without its MFMAs (1) / result stores (2) / operand DMA (4) — wrong results, timing only */,
        CLC_TUNE_P1X1 = 13 /* large-map 1x1 layers on the persistent pipelined kernel (conv_igemm_p1x1_kernel) */,
        CLC_TUNE_BF16 = 14 /* opt-in reduced-precision mode: bf16-in / f32-accumulate MFMA in the 3x3 convolutions, data- and filter-gradient kernels of maps larger than 16x16 */,

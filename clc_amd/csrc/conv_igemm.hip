@@ -70,6 +70,7 @@ struct ConvParams {
   const float* out_gate; int ldog, og_act, og_pre;   // whole result *= act'(out_gate)
   int xcd_map;                 // conv_igemm_dma2_kernel: workgroups that share a pixel tile run back to back on ONE XCD (see the kernel)
   int dma_place;               // conv_igemm_dma2_kernel: 1 = next tile's DMA pieces at the top of the iteration, 0 = between the MFMA groups
+  int ksplit; float* partial;   // conv_igemm_dma2_kernel: K range split over `ksplit` workgroups per tile (blockIdx.z = class * ksplit + split), raw partial tiles to `partial`
   int reg_epi;                 // conv_igemm_dma2_kernel: per-wave register epilogue (epilogue_regs) instead of the C tile through LDS
   int ablate;                  // CLC_TUNE_ABLATE (diagnostic builds of the timing only, results are WRONG): 1 = no MFMAs, 2 = no result stores, 4 = no operand DMA
 };
@@ -685,7 +686,8 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
     bxm = (j / (int)gridDim.y) * 8 + c;
   }
   const int m0 = bxm * BM, n0 = bym * BN;
-  const int cls = blockIdx.z, ph = cls >> 1, pw = cls & 1;
+  const int ksp = p.ksplit > 1 ? p.ksplit : 1;                // block-uniform
+  const int cls = blockIdx.z / ksp, sk = blockIdx.z - cls * ksp, ph = cls >> 1, pw = cls & 1;
   const bool half = p.transposed && p.stride == 2;
   const int DH = half ? p.OH / 2 : p.OH, DW = half ? p.OW / 2 : p.OW;
   const TapGrid tg = KS == 1 ? TapGrid{0, 0, 1, 1, 1} : make_taps(p, ph, pw);   // (KS = 1 is dispatched for stride 1 only)
@@ -740,8 +742,16 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int total = tg.nkh * tg.nkw * p.kc_tiles;
-  int tj = 0, ti = 0, kc = 0;
+  // this workgroup's K-steps: all of them, or split sk's share [it_begin, it_begin + total) of a split launch
+  const int total_all = tg.nkh * tg.nkw * p.kc_tiles;
+  const int it_begin = (int)((long)total_all * sk / ksp), total = (int)((long)total_all * (sk + 1) / ksp) - it_begin;
+  int tj, ti, kc;
+  {
+    const int tap = it_begin / p.kc_tiles;
+    kc = it_begin - tap * p.kc_tiles;
+    tj = tap / tg.nkw;
+    ti = tap - tj * tg.nkw;
+  }
   auto advance = [&]() {   // branch-free: the loop body stays ONE scheduling region
     const int kc1 = kc + 1;
     const bool w1 = kc1 == p.kc_tiles;
@@ -861,6 +871,19 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
   }
 
   if (p.ablate & 2) { if (acc[0][0][0] == 123.456f) p.y[0] = 1.f; return; }
+  if (ksp > 1) {   // raw partial tile -> scratch [class][split][M][Cout] (whole tiles: host-checked); conv_splitk_finish_kernel does the rest
+    float* dst = p.partial + ((size_t)(cls * ksp + sk) * p.M) * p.Cout;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int co = n0 + wn * (BN / WN) + j * 32 + lr;
+        const int row0 = m0 + wm * (BM / WM) + i * 32 + 4 * hh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(size_t)(row0 + (r & 3) + 8 * (r >> 2)) * p.Cout + co] = acc[i][j][r];
+      }
+    return;
+  }
   if (p.reg_epi) {   // block-uniform (host: reg_epi_ok): every wave stores its own 32 x 32 blocks, no C tile in LDS, no barrier
     const RegEpi re = make_reg_epi(p);
 #pragma unroll
@@ -1171,6 +1194,39 @@ void conv_igemm_splitk_kernel(const ConvParams p) {
   }
 }
 
+// Finish of a K-split launch: the `ksplit` partial tiles of every output element added in split order (fixed -> reproducible), then the
+// ordinary epilogue (epilogue_store4: bias, residual / gates, activation ...), one thread per 4 channels of a pixel.
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvParams p, int classes) {
+  const int c4n = p.Cout >> 2;
+  const long per_class = (long)p.M * c4n, total = per_class * classes;
+  const bool half = p.transposed && p.stride == 2;
+  const int DH = half ? p.OH / 2 : p.OH, DW = half ? p.OW / 2 : p.OW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cls = (int)(i / per_class);
+    const long r = i - (long)cls * per_class;
+    const int m = (int)(r / c4n), co = (int)(r - (long)m * c4n) * 4;
+    const float* src = p.partial + ((size_t)(cls * p.ksplit) * p.M + m) * p.Cout + co;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(src);
+    for (int s2 = 1; s2 < p.ksplit; ++s2) acc = acc + *reinterpret_cast<const f32x4*>(src + (size_t)s2 * p.M * p.Cout);
+    const int fset = p.group_rows ? min(m / p.group_rows, 3) : 0;
+    const float* bsel = fset == 0 ? p.bias : (fset == 1 ? p.bias2 : (fset == 2 ? p.bias3 : p.bias4));
+    epilogue_store4(p, bsel, acc, m, co, DH, DW, cls >> 1, cls & 1);
+  }
+}
+// how many ways clc_conv2d would split the K range of a 64x64-tile data-gradient launch (1: not at all)
+static int conv_ksplit(const ConvParams& p, int classes) {
+  if (!clc_tuning[CLC_TUNE_DGRAD_SPLITK] || !p.transposed || !p.vec_epi || p.in_op != CLC_IN_NONE || p.xs || p.shuffle) return 1;
+  if (p.M % 64 || p.Cout % 64) return 1;
+  const long wgs = (long)(p.M / 64) * (p.Cout / 64) * classes;
+  const int ksteps = (p.transposed && p.stride == 2 ? ((p.ks + 1) / 2) * ((p.ks + 1) / 2) : p.ks * p.ks) * p.kc_tiles;   // (upper bound for stride 2)
+  // (measured, r3: 512 -> 128 @ 8x32x32 123 -> 102 us, 512 -> 320 @ 8x16x16 122 -> 81 us; a 36-step layer got slower: long K ranges only)
+  if (wgs >= 384 || ksteps < 64) return 1;
+  int k = (int)((640 + wgs - 1) / wgs);
+  if (k > 4) k = 4;
+  while (k > 1 && ksteps / k < 24) --k;
+  return k;
+}
+
 template <int BM, int BN, int WM, int WN, bool TR>
 int launch_t(const ConvParams& p, int classes, hipStream_t st) {
   dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, classes);
@@ -1210,8 +1266,19 @@ int launch_dma2_t(const ConvParams& p, int classes, hipStream_t st) {
   const int xm = clc_tuning[CLC_TUNE_XCD_MAP];
   q.xcd_map = grid.y > 1 && grid.x % 8 == 0 && (xm == 2 || (xm == 1 && KS == 1));
   q.reg_epi = clc_tuning[CLC_TUNE_REG_EPI] && reg_epi_ok(p, BM, BN);
+  if (p.ksplit > 1) {   // (set by clc_conv2d for the 64x64 tile only)
+    grid.z = classes * p.ksplit;
+    q.xcd_map = 0;
+  }
   hipLaunchKernelGGL((conv_igemm_dma2_kernel<BM, BN, WM, WN, TR, KS, OP, BF>), grid, dim3(64 * WM * WN), lds, st, q);
   CLC_LAUNCH_CHECK();
+  if (p.ksplit > 1) {
+    const long total = (long)p.M * (p.Cout / 4) * classes;
+    long nb = (total + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)nb), dim3(256), 0, st, q, classes);
+    CLC_LAUNCH_CHECK();
+  }
   return ((KS == 1 ? 5 : 4) << 20) | (OP << 24) | ((BF ? 1 : 0) << 26) | (WM << 16) | (WN << 12) | (BM << 3) | (BN >> 5);  // family 4 / 5 = conv_igemm_dma2_kernel<BM,BN,WM,WN,TR,3 / 1,OP>
 }
 // persistent 1x1 kernel: eligibility + launch; returns 0 when the layer does not qualify (the caller falls through to the tiled kernels)
@@ -1363,8 +1430,18 @@ extern "C" int clc_filter_transpose_batched(const clc_transpose_entry* table_dev
   return 0;
 }
 
-extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
-  hipStream_t st = (hipStream_t)stream;
+// turns the K split on for this launch when the caller provided the scratch for it
+static void use_split(ConvParams& p, const clc_conv_desc* d, int classes) {
+  const int k = conv_ksplit(p, classes);
+  if (k > 1 && d->workspace && d->workspace_bytes >= (size_t)k * classes * p.M * p.Cout * sizeof(float) && aligned16(d->workspace) &&
+      clc_tuning[CLC_TUNE_DMA_LOOP] == 2) {
+    p.ksplit = k;
+    p.partial = (float*)d->workspace;
+  }
+}
+
+// validates a descriptor and fills the kernel parameters (shared by clc_conv2d and clc_conv2d_workspace_bytes)
+static int fill_params(const clc_conv_desc* d, ConvParams& p, int& classes) {
   CLC_CHECK(d && d->x && d->w && d->y, "clc_conv2d: null pointer");
   CLC_CHECK(d->ks == 1 || d->ks == 3, "clc_conv2d: ks must be 1 or 3 (got %d)", d->ks);
   CLC_CHECK(d->stride == 1 || d->stride == 2, "clc_conv2d: stride must be 1 or 2 (got %d)", d->stride);
@@ -1388,7 +1465,6 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   CLC_CHECK(x_bytes < (1ull << 31) && w_bytes < (1ull << 31), "clc_conv2d: tensor larger than 2 GiB");
   CLC_CHECK((size_t)d->N * d->OH * d->OW * (d->shuffle ? 4 : 1) < (1ull << 31), "clc_conv2d: too many pixels");
 
-  ConvParams p;
   p.x = d->x; p.w = d->w; p.bias = d->bias; p.y = d->y; p.mul = d->mul; p.res = d->res; p.y_pre = d->y_pre;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.ldx = d->ldx;
   p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout; p.ldy = d->ldy;
@@ -1408,11 +1484,11 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
     auto ok4 = [](const void* ptr, int ld) { return ptr == nullptr || (aligned16(ptr) && ld % 4 == 0); };
     p.vec_epi = !d->shuffle && d->Cout % 4 == 0 && ok4(d->y, d->ldy) && ok4(d->res, d->ldr) && ok4(d->mul, d->ldm) && ok4(d->y_pre, d->ldp) && ok4(d->res_gate, d->ldg) && ok4(d->out_gate, d->ldog);
   }
-  int classes = 1;
+  classes = 1;
   p.M = d->N * d->OH * d->OW;
   if (d->transposed && d->stride == 2) { classes = 4; p.M = d->N * (d->OH / 2) * (d->OW / 2); }
   p.w2 = d->w2; p.bias2 = d->bias2; p.group_rows = 0; p.pre_deriv = d->pre_deriv;
-  p.dma_place = clc_tuning[CLC_TUNE_DMA_PLACE]; p.xcd_map = 0; p.ablate = clc_tuning[CLC_TUNE_ABLATE]; p.reg_epi = 0;
+  p.dma_place = clc_tuning[CLC_TUNE_DMA_PLACE]; p.xcd_map = 0; p.ablate = clc_tuning[CLC_TUNE_ABLATE]; p.reg_epi = 0; p.ksplit = 1; p.partial = nullptr;
   p.res_gate = d->res ? d->res_gate : nullptr; p.ldg = d->ldg; p.rg_act = d->res_gate_act; p.rg_pre = d->res_gate_pre;
   p.out_gate = d->out_gate; p.ldog = d->ldog; p.og_act = d->out_gate_act; p.og_pre = d->out_gate_pre;
   CLC_CHECK(!d->out_gate || !d->shuffle, "clc_conv2d: out_gate with shuffle");
@@ -1431,6 +1507,27 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
     CLC_CHECK(!d->w3 && !d->w4, "clc_conv2d: w3 / w4 without w2");
   }
 
+  return 0;
+}
+
+extern "C" size_t clc_conv2d_workspace_bytes(const clc_conv_desc* d) {
+  if (!d || !d->transposed) return 0;
+  ConvParams p;
+  int classes = 1;
+  if (fill_params(d, p, classes) < 0) return 0;
+  const bool vec_ok = (d->Cin % 4 == 0) && (d->ldx % 4 == 0) && aligned16(d->x) && aligned16(d->w);
+  if (!vec_ok || d->Cout < 64) return 0;
+  const int img_pix = (d->transposed && d->stride == 2) ? (d->OH / 2) * (d->OW / 2) : d->OH * d->OW;
+  if (img_pix > 1024) return 0;   // (only the 64x64-tile family splits; whether THIS launch lands there is decided in clc_conv2d — an unused scratch is harmless)
+  const int k = conv_ksplit(p, classes);
+  return k > 1 ? (size_t)k * classes * p.M * p.Cout * sizeof(float) : 0;
+}
+
+extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  ConvParams p;
+  int classes = 1;
+  if (fill_params(d, p, classes) < 0) return -1;
   const bool vec_ok = (d->Cin % 4 == 0) && (d->ldx % 4 == 0) && aligned16(d->x) && aligned16(d->w);
   if (!vec_ok) {
     CLC_CHECK(!d->transposed && !d->xs, "clc_conv2d: unaligned/small-Cin path has no transposed / fused-activation mode (Cin=%d ldx=%d)", d->Cin, d->ldx);
@@ -1456,8 +1553,10 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
     static const int heavy_dgrad = getenv("CLC_HEAVY_DGRAD") ? atoi(getenv("CLC_HEAVY_DGRAD")) : 1;   // 0: A/B knob
     static const int heavy_min = getenv("CLC_HEAVY_MIN") ? atoi(getenv("CLC_HEAVY_MIN")) : 60;   // K-tiles (224-channel 3x3: 63); the 36-tile ones measured faster on split-K in the step
     if (heavy_dgrad && img_pix <= 256 && d->transposed && d->ks * d->ks * p.kc_tiles >= heavy_min && C >= 128 &&
-        (long)((p.M + 63) / 64) * ((C + 63) / 64) * classes >= 128)
+        (long)((p.M + 63) / 64) * ((C + 63) / 64) * classes >= 128) {
+      use_split(p, d, classes);
       return launch<64, 64, 2, 2>(p, classes, st);
+    }
     // 32x32 tiles: these layers are bound by how many CUs get MFMA work (f32 MFMA = 64 cycles each), not by operand
     // re-use, so the smaller tile (2x the workgroups of 32x64) wins on every 16x16 shape measured
     // ... except the slice-parameter nets with multi-MB filters (448..704 -> 224), where halving the number of N tiles
@@ -1474,7 +1573,10 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
     return launch_splitk<32>(p, classes, st);
   }
   if (img_pix <= 1024) {
-    if (C >= 64) return launch<64, 64, 2, 2>(p, classes, st);
+    if (C >= 64) {
+      use_split(p, d, classes);
+      return launch<64, 64, 2, 2>(p, classes, st);
+    }
     return launch<64, 32, 2, 1>(p, classes, st);
   }
   // 8 waves per tile (4 per SIMD at 2 workgroups/CU): measured +3..15 % over 4 waves on every large-map shape

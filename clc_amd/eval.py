@@ -122,7 +122,11 @@ def rd_sweep(make_net, checkpoints, samples, results_dir, device="cuda", use_eng
                 from .codec import CodecEngine
 
                 engine = CodecEngine(net)
-            r = evaluate(net, samples, device=device, engine=engine)
+            try:
+                r = evaluate(net, samples, device=device, engine=engine)
+            finally:
+                if engine is not None:
+                    engine.close()   # (one engine per checkpoint: its threads, graphs and pinned buffers go with it)
             results.append({"checkpoint": cp["path"], "bitrate": r["avg_bpp"], "psnr": r["avg_psnr"], "time": r["avg_time_s"]})
             w.writerow([cp["path"], f"{r['avg_bpp']:.4f}", f"{r['avg_psnr']:.2f}", f"{r['avg_time_s']:.4f}"])
             f.flush()

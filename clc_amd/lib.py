@@ -32,7 +32,8 @@ class ConvDesc(C.Structure):
                 ("w2", fp), ("bias2", fp), ("pre_deriv", C.c_int),
                 ("res_gate", fp), ("ldg", C.c_int), ("res_gate_act", C.c_int), ("res_gate_pre", C.c_int),
                 ("out_gate", fp), ("ldog", C.c_int), ("out_gate_act", C.c_int), ("out_gate_pre", C.c_int),
-                ("w3", fp), ("bias3", fp), ("w4", fp), ("bias4", fp)]
+                ("w3", fp), ("bias3", fp), ("w4", fp), ("bias4", fp),
+                ("workspace", fp), ("workspace_bytes", C.c_size_t)]
 
 
 class WgradDesc(C.Structure):
@@ -66,6 +67,7 @@ SIGNATURES = {
     "clc_version": (_i, []),
     "clc_set_tuning": (_i, [_i, _i]),
     "clc_conv2d": (_i, [C.POINTER(ConvDesc), fp]),
+    "clc_conv2d_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
     "clc_conv2d_wgrad_workspace_bytes": (_sz, [C.POINTER(WgradDesc)]),
     "clc_conv2d_wgrad": (_i, [C.POINTER(WgradDesc), fp]),
     "clc_conv2d_wgrad_batched": (_i, [C.POINTER(WgradDesc), _i, fp]),

@@ -549,6 +549,12 @@ def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_
         xs_t, xsp, *_r, ldxs = nhwc(xs)
         d.xs, d.ldxs, d.xs_act, d.xs_pre = xsp, ldxs, xs_act, int(xs_pre)
         keep.append(xs_t)
+    if transposed and H * W <= 1024:   # data gradients on small maps: scratch for the K split of under-filled grids (0 bytes: no split)
+        nws = _lib.load().clc_conv2d_workspace_bytes(C.byref(d))
+        if nws:
+            ws = torch.empty((nws + 3) // 4, device=x.device, dtype=torch.float32)
+            d.workspace, d.workspace_bytes = ws.data_ptr(), nws
+            keep.append(ws)
     if PROFILE is None:
         _lib.check(_lib.load().clc_conv2d(C.byref(d), _stream()), "clc_conv2d")
     else:

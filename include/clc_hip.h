@@ -102,9 +102,16 @@ typedef struct {
    * Swin output (CLC_run.py:235-244) — of the mean- AND the scale-parameter net are four same-shaped layers on different data: one
    * launch instead of four.  N must be a multiple of 4. */
   const float* w3; const float* bias3; const float* w4; const float* bias4;
+  /* optional scratch (clc_conv2d_workspace_bytes(d) bytes, caller-owned, 16-B aligned): lets a DATA-GRADIENT launch whose grid would
+   * leave most CUs with one 4-wave workgroup (3x3 layers on 32x32 / 16x16 maps with few output channels) split K over 2-4
+   * workgroups per tile — partial tiles to the scratch, a fixed-order finish launch adds them and applies the epilogue.  Without it
+   * (NULL) the launch is not split.  Forward launches are never split: an image's bits must not depend on the batch size. */
+  void* workspace; size_t workspace_bytes;
 } clc_conv_desc;
 
 int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream);
+/* scratch bytes with which clc_conv2d would split this launch's K range (0: it would not split) */
+size_t clc_conv2d_workspace_bytes(const clc_conv_desc* d);
 
 /* Weight gradient: dw[co,kh,kw,ci] = sum_{n,oh,ow} dy[n,oh,ow,co] * in_op(x[n,oh*s-pad+kh,ow*s-pad+kw,ci]).
  * Deterministic split-K: partial slabs in `workspace`, summed in a fixed order.

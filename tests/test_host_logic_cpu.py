@@ -143,3 +143,17 @@ def test_host_tables_follow_load_state_dict_and_update():
     # update(force) replaces the buffer objects
     c.update_scale_table(get_scale_table(), force=True)
     assert (c.host_tables()[0] == cdf_a).all()
+
+
+def test_container_header_errors_and_kernel_tag():
+    """clc_amd.codec container: a blob shorter than its header raises ValueError (not struct.error); the header records which generation
+    of context-model kernels encoded the image (the decoder must reproduce the encoder's float context bit for bit)."""
+    from clc_amd import codec
+
+    blob = codec.pack([[b"yyyy"], [b"zz"]], (4, 4), (256, 256), n_refs=1)
+    strings, shape, meta = codec.unpack(blob)
+    assert strings == [[b"yyyy"], [b"zz"]] and tuple(shape) == (4, 4) and meta["image_hw"] == (256, 256) and meta["n_refs"] == 1
+    assert meta["kernel_config_tag"] == codec.KERNEL_CONFIG_TAG and meta["same_kernel_config"]
+    for bad in (b"", b"CLC1", blob[:23], b"XXXX" + blob[4:], blob + b"!"):
+        with pytest.raises(ValueError):
+            codec.unpack(bad)

@@ -710,3 +710,41 @@ def test_activation_gate_in_consumer_dgrad(dev, kind):
         for name, got, want in zip(("dx", "dwa", "dba", "dwb", "dbb"), outs[gated][1], [r.grad for r in ref_in]):
             _close(got, want, 2e-4, f"{kind} gated={gated} {name}")
     assert torch.equal(outs[True][0], outs[False][0])
+
+
+@pytest.mark.parametrize("case", [(8, 128, 32, 32, 512, True), (8, 320, 16, 16, 512, False), (2, 128, 32, 32, 512, True)])
+def test_dgrad_k_split_matches_unsplit(dev, case):
+    """Round 3: a 3x3 data gradient whose 64x64-tile grid would leave most CUs with one workgroup (few output channels, long K) splits
+    its K range over 2-4 workgroups per tile (partials to a scratch buffer, fixed-order finish launch with the ordinary epilogue).
+    Same values as the unsplit launch up to fp32 summation order, with the epilogue operands (folded residual gradient + the producer's
+    activation-derivative gate) applied once; run-to-run bit-identical; and a torch reference of the plain transposed convolution."""
+    from clc_amd import lib as _clib
+    from clc_amd import ops
+
+    N, Cin, H, W, Cout, with_epi = case
+    g = torch.Generator().manual_seed(3)
+    dy = torch.randn(N, Cout, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).to(dev).contiguous(memory_format=torch.channels_last)
+    res = torch.randn(N, Cin, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last) if with_epi else None
+    gate = torch.randn(N, Cin, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last) if with_epi else None
+    wt = ops.filter_transpose(w, Cout, 9, Cin).view(Cin, -1)
+    L = _clib.load()
+
+    def run():
+        return ops.conv_raw(dy, wt, None, ks=3, pad=1, transposed=True, out_hw=(H, W), res=res, res_scale=0.5,
+                            out_gate=((gate, ops.ACT_LRELU, False) if with_epi else None))
+
+    old = L.clc_set_tuning(11, 0)
+    try:
+        ref = run().clone()
+        L.clc_set_tuning(11, 1)
+        got, again = run().clone(), run().clone()
+    finally:
+        L.clc_set_tuning(11, old)
+    assert torch.equal(got, again), "K-split data gradient is not reproducible"
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 2e-5 * scale
+    want = torch.nn.functional.conv_transpose2d(dy.cpu().double(), w.cpu().double(), padding=1)
+    if with_epi:
+        want = (want + 0.5 * res.cpu().double()) * torch.where(gate.cpu().double() > 0, 1.0, 0.01)
+    assert (got.cpu().double() - want).abs().max().item() <= 3e-5 * want.abs().max().item()
