@@ -264,6 +264,11 @@ class ResidualUnit(nn.Module):
             q = [tuple(m.conv[k] for m in pair) for k in range(5)]
         else:
             q = pair.conv if pair is not None else (None,) * 5
+        units = (self,) + (tuple(pair) if isinstance(pair, (tuple, list)) else ((pair,) if pair is not None else ()))
+        if ops.residual_unit_fusable(x, units):
+            # the 16x16 latent maps of the slice loop: the three layers in ONE launch, their data gradients in one more (csrc/fused_ru.hip)
+            return ops.residual_unit(x, [(m.conv[0].weight, m.conv[0].bias, m.conv[2].weight, m.conv[2].bias, m.conv[4].weight, m.conv[4].bias)
+                                         for m in units])
         f = ops.GradFold(gated=True) if x.requires_grad else None
         g0, g1 = ops.ActGate(), ops.ActGate()   # each ReLU' rides in the NEXT layer's data-gradient epilogue
         t = self.conv[0](x, act=ACT_RELU, pair=q[0], fold_in=f, gate_out=g0)

@@ -46,6 +46,13 @@ class WgradDesc(C.Structure):
                 ("dys", fp), ("lddys", C.c_int), ("dys_act", C.c_int), ("dys_pre", C.c_int)]
 
 
+class RUDesc(C.Structure):
+    _fields_ = [("x", fp), ("ldx", C.c_int), ("t1", fp), ("t2", fp), ("y", fp),
+                ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("sets", C.c_int),
+                ("w1", fp * 4), ("b1", fp * 4), ("w2", fp * 4), ("b2", fp * 4), ("w3", fp * 4), ("b3", fp * 4),
+                ("saved_y", fp), ("saved_t2", fp), ("saved_t1", fp)]
+
+
 class TransposeEntry(C.Structure):
     _fields_ = [("w", fp), ("wt", fp), ("Cout", C.c_int), ("T", C.c_int), ("Cin", C.c_int), ("tile_begin", C.c_int)]
 
@@ -131,6 +138,8 @@ SIGNATURES = {
     "clc_ssim_scale_fwd": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, _f, fp, fp, _sz, fp]),
     "clc_ssim_scale_bwd": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, _f, fp, fp, fp, _i, fp, _sz, fp]),
     "clc_avgpool2": (_i, [fp, _i, fp, _i, _i, _i, _i, fp]),
+    "clc_residual_unit_fwd": (_i, [C.POINTER(RUDesc), fp]),
+    "clc_residual_unit_dgrad": (_i, [C.POINTER(RUDesc), fp]),
     "clc_maxpool2d": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, fp]),
     "clc_adaptive_pool2d": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, _i, fp]),
     "clc_optim_chunk_elems": (_i, []),

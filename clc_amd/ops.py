@@ -866,6 +866,101 @@ def conv2d(x, w, b=None, *, stride=1, act=ACT_NONE, res=None, res_scale=1.0, shu
                          grad_slot, park_dx, gate_in, gate_out, w3, b3, w4, b4)
 
 
+FUSED_RU = int(os.environ.get("CLC_FUSED_RU", "1"))   # ResidualUnits on 16x16 maps with 128 channels: one launch forward, one for the data gradient
+
+
+def residual_unit_fusable(x, sets) -> bool:
+    return bool(FUSED_RU) and x.dim() == 4 and tuple(x.shape[1:]) == (128, 16, 16) and len(sets) in (1, 2, 4) and x.shape[0] % len(sets) == 0
+
+
+def _ru_desc(x, xp, ldx, N, H, W, Cc, outs, filters, biases):
+    d = _lib.RUDesc()
+    d.x, d.ldx = xp, ldx
+    d.t1, d.t2, d.y = (o.data_ptr() for o in outs)
+    d.N, d.H, d.W, d.C, d.sets = N, H, W, Cc, len(filters)
+    for k, (f1, f2, f3) in enumerate(filters):
+        d.w1[k], d.w2[k], d.w3[k] = f1.data_ptr(), f2.data_ptr(), f3.data_ptr()
+        if biases is not None:
+            d.b1[k], d.b2[k], d.b3[k] = (bt.data_ptr() for bt in biases[k])
+    return d
+
+
+def residual_unit_fwd_raw(x, sets):
+    """One clc_residual_unit_fwd launch.  sets: 1, 2 or 4 tuples (w1, b1, w2, b2, w3, b3) of nn.Conv2d parameters (equal parts of the
+    batch each).  Returns the two intermediate activations and the output."""
+    _require_gpu(x, "residual_unit")
+    x, xp, N, H, W, Cc, ldx = nhwc(x)
+    outs = (new_act(N, Cc // 2, H, W, x), new_act(N, Cc // 2, H, W, x), new_act(N, Cc, H, W, x))
+    filters = [tuple(to_kernel_weight(wt) for wt in (st[0], st[2], st[4])) for st in sets]
+    d = _ru_desc(x, xp, ldx, N, H, W, Cc, outs, filters, [(st[1], st[3], st[5]) for st in sets])
+    _prof_hint(2.0 * N * H * W * (Cc * (Cc // 2) * 2 + 9 * (Cc // 2) * (Cc // 2)), f"residual unit fwd {N}x{H}x{W} C{Cc} sets{len(sets)}")
+    _lib.check(_L().clc_residual_unit_fwd(C.byref(d), _stream()), "clc_residual_unit_fwd")
+    return outs
+
+
+def _wt_of(wp):
+    """[Cin][taps][Cout] image of a filter parameter: refreshed once per step by the batched transpose (clc_amd.train), else made here."""
+    wt = getattr(wp, "_clc_wt", None)
+    if wt is None:
+        ks = wp.shape[2] if wp.dim() == 4 else 1
+        wt = filter_transpose(to_kernel_weight(wp), wp.shape[0], ks * ks, wp.shape[1])
+    return wt.view(wp.shape[1], -1)
+
+
+def residual_unit_dgrad_raw(dy, y, t2, t1, sets):
+    """One clc_residual_unit_dgrad launch: (g2, g1, dx) = the pre-activation gradients of layers 2 and 1 and the unit's input gradient."""
+    dy, dp, N, H, W, Cc, ldd = nhwc(dy)
+    outs = (new_act(N, Cc // 2, H, W, dy), new_act(N, Cc // 2, H, W, dy), new_act(N, Cc, H, W, dy))
+    filters = [(_wt_of(st[4]), _wt_of(st[2]), _wt_of(st[0])) for st in sets]   # the chain runs backwards: layer 3's filter first
+    d = _ru_desc(dy, dp, ldd, N, H, W, Cc, outs, filters, None)
+    for t in (y, t2, t1):
+        assert t.is_contiguous(memory_format=CL)
+    d.saved_y, d.saved_t2, d.saved_t1 = y.data_ptr(), t2.data_ptr(), t1.data_ptr()
+    _prof_hint(2.0 * N * H * W * (Cc * (Cc // 2) * 2 + 9 * (Cc // 2) * (Cc // 2)), f"residual unit dgrad {N}x{H}x{W} C{Cc} sets{len(sets)}")
+    _lib.check(_L().clc_residual_unit_dgrad(C.byref(d), _stream()), "clc_residual_unit_dgrad")
+    return outs
+
+
+class _ResidualUnitFn(Function):
+    """y = relu(x + conv1x1(relu(conv3x3(relu(conv1x1 x))))) on the 16x16 latent maps: ONE launch forward, ONE launch for the whole data
+    gradient (csrc/fused_ru.hip) and the three layers' ordinary (grouped, deferred) filter-gradient problems.  params: per filter set
+    (w1, b1, w2, b2, w3, b3); the sets take equal parts of the batch."""
+
+    @staticmethod
+    def forward(ctx, x, nsets, *params):
+        _own(ctx)
+        sets = [params[6 * k: 6 * k + 6] for k in range(nsets)]
+        t1, t2, y = residual_unit_fwd_raw(x, sets)
+        ctx.nsets = nsets
+        ctx.save_for_backward(x, t1, t2, y, *params)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        _reown(ctx)
+        x, t1, t2, y, *params = ctx.saved_tensors
+        nsets, need = ctx.nsets, ctx.needs_input_grad
+        sets = [params[6 * k: 6 * k + 6] for k in range(nsets)]
+        g2, g1, dx = residual_unit_dgrad_raw(dy, y, t2, t1, sets)
+        per = x.shape[0] // nsets
+        grads = []
+        for k, (w1, b1, w2, b2, w3, b3) in enumerate(sets):
+            sl, nb = slice(k * per, (k + 1) * per), 2 + 6 * k
+            out = [None] * 6
+            # layer 3: its dy operand is dy . [y > 0], applied in the filter-gradient kernel's loader; layers 2 / 1 get g2 / g1 as they are
+            for j, (xin, dz, w, b, ks, fw) in enumerate(((x[sl], g1[sl], w1, b1, 1, {}), (t1[sl], g2[sl], w2, b2, 3, {}),
+                                                         (t2[sl], dy[sl], w3, b3, 1, dict(dys=y[sl], dys_act=ACT_RELU, dys_pre=False)))):
+                if need[nb + 2 * j] or need[nb + 2 * j + 1]:
+                    out[2 * j], out[2 * j + 1] = _ConvFn._wgrad(xin, dz, w, b, True, need[nb + 2 * j], need[nb + 2 * j + 1], ks, 1, ks // 2, fw)
+            grads += out
+        return (dx if need[0] else None, None, *grads)
+
+
+def residual_unit(x, units):
+    """units: 1, 2 or 4 tuples (w1, b1, w2, b2, w3, b3) — see _ResidualUnitFn."""
+    return _ResidualUnitFn.apply(x, len(units), *[t for u in units for t in u])
+
+
 def linear(x, w, b=None, *, act=ACT_NONE, res=None, w2=None, b2=None, fold_in=None, fold_out=None, out=None, gate_in=None, gate_out=None):
     """nn.Linear on channels (tokens are pixels): x [N,Cin,H,W] pixel-major, w [Cout,Cin]."""
     return _ConvFn.apply(x, w, b, res, 1, 1, act, 1.0, False, False, w2, b2, fold_in, fold_out, out, None, None, gate_in, gate_out)

@@ -389,6 +389,30 @@ long clc_rans_decoder_decode(clc_rans_decoder* d, const int32_t* indexes, long n
 void clc_rans_decoder_destroy(clc_rans_decoder* d);
 int clc_pmf_to_quantized_cdf(const float* pmf, int n, int precision, int32_t* cdf_out /* n+1 */);  /* HOST */
 
+/* ---- fused ResidualUnit (forward), round 3 ----
+ * One launch for CompressAI's AttentionBlock.ResidualUnit as SWAtten uses it (/root/reference/models/CLC_run.py:222-244):
+ *   y = relu(x + conv1x1(W3, relu(conv3x3(W2, relu(conv1x1(W1, x) + b1)) + b2)) + b3),  C -> C/2 -> C/2 -> C, on 16x16 maps, C = 128.
+ * x [N,16,16,C] pixel-major (leading dimension ldx); t1, t2 [N,16,16,C/2] and y [N,16,16,C] dense outputs — t1 / t2 are the activated
+ * outputs of the first two layers, which the ordinary gradient kernels (clc_conv2d transposed / clc_conv2d_wgrad) take as saved
+ * activations, so the backward pass of the three layers is unchanged.  sets = 1, 2 or 4 filter sets on equal parts of the batch
+ * (images [k N/sets, (k+1) N/sets) use set k), filters in clc_conv2d's layout ([Cout][kh][kw][Cin]).  A result depends on its own
+ * image only (one workgroup per 8x4-pixel tile, fixed summation order). */
+typedef struct {
+  const float* x; int ldx;
+  float* t1; float* t2; float* y;
+  int N, H, W, C, sets;
+  const float* w1[4]; const float* b1[4];
+  const float* w2[4]; const float* b2[4];
+  const float* w3[4]; const float* b3[4];
+  const float* saved_y; const float* saved_t2; const float* saved_t1;   /* clc_residual_unit_dgrad only */
+} clc_ru_desc;
+int clc_residual_unit_fwd(const clc_ru_desc* d, clc_stream_t stream);
+/* The unit's data gradient, one launch: with x = dy (leading dimension ldx), w1 / w2 / w3 = the TRANSPOSED filters of layers 3 / 2 / 1
+ * (clc_filter_transpose: [64][128], [64][9][64], [128][64]; biases unused) and the forward pass's saved_y / saved_t2 / saved_t1 (dense),
+ * writes  t1 <- g2 = d(layer-2 pre-activation),  t2 <- g1 = d(layer-1 pre-activation)  (the dy operands of those layers' filter
+ * gradients; layer 3's is dy gated by saved_y, which clc_conv2d_wgrad applies itself) and  y <- dx  (including the identity branch). */
+int clc_residual_unit_dgrad(const clc_ru_desc* d, clc_stream_t stream);
+
 /* ---- reference-retrieval feature extractor: the pooling layers of torchvision's ResNet50 as the reference uses it ----
  * clc_maxpool2d        nn.MaxPool2d(ks, stride, pad) of resnet50.maxpool (/root/reference/dataloader_ref_cluster.py:41-44, dataloader_CLC.py:275),
  *                      pixel-major in / out, C and the leading dimensions multiples of 4.

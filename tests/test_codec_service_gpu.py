@@ -18,7 +18,8 @@ def test_container_roundtrip(tmp_path):
     blob = codec.pack(strings, shape, (200, 300), n_refs=3, model_id=1)
     assert len(blob) == 24 + 20 + 12 and blob[:4] == b"CLC1"
     s2, sh2, meta = codec.unpack(blob)
-    assert s2 == strings and tuple(sh2) == (4, 6) and meta == {"image_hw": (200, 300), "n_refs": 3, "model_id": 1}
+    assert s2 == strings and tuple(sh2) == (4, 6)
+    assert meta == {"image_hw": (200, 300), "n_refs": 3, "model_id": 1, "kernel_config_tag": codec.KERNEL_CONFIG_TAG, "same_kernel_config": True}
     n = codec.write_file(tmp_path / "a.clc", strings, shape, (200, 300), 3, 1)
     assert n == len(blob) and os.path.getsize(tmp_path / "a.clc") == n
     s3, sh3, meta3 = codec.read_file(tmp_path / "a.clc")

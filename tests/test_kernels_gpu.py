@@ -748,3 +748,56 @@ def test_dgrad_k_split_matches_unsplit(dev, case):
     if with_epi:
         want = (want + 0.5 * res.cpu().double()) * torch.where(gate.cpu().double() > 0, 1.0, 0.01)
     assert (got.cpu().double() - want).abs().max().item() <= 3e-5 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("sets,n", [(1, 1), (1, 3), (2, 4), (4, 8), (4, 32)])
+def test_fused_residual_unit_matches_three_layers(dev, sets, n):
+    """clc_residual_unit_fwd / clc_residual_unit_dgrad (csrc/fused_ru.hip: 1x1 -> 3x3 -> 1x1 + identity on 16x16 maps in one launch, and the
+    whole data gradient in one more) vs torch fp32 layer by layer.  The gradient reference applies the ReLU masks of the kernel's OWN
+    activations (a pre-activation within rounding of 0 may land on either side of the kink; the forward check bounds how far)."""
+    import torch.nn.functional as F
+    from torch.nn.grad import conv2d_weight
+    from clc_amd import layers, ops
+
+    torch.manual_seed(40 + sets)
+    units = [layers.ResidualUnit(128).to(dev) for _ in range(sets)]
+    x = torch.randn(n, 128, 16, 16, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    pair = None if sets == 1 else (units[1] if sets == 2 else tuple(units[1:]))
+    assert ops.residual_unit_fusable(x, units)
+    y = units[0](x, pair=pair)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    per = n // sets
+    with torch.no_grad():
+        t1, t2, y_again = ops.residual_unit_fwd_raw(x.detach(), [(u.conv[0].weight, u.conv[0].bias, u.conv[2].weight, u.conv[2].bias,
+                                                                  u.conv[4].weight, u.conv[4].bias) for u in units])
+        assert torch.equal(y_again, y)
+        for k, u in enumerate(units):
+            sl = slice(k * per, (k + 1) * per)
+            c, xs = u.conv, x.detach()[sl]
+            r1 = F.relu(F.conv2d(xs, c[0].weight, c[0].bias))
+            r2 = F.relu(F.conv2d(r1, c[2].weight, c[2].bias, padding=1))
+            ry = F.relu(F.conv2d(r2, c[4].weight, c[4].bias) + xs)
+            for got, want in ((t1[sl], r1), (t2[sl], r2), (y[sl], ry)):
+                assert (got - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+            g3 = gy[sl] * (y[sl] > 0)
+            g2 = F.conv_transpose2d(g3, c[4].weight) * (t2[sl] > 0)
+            g1 = F.conv_transpose2d(g2, c[2].weight, padding=1) * (t1[sl] > 0)
+            dx = F.conv_transpose2d(g1, c[0].weight) + g3
+            want = (conv2d_weight(xs, c[0].weight.shape, g1), g1.sum((0, 2, 3)), conv2d_weight(t1[sl], c[2].weight.shape, g2, padding=1), g2.sum((0, 2, 3)),
+                    conv2d_weight(t2[sl], c[4].weight.shape, g3), g3.sum((0, 2, 3)))
+            assert (x.grad[sl] - dx).abs().max().item() <= 1e-4 * max(1.0, dx.abs().max().item())
+            for prm, w in zip(u.parameters(), want):
+                assert (prm.grad - w).abs().max().item() <= 2e-4 * max(1.0, w.abs().max().item()), (k, tuple(prm.shape))
+    # the unfused path gives the same result to rounding, and a result does not depend on the rest of the batch
+    old = ops.FUSED_RU
+    try:
+        ops.FUSED_RU = 0
+        with torch.no_grad():
+            yu = units[0](x.detach(), pair=pair)
+    finally:
+        ops.FUSED_RU = old
+    assert (y - yu).abs().max().item() <= 2e-5 * max(1.0, yu.abs().max().item())
+    with torch.no_grad():
+        y1 = units[0](x.detach()[:1].contiguous(memory_format=torch.channels_last))
+    assert torch.equal(y1, y[:1].detach())
