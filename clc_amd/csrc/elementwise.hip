@@ -714,6 +714,40 @@ extern "C" int clc_im2col_small(const float* x, int ldx, int N, int H, int W, in
   CLC_LAUNCH_CHECK();
   return 0;
 }
+// ---- RGB-head filters as patch-row matrices -------------------------------------------------------------------------------------
+// The stride-2 3x3 head convolution and its 1x1 skip run as 1x1 convolutions over 32-column patch rows (clc_im2col_small).  Their filter
+// matrices are the parameters re-laid: w1[o][k] = w3[o][k] for k < 9 cin (the parameter's own [o][kh][kw][c] order), zero beyond;
+// ws[o][4 cin + c] = w1x1[o][c] (the window's centre tap), zero elsewhere.  One launch builds both (was 2 x (fill + copy) per step), one
+// launch adds both gradients back into the parameters' gradient buffers (was a slice, a copy and an add per tensor).
+__global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict__ w3, const float* __restrict__ w1x1, float* __restrict__ w1,
+                                                        float* __restrict__ ws, int co, int cin) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= co * 32) return;
+  const int o = i >> 5, k = i & 31;
+  w1[i] = k < 9 * cin ? w3[o * 9 * cin + k] : 0.f;
+  ws[i] = (k >= 4 * cin && k < 5 * cin) ? w1x1[o * cin + k - 4 * cin] : 0.f;
+}
+__global__ __launch_bounds__(256) void stem_unpack_add_kernel(const float* __restrict__ dw1, const float* __restrict__ dws, float* __restrict__ g3,
+                                                              float* __restrict__ g1x1, int co, int cin) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= co * 32) return;
+  const int o = i >> 5, k = i & 31;
+  if (k < 9 * cin) g3[o * 9 * cin + k] += dw1[i];
+  if (k >= 4 * cin && k < 5 * cin) g1x1[o * cin + k - 4 * cin] += dws[i];
+}
+extern "C" int clc_stem_pack(const float* w3, const float* w1x1, float* w1, float* ws, int co, int cin, clc_stream_t stream) {
+  CLC_CHECK(w3 && w1x1 && w1 && ws && co > 0 && cin > 0 && 9 * cin <= 32, "clc_stem_pack: bad args (9 * cin must fit 32 columns)");
+  hipLaunchKernelGGL(stem_pack_kernel, dim3((co * 32 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w3, w1x1, w1, ws, co, cin);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int clc_stem_unpack_add(const float* dw1, const float* dws, float* g3, float* g1x1, int co, int cin, clc_stream_t stream) {
+  CLC_CHECK(dw1 && dws && g3 && g1x1 && co > 0 && cin > 0 && 9 * cin <= 32, "clc_stem_unpack_add: bad args");
+  hipLaunchKernelGGL(stem_unpack_add_kernel, dim3((co * 32 + 255) / 256), dim3(256), 0, (hipStream_t)stream, dw1, dws, g3, g1x1, co, cin);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int clc_copy2d(const float* src, int lds, float* dst, int ldd, long rows, int C, clc_stream_t stream) {
   CLC_CHECK(src && dst && rows > 0 && C > 0, "clc_copy2d: bad args");
   hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(rows * C, 1024)), dim3(256), 0, ST, src, lds, dst, ldd, rows, C);

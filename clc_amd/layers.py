@@ -191,8 +191,7 @@ class ResidualBlockWithStride(nn.Module):
             # tap, columns 4*cin .. 5*cin) are 1x1 convolutions over those rows on the MFMA kernel.
             col = ops.im2col_small(x, 3, 2, 32)
             co = self.conv1.out_channels
-            w1 = torch.nn.functional.pad(self.conv1.weight.permute(0, 2, 3, 1).reshape(co, 9 * cin), (0, 32 - 9 * cin))
-            ws = torch.nn.functional.pad(self.skip.weight.reshape(co, cin), (4 * cin, 32 - 5 * cin))
+            w1, ws = ops.stem_filters(self.conv1.weight, self.skip.weight)
             g = ops.ActGate()   # conv2's data gradient arrives already multiplied by LeakyReLU'
             t = self.conv2(ops.linear(col, w1, self.conv1.bias, act=ACT_LRELU, gate_out=g), gate_in=g)
             return self.gdn(t, res=ops.linear(col, ws, self.skip.bias))

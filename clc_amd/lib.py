@@ -103,6 +103,8 @@ SIGNATURES = {
     "clc_gate_bwd": (_i, [fp, fp, fp, fp, fp, _l, fp]),
     "clc_axpby": (_i, [fp, _f, fp, _f, fp, _l, fp]),
     "clc_copy2d": (_i, [fp, _i, fp, _i, _l, _i, fp]),
+    "clc_stem_pack": (_i, [fp, fp, fp, fp, _i, _i, fp]),
+    "clc_stem_unpack_add": (_i, [fp, fp, fp, fp, _i, _i, fp]),
     "clc_im2col_small": (_i, [fp, _i, _i, _i, _i, _i, _i, _i, _i, fp, _i, _i, _i, fp]),
     "clc_winattn_fwd": (_i, [fp, _i, fp, fp, _i, fp, _i, _i, _i, _i, _i, _i, _i, fp]),
     "clc_winattn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),

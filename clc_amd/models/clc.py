@@ -291,9 +291,10 @@ class _SliceCodec(CompressionModel):
         x_hat = self.g_s(ops.flush_point(y_hat))
         if prof:
             ops.set_owner("other")
-        return {"x_hat": x_hat,
-                "likelihoods": {"y": torch.cat(y_lik, dim=1), "z": z_likelihoods},
-                "para": {"means": torch.cat(mus, dim=1), "scales": torch.cat(scales, dim=1), "y": y}}
+        out = {"x_hat": x_hat, "likelihoods": {"y": torch.cat(y_lik, dim=1), "z": z_likelihoods}}
+        if not getattr(self, "_lean_outputs", False):   # (clc_amd.train.TrainEngine: the criterion never reads these two concatenations)
+            out["para"] = {"means": torch.cat(mus, dim=1), "scales": torch.cat(scales, dim=1), "y": y}
+        return out
 
     @torch.no_grad()
     def compress(self, x, ref_frames=None):

@@ -588,6 +588,36 @@ def im2col_small(x, ks, stride, ldc=32):
     return col
 
 
+class _StemPackFn(Function):
+    """(3x3/s2 filter [co,cin,3,3], 1x1 skip filter [co,cin,1,1]) -> their 32-column patch-row matrices (clc_stem_pack): one launch
+    forward, one launch adding both gradients straight into the optimizer's gradient buffers backward."""
+
+    @staticmethod
+    def forward(ctx, w3, w1x1):
+        co, cin = w3.shape[0], w3.shape[1]
+        k3, k1 = to_kernel_weight(w3), to_kernel_weight(w1x1)
+        w1 = torch.empty((co, 32), device=w3.device, dtype=torch.float32)
+        ws = torch.empty((co, 32), device=w3.device, dtype=torch.float32)
+        _lib.check(_L().clc_stem_pack(k3.data_ptr(), k1.data_ptr(), w1.data_ptr(), ws.data_ptr(), co, cin, _stream()), "clc_stem_pack")
+        ctx.refs = (w3, w1x1)
+        return w1, ws
+
+    @staticmethod
+    def backward(ctx, dw1, dws):
+        w3, w1x1 = ctx.refs
+        co, cin = w3.shape[0], w3.shape[1]
+        g3, g1 = _direct_grad(w3), _direct_grad(w1x1)
+        if g3 is not None and g1 is not None and to_kernel_weight(w3) is w3 and to_kernel_weight(w1x1) is w1x1:
+            _lib.check(_L().clc_stem_unpack_add(dw1.contiguous().data_ptr(), dws.contiguous().data_ptr(), g3.data_ptr(), g1.data_ptr(), co, cin,
+                                                _stream()), "clc_stem_unpack_add")
+            return None, None
+        return (dw1[:, : 9 * cin].reshape(co, 3, 3, cin).permute(0, 3, 1, 2), dws[:, 4 * cin: 5 * cin].reshape(co, cin, 1, 1))
+
+
+def stem_filters(w3, w1x1):
+    return _StemPackFn.apply(w3, w1x1)
+
+
 def filter_transpose(w, Cout, T, Cin):
     wt = torch.empty(Cin * T * Cout, device=w.device, dtype=torch.float32)
     _lib.check(_L().clc_filter_transpose(w.data_ptr(), wt.data_ptr(), Cout, T, Cin, _stream()), "clc_filter_transpose")
@@ -1626,6 +1656,11 @@ class _EBLikFn(Function):
                                        dz.data_ptr() if dz is not None else None, Cc, rows, Cc, 0 if ctx.training else 1, _stream()), "clc_eb_lik_bwd")
         if dzhat is not None:  # z_hat = ste_round(z - med) + med
             dz = dzhat if dz is None else dz + dzhat
+        direct = [_direct_grad(p) for p in params]
+        if all(d is not None for d in direct):
+            # the optimizer's gradient arena: ONE multi-tensor add instead of autograd's 14 single-workgroup accumulation kernels
+            torch._foreach_add_(direct, grads)
+            grads = [None] * len(params)
         return (dz, None, None, None, *grads)
 
 

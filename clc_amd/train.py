@@ -315,11 +315,19 @@ class TrainEngine:
         self.two_phase = bool(cut) and hasattr(self.model, "_boundary_ok") and not getattr(self.model, "wire_clm", False)
         self.aux_sync = GradSync(self.aux_opt.grad_flat)
 
+    def _model_out(self, x, refs):
+        # (the criterion reads x_hat and the likelihoods only: the concatenated means / scales of the output dict are not assembled)
+        self.model._lean_outputs = True
+        try:
+            return self.model(x, refs)
+        finally:
+            self.model._lean_outputs = False
+
     def _fwd_bwd(self, x, refs):
         self.opt.zero_grad()
         self.aux_opt.zero_grad()
         self.transposer.refresh()
-        out = self.criterion(self.model(x, refs), x)
+        out = self.criterion(self._model_out(x, refs), x)
         out["loss"].backward()
         ops.join_side_streams()   # filter gradients computed on the side stream are complete from here on
         return out
@@ -332,7 +340,7 @@ class TrainEngine:
         self.transposer.refresh()
         self.model._keep_boundary = True
         try:
-            out = self.criterion(self.model(x, refs), x)
+            out = self.criterion(self._model_out(x, refs), x)
         finally:
             self.model._keep_boundary = False
         self._bt = [t for t in self.model._boundary if t is not None and t.requires_grad]

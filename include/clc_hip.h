@@ -224,6 +224,11 @@ int clc_gate_bwd(const float* dout, const float* a, const float* b, float* da, f
 
 /* generic fused adds: out = alpha*a + beta*b */
 int clc_axpby(const float* a, float alpha, const float* b, float beta, float* out, long n, clc_stream_t stream);
+/* RGB-head filters (3x3 / stride 2 [co][3][3][cin] and its 1x1 skip [co][cin], 9 cin <= 32) as the 32-column matrices of the patch-row
+ * formulation (clc_im2col_small): w1[o][k] = w3[o][k] (k < 9 cin), ws[o][4 cin + c] = w1x1[o][c], zero elsewhere; and the reverse, ADDING the
+ * two matrices' gradients into the parameters' gradient buffers. */
+int clc_stem_pack(const float* w3, const float* w1x1, float* w1, float* ws, int co, int cin, clc_stream_t stream);
+int clc_stem_unpack_add(const float* dw1, const float* dws, float* g3, float* g1x1, int co, int cin, clc_stream_t stream);
 /* strided copy of a channel slice: dst[r*ldd + c] = src[r*lds + c] (c < C) */
 int clc_copy2d(const float* src, int lds, float* dst, int ldd, long rows, int C, clc_stream_t stream);
 /* Patch rows of a few-channel image (the RGB heads, Cin = 3: g_a.0 / ref_encoder.encoder.0 of CLC_run.py:274,335):

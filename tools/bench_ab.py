@@ -16,6 +16,7 @@ SHAPES = [  # N, Cin, H, W, Cout, ks, epilogue tensors (res, pre)
     (8, 128, 128, 128, 128, 1, 1, 0), (8, 64, 128, 128, 256, 1, 0, 1), (8, 256, 128, 128, 64, 1, 1, 0), (8, 64, 128, 128, 192, 1, 0, 0),
     (8, 64, 128, 128, 64, 1, 1, 0), (8, 128, 64, 64, 128, 1, 1, 0),
     (8, 128, 32, 32, 512, 3, 0, 0), (8, 320, 16, 16, 512, 3, 0, 0), (8, 128, 32, 32, 128, 3, 1, 0), (8, 64, 32, 32, 64, 3, 0, 0), (8, 320, 32, 32, 320, 3, 0, 0),
+    (16, 640, 16, 16, 224, 3, 0, 0), (16, 512, 16, 16, 224, 3, 0, 0), (16, 384, 16, 16, 224, 3, 0, 0), (8, 704, 16, 16, 224, 3, 0, 0), (8, 448, 16, 16, 224, 3, 0, 0),   # 15..19: slice-parameter nets
 ]
 
 

@@ -107,8 +107,8 @@ def cmd_step(args):
     wall = t1 - t0
     print(f"step wall {wall/1e6:.3f} ms, {len(step)} dispatches, queues {sorted(set(r[3] for r in step))}")
     print("concurrency (kernels in flight) -> ms:", {k: round(v / 1e6, 3) for k, v in sorted(conc.items())})
-    print("\ntime share attributed per kernel (dt / kernels in flight), top 40:")
-    for n, v in sorted(shared.items(), key=lambda kv: -kv[1])[:40]:
+    print(f"\ntime share attributed per kernel (dt / kernels in flight), top {args.top}:")
+    for n, v in sorted(shared.items(), key=lambda kv: -kv[1])[:args.top]:
         cnt = sum(1 for r in step if r[0] == n)
         tot = sum(r[2] - r[1] for r in step if r[0] == n)
         print(f"  {v/1e6:7.3f} ms share | alone {alone.get(n,0)/1e6:7.3f} | sum {tot/1e6:7.3f} | n={cnt:4d} | {n}")
@@ -119,7 +119,7 @@ if __name__ == "__main__":
     sub = ap.add_subparsers(dest="cmd", required=True)
     s = sub.add_parser("stats"); s.add_argument("db"); s.add_argument("--md"); s.add_argument("--csv"); s.add_argument("--top", type=int, default=60)
     s.set_defaults(fn=cmd_stats)
-    t = sub.add_parser("step"); t.add_argument("db"); t.set_defaults(fn=cmd_step)
+    t = sub.add_parser("step"); t.add_argument("db"); t.add_argument("--top", type=int, default=40); t.set_defaults(fn=cmd_step)
     q = sub.add_parser("seq"); q.add_argument("db"); q.add_argument("--from", dest="first", type=int, default=0)
     q.add_argument("--count", type=int, default=100000); q.set_defaults(fn=cmd_seq)
     a = ap.parse_args()
