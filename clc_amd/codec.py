@@ -37,7 +37,7 @@ MAGIC = b"CLC1"
 # ------------------------------------------------------------------------------------------------ container
 
 
-KERNEL_CONFIG_TAG = 4   # bumped whenever the kernels of the context model change their summation order (the decoder must re-derive the
+KERNEL_CONFIG_TAG = 5   # bumped whenever the kernels of the context model change their summation order (the decoder must re-derive the
                         # encoder's float means / scales bit for bit: decode with the build that encoded, or one carrying the same tag)
 
 

@@ -24,18 +24,22 @@ for N, C, H, W, heads, ws in ((8, 64, 128, 128, 8, 8), (8, 64, 64, 64, 4, 8), (8
         def bwd(i):
             torch.autograd.grad(outs[i], [qkvs[i], rb], douts[i], retain_graph=True)
         line = f"C{C} h{heads} ws{ws} {N}x{H}x{W} shift={int(shift)}:"
-        for label, fn in (("fwd", fwd), ("bwd", bwd)):
-            for i in range(nb):
-                fn(i)
-            torch.cuda.synchronize()
-            ts = []
-            for _ in range(5):   # eager launches queued behind a spin kernel: the GPU runs them back to back
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                torch.cuda._sleep(int(0.01 * 2.4e9))
-                e0.record()
-                for i in range(reps):
-                    fn(i % nb)
-                e1.record(); torch.cuda.synchronize()
-                ts.append(e0.elapsed_time(e1) * 1e3 / reps)
-            line += f"  {label} {sorted(ts)[2]:7.1f} us"
+        from clc_amd import lib as _lib
+        for key16 in [int(v) for v in os.environ.get("ATTN_4B", "0,1").split(",")]:
+          _lib.load().clc_set_tuning(16, key16)
+          line += f"  [4B={key16}]"
+          for label, fn in (("fwd", fwd), ("bwd", bwd)):
+              for i in range(nb):
+                  fn(i)
+              torch.cuda.synchronize()
+              ts = []
+              for _ in range(5):   # eager launches queued behind a spin kernel: the GPU runs them back to back
+                  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                  torch.cuda._sleep(int(0.01 * 2.4e9))
+                  e0.record()
+                  for i in range(reps):
+                      fn(i % nb)
+                  e1.record(); torch.cuda.synchronize()
+                  ts.append(e0.elapsed_time(e1) * 1e3 / reps)
+              line += f"  {label} {sorted(ts)[2]:7.1f} us"
         print(line, flush=True)
