@@ -72,6 +72,7 @@ struct ConvParams {
   int dma_place;               // conv_igemm_dma2_kernel: 1 = next tile's DMA pieces at the top of the iteration, 0 = between the MFMA groups
   int ksplit; float* partial;   // conv_igemm_dma2_kernel: K range split over `ksplit` workgroups per tile (blockIdx.z = class * ksplit + split), raw partial tiles to `partial`
   int reg_epi;                 // conv_igemm_dma2_kernel: per-wave register epilogue (epilogue_regs) instead of the C tile through LDS
+  int batch_variant_ok;        // clc_conv_desc.batch_variant_ok
   int ablate;                  // CLC_TUNE_ABLATE (diagnostic builds of the timing only, results are WRONG): 1 = no MFMAs, 2 = no result stores, 4 = no operand DMA
 };
 
@@ -879,6 +880,7 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
       for (int j = 0; j < TN; ++j) {
         const int co = n0 + wn * (BN / WN) + j * 32 + lr;
         const int row0 = m0 + wm * (BM / WM) + i * 32 + 4 * hh;
+        if (co >= p.Cout) continue;                       // (Cout a multiple of 32, not of the tile: the last tile's upper column blocks)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dst[(size_t)(row0 + (r & 3) + 8 * (r >> 2)) * p.Cout + co] = acc[i][j][r];
       }
@@ -1213,8 +1215,26 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvParam
     epilogue_store4(p, bsel, acc, m, co, DH, DW, cls >> 1, cls & 1);
   }
 }
+// Long-K FORWARD 3x3 layers on <= 16x16 maps in training (the slice-parameter nets: 384..704 -> 224 on 2048 / 4096 rows): the split-K
+// family re-fetches both operands per 32-row workgroup (1.1 GB through L2 for 640 -> 224, which is what bounds it); 128x128 LDS tiles
+// move a third of that, with the K range split so that >= 256 workgroups exist.  The split looks at the row count, so the caller must
+// allow a batch-dependent summation order (clc_conv_desc.batch_variant_ok: training forward passes; never the codec).  The same
+// routing for the data gradients of these layers measured slower than their 64x64 tiles (121.6 -> 146.3 us).
+// (heavy128_split > 1 <=> the layer takes this path.)
+static int heavy128_split(const ConvParams& p, int classes) {
+  if (!clc_tuning[CLC_TUNE_HEAVY128] || !p.batch_variant_ok || p.transposed || !p.vec_epi || p.in_op != CLC_IN_NONE || p.xs || p.shuffle || classes != 1) return 1;
+  if (p.ks != 3 || p.stride != 1 || p.OH * p.OW > 256 || p.Cout < 128 || p.Cout % 32 || p.M % 128 || p.M < 2048) return 1;
+  const int ksteps = 9 * p.kc_tiles;
+  if (ksteps < 108) return 1;
+  const long wgs = (long)(p.M / 128) * ((p.Cout + 127) / 128);
+  int k = (int)((256 + wgs - 1) / wgs);
+  if (k > 8) k = 8;
+  while (k > 1 && ksteps / k < 16) --k;
+  return k;
+}
 // how many ways clc_conv2d would split the K range of a 64x64-tile data-gradient launch (1: not at all)
 static int conv_ksplit(const ConvParams& p, int classes) {
+  { const int k128 = heavy128_split(p, classes); if (k128 > 1) return k128; }
   if (!clc_tuning[CLC_TUNE_DGRAD_SPLITK] || !p.transposed || !p.vec_epi || p.in_op != CLC_IN_NONE || p.xs || p.shuffle) return 1;
   if (p.M % 64 || p.Cout % 64) return 1;
   const long wgs = (long)(p.M / 64) * (p.Cout / 64) * classes;
@@ -1488,7 +1508,7 @@ static int fill_params(const clc_conv_desc* d, ConvParams& p, int& classes) {
   p.M = d->N * d->OH * d->OW;
   if (d->transposed && d->stride == 2) { classes = 4; p.M = d->N * (d->OH / 2) * (d->OW / 2); }
   p.w2 = d->w2; p.bias2 = d->bias2; p.group_rows = 0; p.pre_deriv = d->pre_deriv;
-  p.dma_place = clc_tuning[CLC_TUNE_DMA_PLACE]; p.xcd_map = 0; p.ablate = clc_tuning[CLC_TUNE_ABLATE]; p.reg_epi = 0; p.ksplit = 1; p.partial = nullptr;
+  p.dma_place = clc_tuning[CLC_TUNE_DMA_PLACE]; p.xcd_map = 0; p.ablate = clc_tuning[CLC_TUNE_ABLATE]; p.reg_epi = 0; p.ksplit = 1; p.partial = nullptr; p.batch_variant_ok = d->batch_variant_ok;
   p.res_gate = d->res ? d->res_gate : nullptr; p.ldg = d->ldg; p.rg_act = d->res_gate_act; p.rg_pre = d->res_gate_pre;
   p.out_gate = d->out_gate; p.ldog = d->ldog; p.og_act = d->out_gate_act; p.og_pre = d->out_gate_pre;
   CLC_CHECK(!d->out_gate || !d->shuffle, "clc_conv2d: out_gate with shuffle");
@@ -1511,7 +1531,7 @@ static int fill_params(const clc_conv_desc* d, ConvParams& p, int& classes) {
 }
 
 extern "C" size_t clc_conv2d_workspace_bytes(const clc_conv_desc* d) {
-  if (!d || !d->transposed) return 0;
+  if (!d) return 0;
   ConvParams p;
   int classes = 1;
   if (fill_params(d, p, classes) < 0) return 0;
@@ -1546,6 +1566,10 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   const int splitk_pix = clc_tuning[CLC_TUNE_SPLITK_PIX] > 0 ? clc_tuning[CLC_TUNE_SPLITK_PIX] : 256;
   const bool small_map = img_pix <= 256 || (img_pix <= splitk_pix && C <= clc_tuning[CLC_TUNE_SPLITK_MAXC]);
   if (small_map) {
+    if (heavy128_split(p, classes) > 1) {
+      use_split(p, d, classes);
+      if (p.ksplit > 1) return launch<128, 128, 4, 2>(p, classes, st);
+    }
     // Heavy data gradients of the slice loop (3x3, 224 -> 448..768 on the stacked batch): enough 64x64 tiles to fill the
     // chip without splitting K, and the LDS-tiled kernel shares each operand tile among 4 waves where the split-K family
     // re-fetches fragments per wave (224 -> 704 @ 4096 rows: 192 -> 130 us).  Data gradients exist in training only, so the

@@ -33,7 +33,7 @@ class ConvDesc(C.Structure):
                 ("res_gate", fp), ("ldg", C.c_int), ("res_gate_act", C.c_int), ("res_gate_pre", C.c_int),
                 ("out_gate", fp), ("ldog", C.c_int), ("out_gate_act", C.c_int), ("out_gate_pre", C.c_int),
                 ("w3", fp), ("bias3", fp), ("w4", fp), ("bias4", fp),
-                ("workspace", fp), ("workspace_bytes", C.c_size_t)]
+                ("workspace", fp), ("workspace_bytes", C.c_size_t), ("batch_variant_ok", C.c_int)]
 
 
 class WgradDesc(C.Structure):

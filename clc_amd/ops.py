@@ -492,8 +492,9 @@ def to_kernel_weight(w: torch.Tensor) -> torch.Tensor:
 
 def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_NONE, norm=NORM_NONE, mul=None,
              res=None, res_scale=1.0, res_first=False, y_pre=None, shuffle=False, transposed=False, out=None, out_hw=None,
-             xs=None, xs_act=ACT_NONE, xs_pre=False, w2=None, bias2=None, pre_deriv=False, res_gate=None, out_gate=None, wx=None):
+             xs=None, xs_act=ACT_NONE, xs_pre=False, w2=None, bias2=None, pre_deriv=False, res_gate=None, out_gate=None, wx=None, batch_variant_ok=False):
     """One clc_conv2d launch. ``w`` must already be in kernel layout [Cout][ks][ks][Cin].
+    batch_variant_ok: the summation order may depend on the batch size (training forward passes only, never the codec path).
     wx: ((w3, bias3), (w4, bias4)) — with (w2, bias2), four filter sets on the four quarters of the batch."""
     _require_gpu(x, "conv2d")
     x, xp, N, H, W, Cin, ldx = nhwc(x)
@@ -549,7 +550,8 @@ def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_
         xs_t, xsp, *_r, ldxs = nhwc(xs)
         d.xs, d.ldxs, d.xs_act, d.xs_pre = xsp, ldxs, xs_act, int(xs_pre)
         keep.append(xs_t)
-    if transposed and H * W <= 1024:   # data gradients on small maps: scratch for the K split of under-filled grids (0 bytes: no split)
+    d.batch_variant_ok = int(bool(batch_variant_ok))
+    if (transposed and H * W <= 1024) or (batch_variant_ok and ks == 3 and OH * OW <= 256):   # scratch for the K split of under-filled grids (0 bytes: no split)
         nws = _lib.load().clc_conv2d_workspace_bytes(C.byref(d))
         if nws:
             ws = torch.empty((nws + 3) // 4, device=x.device, dtype=torch.float32)
@@ -754,7 +756,7 @@ class _ConvFn(Function):
         # the gradient kernels' loaders — no erf/exp there and no elementwise dz pass
         deriv = save_pre and act == ACT_GELU
         y = conv_raw(x, wk, b, ks=ks, stride=stride, act=act, res=res, res_scale=res_scale, res_first=res_first, y_pre=y_pre, shuffle=shuffle,
-                     w2=wk2, bias2=b2, pre_deriv=deriv, out=out_buf, wx=wkx)
+                     w2=wk2, bias2=b2, pre_deriv=deriv, out=out_buf, wx=wkx, batch_variant_ok=need_grad)
         if out_buf is not None:   # written in place into the caller's (strided) buffer: hand autograd a fresh alias of it
             y = out_buf.detach()
         ctx.cfg = (ks, stride, ACT_SAVED_DERIV if deriv else act, res_scale, shuffle, b is not None, res is not None, res_first)

@@ -105,8 +105,13 @@ typedef struct {
   /* optional scratch (clc_conv2d_workspace_bytes(d) bytes, caller-owned, 16-B aligned): lets a DATA-GRADIENT launch whose grid would
    * leave most CUs with one 4-wave workgroup (3x3 layers on 32x32 / 16x16 maps with few output channels) split K over 2-4
    * workgroups per tile — partial tiles to the scratch, a fixed-order finish launch adds them and applies the epilogue.  Without it
-   * (NULL) the launch is not split.  Forward launches are never split: an image's bits must not depend on the batch size. */
+   * (NULL) the launch is not split.  Forward launches are not split unless batch_variant_ok is set: an image's bits must not depend on
+   * the batch size in the codec. */
   void* workspace; size_t workspace_bytes;
+  /* nonzero: this launch's result may depend (in summation order only) on the batch size — set by training forward passes, never by the
+   * codec path.  Lets the long-K forward layers of the slice-parameter nets (3x3, 384..704 -> 224 on 16x16 maps) run on 128x128 LDS tiles
+   * with a K split sized to the grid (needs `workspace`). */
+  int batch_variant_ok;
 } clc_conv_desc;
 
 int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream);
