@@ -17,6 +17,7 @@ SHAPES = [  # N, Cin, H, W, Cout, ks, epilogue tensors (res, pre)
     (8, 64, 128, 128, 64, 1, 1, 0), (8, 128, 64, 64, 128, 1, 1, 0),
     (8, 128, 32, 32, 512, 3, 0, 0), (8, 320, 16, 16, 512, 3, 0, 0), (8, 128, 32, 32, 128, 3, 1, 0), (8, 64, 32, 32, 64, 3, 0, 0), (8, 320, 32, 32, 320, 3, 0, 0),
     (16, 640, 16, 16, 224, 3, 0, 0), (16, 512, 16, 16, 224, 3, 0, 0), (16, 384, 16, 16, 224, 3, 0, 0), (8, 704, 16, 16, 224, 3, 0, 0), (8, 448, 16, 16, 224, 3, 0, 0),   # 15..19: slice-parameter nets
+    (16, 128, 16, 16, 512, 1, 0, 1), (16, 512, 16, 16, 128, 1, 1, 0), (16, 128, 16, 16, 384, 1, 0, 0), (16, 224, 16, 16, 128, 3, 0, 0), (16, 128, 16, 16, 128, 1, 1, 0), (16, 128, 16, 16, 64, 3, 0, 0),   # 20..25: slice-loop Swin / cc layers
 ]
 
 
@@ -42,7 +43,8 @@ def main():
         flops = 2.0 * N * H * W * ks * ks * Cin * Cout
 
         def fwd(i):
-            ops.conv_raw(xs[i], w, b, ks=ks, act=(ops.ACT_GELU if with_pre else ops.ACT_LRELU), out=ys[i], res=rs[i], y_pre=ps[i], pre_deriv=bool(with_pre))
+            ops.conv_raw(xs[i], w, b, ks=ks, act=(ops.ACT_GELU if with_pre else ops.ACT_LRELU), out=ys[i], res=rs[i], y_pre=ps[i], pre_deriv=bool(with_pre),
+                         batch_variant_ok=bool(int(os.environ.get("BATCH_VARIANT", "1"))))
 
         def dgrad(i):
             ops.conv_raw(dys[i], wt, None, ks=ks, pad=ks // 2, transposed=True, out_hw=(H, W), out=dxs[i], res=(xs[i] if with_res else None))
