@@ -24,7 +24,7 @@ enum { CLC_TUNE_DMA_LOOP = 0 /* 1: conv_igemm_dma_kernel, 2: conv_igemm_dma2_ker
        CLC_TUNE_P1X1 = 13 /* large-map 1x1 layers on the persistent pipelined kernel (conv_igemm_p1x1_kernel) */,
        CLC_TUNE_BF16 = 14 /* opt-in reduced-precision mode: bf16-in / f32-accumulate MFMA in the 3x3 convolutions, data- and filter-gradient kernels of maps larger than 16x16 */,
        CLC_TUNE_TILE256 = 15 /* 64-channel 3x3 layers on >= 131072 rows: 256 x 64 tiles (64 x 32 per wave) */,
-       CLC_TUNE_ATTN_4B = 16 /* window attention, head_dim <= 16: the N = head_dim products on 4-block 16x16x1 MFMAs (1: backward, and forward with head_dim 16; 2: forward with head_dim 8 too) */,
+       CLC_TUNE_ATTN_4B = 16 /* window attention: the N = head_dim products on 4-block 16x16x1 MFMAs; bit mask: 1 = head_dim 16, 2 = head_dim-8 backward, 4 = head_dim-8 forward (off: see winattn.hip) */,
        CLC_TUNE_HEAVY128 = 17 /* long-K 3x3 layers on <= 16x16 maps (the slice-parameter nets): 128x128 LDS tiles with the K range split to fill the chip */,
        CLC_TUNE_COUNT = 18 };
 extern int clc_tuning[CLC_TUNE_COUNT];

@@ -740,13 +740,13 @@ static int winattn_fwd_impl(const float* qkv, int ldq, const float* relbias, con
   const int hd = C / heads;
   static const int use_mfma = getenv("CLC_ATTN_MFMA") ? atoi(getenv("CLC_ATTN_MFMA")) : 1;   // 0: VALU kernels (A/B knob)
   if (ws == 8 && use_mfma) {
-    // head_dim <= 16: the N = head_dim products on 4-block 16x16x1 MFMAs.  FORWARD with head_dim 8 (the analysis / synthesis transforms)
-    // only with key 16 = 2: another summation order moves y by ~4e-6, and on the parity sample one hyper-latent sits that close to .5 —
-    // its flip costs 9e-4 bpp against the oracle (bar: 1e-4).  Both orders are equally exact (3e-7 of fp64); the default keeps the
-    // order the parity numbers were taken with and gives up 8 us per launch.
-    const bool b4 = clc_tuning[CLC_TUNE_ATTN_4B] != 0;
-    if (hd == 8) { if (clc_tuning[CLC_TUNE_ATTN_4B] >= 2) hipLaunchKernelGGL((winattn_fwd_mfma_kernel<8, true>), grid, dim3(64), 0, (hipStream_t)stream, p); else hipLaunchKernelGGL((winattn_fwd_mfma_kernel<8, false>), grid, dim3(64), 0, (hipStream_t)stream, p); }
-    else if (hd == 16) { if (b4) hipLaunchKernelGGL((winattn_fwd_mfma_kernel<16, true>), grid, dim3(64), 0, (hipStream_t)stream, p); else hipLaunchKernelGGL((winattn_fwd_mfma_kernel<16, false>), grid, dim3(64), 0, (hipStream_t)stream, p); }
+    // head_dim <= 16: the N = head_dim products on 4-block 16x16x1 MFMAs (key 16, bit mask: 1 = head_dim 16, 2 = head_dim-8 backward,
+    // 4 = head_dim-8 forward).  The head_dim-8 FORWARD (the analysis / synthesis transforms) is off by default: another summation order
+    // moves y by ~4e-6, and on the parity sample one hyper-latent sits that close to .5 — its flip costs 9e-4 bpp against the oracle
+    // (bar: 1e-4).  Both orders are equally exact (3e-7 of fp64); the default keeps the order the parity numbers were taken with.
+    const int m4 = clc_tuning[CLC_TUNE_ATTN_4B];
+    if (hd == 8) { if (m4 & 4) hipLaunchKernelGGL((winattn_fwd_mfma_kernel<8, true>), grid, dim3(64), 0, (hipStream_t)stream, p); else hipLaunchKernelGGL((winattn_fwd_mfma_kernel<8, false>), grid, dim3(64), 0, (hipStream_t)stream, p); }
+    else if (hd == 16) { if (m4 & 1) hipLaunchKernelGGL((winattn_fwd_mfma_kernel<16, true>), grid, dim3(64), 0, (hipStream_t)stream, p); else hipLaunchKernelGGL((winattn_fwd_mfma_kernel<16, false>), grid, dim3(64), 0, (hipStream_t)stream, p); }
     else hipLaunchKernelGGL((winattn_fwd_mfma_kernel<32, false>), grid, dim3(64), 0, (hipStream_t)stream, p);
   } else if (ws == 8) DISPATCH(winattn_fwd_kernel, 64, hd, grid, p, (hipStream_t)stream);
   else DISPATCH(winattn_fwd_kernel, 16, hd, grid, p, (hipStream_t)stream);
@@ -784,9 +784,9 @@ static int winattn_bwd_impl(const float* dout, int lddo, const float* qkv, int l
   const int hd = C / heads;
   static const int use_mfma = getenv("CLC_ATTN_MFMA") ? atoi(getenv("CLC_ATTN_MFMA")) : 1;   // 0: VALU kernels (A/B knob)
   if (ws == 8 && use_mfma) {
-    const bool b4 = clc_tuning[CLC_TUNE_ATTN_4B] != 0;
-    if (hd == 8) { if (b4) hipLaunchKernelGGL((winattn_bwd_mfma_kernel<8, true>), grid, dim3(64), 0, (hipStream_t)stream, p); else hipLaunchKernelGGL((winattn_bwd_mfma_kernel<8, false>), grid, dim3(64), 0, (hipStream_t)stream, p); }
-    else if (hd == 16) { if (b4) hipLaunchKernelGGL((winattn_bwd_mfma_kernel<16, true>), grid, dim3(64), 0, (hipStream_t)stream, p); else hipLaunchKernelGGL((winattn_bwd_mfma_kernel<16, false>), grid, dim3(64), 0, (hipStream_t)stream, p); }
+    const int m4 = clc_tuning[CLC_TUNE_ATTN_4B];
+    if (hd == 8) { if (m4 & 2) hipLaunchKernelGGL((winattn_bwd_mfma_kernel<8, true>), grid, dim3(64), 0, (hipStream_t)stream, p); else hipLaunchKernelGGL((winattn_bwd_mfma_kernel<8, false>), grid, dim3(64), 0, (hipStream_t)stream, p); }
+    else if (hd == 16) { if (m4 & 1) hipLaunchKernelGGL((winattn_bwd_mfma_kernel<16, true>), grid, dim3(64), 0, (hipStream_t)stream, p); else hipLaunchKernelGGL((winattn_bwd_mfma_kernel<16, false>), grid, dim3(64), 0, (hipStream_t)stream, p); }
     else hipLaunchKernelGGL((winattn_bwd_mfma_kernel<32, false>), grid, dim3(64), 0, (hipStream_t)stream, p);
   } else if (ws == 8) DISPATCH(winattn_bwd_kernel, 64, hd, grid, p, (hipStream_t)stream);
   else DISPATCH(winattn_bwd_kernel, 16, hd, grid, p, (hipStream_t)stream);
