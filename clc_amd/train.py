@@ -424,6 +424,8 @@ class TrainEngine:
                              % ("with" if self._live_refs else "without"))
         # CLC_FORCE_SPLIT_GRAPHS=1 exercises the multi-GPU structure (graph A | exchange | graph B) on one GPU
         single = self.sync.world == 1 and os.environ.get("CLC_FORCE_SPLIT_GRAPHS", "0") != "1"
+        if self.graph is not None:
+            single = not isinstance(self.graph, tuple)   # (the structure is fixed once captured)
         if not self.use_graph:
             return self._eager_step(x, refs, split=not single)
         sig = self._signature(x, refs)
