@@ -866,7 +866,7 @@ class _ConvFn(Function):
                 dw2, db2 = _ConvFn._wgrad(x[h:], dz[h:], w2, b2, has_b, need_w, need_b, ks, stride, pad, fw2)
         if need_x:
             def wt_of(wp):
-                wt = getattr(wp, "_clc_wt", None)   # refreshed once per step by the batched transpose (clc_amd.train)
+                wt = getattr(wp, "_clc_wt", None) if WT_CACHE_VALID else None   # refreshed once per step by the batched transpose (clc_amd.train)
                 if wt is None:
                     wt = filter_transpose(to_kernel_weight(wp), Cout, ks * ks, Cin)
                 return wt.view(Cin, -1)
@@ -897,6 +897,11 @@ def conv2d(x, w, b=None, *, stride=1, act=ACT_NONE, res=None, res_scale=1.0, shu
     return _ConvFn.apply(x, w, b, res, ks, stride, act, float(res_scale), bool(shuffle), bool(res_first), w2, b2, fold_in, fold_out, out,
                          grad_slot, park_dx, gate_in, gate_out, w3, b3, w4, b4)
 
+
+# The [Cin][T][Cout] filter images clc_amd.train.FilterTransposer attaches to the parameters (`_clc_wt`) are refreshed at the START of an
+# engine step; after that step's optimizer update they are one update behind.  They are therefore trusted only while the engine is
+# running (or capturing) the forward/backward of a step — a plain autograd backward on the same model afterwards transposes on the fly.
+WT_CACHE_VALID = False
 
 FUSED_RU = int(os.environ.get("CLC_FUSED_RU", "1"))   # ResidualUnits on 16x16 maps with 128 channels: one launch forward, one for the data gradient
 
@@ -932,7 +937,7 @@ def residual_unit_fwd_raw(x, sets):
 
 def _wt_of(wp):
     """[Cin][taps][Cout] image of a filter parameter: refreshed once per step by the batched transpose (clc_amd.train), else made here."""
-    wt = getattr(wp, "_clc_wt", None)
+    wt = getattr(wp, "_clc_wt", None) if WT_CACHE_VALID else None
     if wt is None:
         ks = wp.shape[2] if wp.dim() == 4 else 1
         wt = filter_transpose(to_kernel_weight(wp), wp.shape[0], ks * ks, wp.shape[1])

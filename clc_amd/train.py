@@ -327,8 +327,12 @@ class TrainEngine:
         self.opt.zero_grad()
         self.aux_opt.zero_grad()
         self.transposer.refresh()
-        out = self.criterion(self._model_out(x, refs), x)
-        out["loss"].backward()
+        ops.WT_CACHE_VALID = True      # (the transposed filter images are this step's: see ops.WT_CACHE_VALID)
+        try:
+            out = self.criterion(self._model_out(x, refs), x)
+            out["loss"].backward()
+        finally:
+            ops.WT_CACHE_VALID = False
         ops.join_side_streams()   # filter gradients computed on the side stream are complete from here on
         return out
 
@@ -348,13 +352,21 @@ class TrainEngine:
         for t in self._bt:
             t.grad = None
         # (retain_graph: the engine would otherwise also release the saved tensors of the boundary's producers, which stage 2 needs)
-        torch.autograd.backward([out["loss"]], inputs=list(self.early_params) + self._bt, retain_graph=True)
+        ops.WT_CACHE_VALID = True
+        try:
+            torch.autograd.backward([out["loss"]], inputs=list(self.early_params) + self._bt, retain_graph=True)
+        finally:
+            ops.WT_CACHE_VALID = False
         ops.join_side_streams()
         return out
 
     def _bwd_late(self):
         """backward of the analysis transform and the reference branch from the parked boundary gradients."""
-        torch.autograd.backward(self._bt, [t.grad for t in self._bt])
+        ops.WT_CACHE_VALID = True
+        try:
+            torch.autograd.backward(self._bt, [t.grad for t in self._bt])
+        finally:
+            ops.WT_CACHE_VALID = False
         ops.join_side_streams()
         self._bt = None
 

@@ -505,3 +505,34 @@ def test_reduced_precision_mode_bf16(dev):
     worst, med = errs[0][0], errs[len(errs) // 2][0]
     print(f"bf16 vs f32 gradients: worst {worst:.3f} ({errs[0][1]}), median {med:.2e}, > 10 %: {sum(e > 0.1 for e, _ in errs)} of {len(errs)}")
     assert med < 2e-2 and sum(e > 0.1 for e, _ in errs) <= len(errs) // 50, errs[:10]
+
+
+def test_plain_autograd_after_engine_steps_uses_current_filters(dev):
+    """The [Cin][T][Cout] filter images the engine attaches to the parameters for its data-gradient kernels are one optimizer update
+    behind once a step has finished: a plain autograd backward on the same model afterwards must not use them (ops.WT_CACHE_VALID)."""
+    from clc_amd import ops
+    from clc_amd.train import RateDistortionLoss, TrainEngine
+
+    x, refs = _inputs(dev, 2, 1)
+    m = _model(dev)
+    eng = TrainEngine(m, lmbda=0.0067, use_graph=False, train_mode=False)
+    for _ in range(2):
+        eng.step(x, refs)
+    assert ops.WT_CACHE_VALID is False
+    # gradient of the loss w.r.t. the INPUT image through plain autograd, with and without the engine's cached images present
+    def input_grad():
+        xi = x.clone().requires_grad_(True)
+        out = RateDistortionLoss(0.0067)(m(xi, refs), xi.detach())
+        (g,) = torch.autograd.grad(out["loss"], [xi])
+        return g
+    g_with = input_grad()
+    saved = {}
+    for p in m.parameters():
+        if hasattr(p, "_clc_wt"):
+            saved[p] = p._clc_wt
+            del p._clc_wt
+    assert saved, "the engine attached no transposed filter images"
+    g_without = input_grad()
+    for p, wt in saved.items():
+        p._clc_wt = wt
+    assert torch.equal(g_with, g_without)
