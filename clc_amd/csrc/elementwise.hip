@@ -276,6 +276,30 @@ __global__ void gdn_reparam_fwd_kernel(const float* __restrict__ gamma, const fl
     }
   }
 }
+// ... for ALL GDN modules of a model in one launch (clc_amd.train refreshes them once per step, like the transposed filter images):
+// block b works on 256 consecutive elements of the entry whose block range holds it.
+__global__ __launch_bounds__(256) void gdn_reparam_fwd_batched_kernel(const clc_gdn_entry* __restrict__ table, int n_entries) {
+  __shared__ int s_e;
+  if (threadIdx.x == 0) {
+    int e = 0;
+    while (e + 1 < n_entries && (int)blockIdx.x >= table[e + 1].first_block) ++e;
+    s_e = e;
+  }
+  __syncthreads();
+  const clc_gdn_entry en = table[s_e];
+  const int C = en.C, n = C * C + C;
+  const int i = ((int)blockIdx.x - en.first_block) * 256 + (int)threadIdx.x;
+  if (i >= n) return;
+  if (i < C * C) {
+    const float t = fmaxf(en.gamma[i], en.gamma_bound), y = t * t - en.pedestal;
+    en.gamma_eff[i] = y;
+    const int r = i / C, c = i - r * C;
+    en.gamma_eff_t[c * C + r] = y;
+  } else {
+    const float t = fmaxf(en.beta[i - C * C], en.beta_bound);
+    en.beta_eff[i - C * C] = t * t - en.pedestal;
+  }
+}
 // backward of the above with the LowerBound gradient rule: dt = 2 max(x,bound) dy; dx = (x >= bound || dt < 0) ? dt : 0
 __global__ void gdn_reparam_bwd_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, int C, float gbound, float bbound,
                                        const float* __restrict__ dg_eff, const float* __restrict__ db_eff, float* __restrict__ dgamma,
@@ -638,6 +662,12 @@ extern "C" int clc_gdn_reparam_fwd(const float* gamma, const float* beta, int C,
   CLC_CHECK(gamma && beta && gamma_eff && gamma_eff_t && beta_eff && C > 0, "clc_gdn_reparam_fwd: bad args");
   hipLaunchKernelGGL(gdn_reparam_fwd_kernel, dim3(grid_for((long)C * C + C, 256)), dim3(256), 0, ST, gamma, beta, C, gamma_bound, beta_bound, pedestal,
                      gamma_eff, gamma_eff_t, beta_eff);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int clc_gdn_reparam_fwd_batched(const clc_gdn_entry* table_dev, int n_entries, int total_blocks, clc_stream_t stream) {
+  CLC_CHECK(table_dev && n_entries > 0 && total_blocks > 0, "clc_gdn_reparam_fwd_batched: bad args");
+  hipLaunchKernelGGL(gdn_reparam_fwd_batched_kernel, dim3(total_blocks), dim3(256), 0, ST, table_dev, n_entries);
   CLC_LAUNCH_CHECK();
   return 0;
 }

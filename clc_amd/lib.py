@@ -53,6 +53,11 @@ class RUDesc(C.Structure):
                 ("saved_y", fp), ("saved_t2", fp), ("saved_t1", fp)]
 
 
+class GDNEntry(C.Structure):
+    _fields_ = [("gamma", fp), ("beta", fp), ("gamma_eff", fp), ("gamma_eff_t", fp), ("beta_eff", fp), ("C", C.c_int), ("first_block", C.c_int),
+                ("gamma_bound", C.c_float), ("beta_bound", C.c_float), ("pedestal", C.c_float)]
+
+
 class TransposeEntry(C.Structure):
     _fields_ = [("w", fp), ("wt", fp), ("Cout", C.c_int), ("T", C.c_int), ("Cin", C.c_int), ("tile_begin", C.c_int)]
 
@@ -97,6 +102,7 @@ SIGNATURES = {
     "clc_gdn_bwd_elem": (_i, [fp, fp, fp, fp, fp, _l, _i, fp]),
     "clc_gdn_bwd_combine": (_i, [fp, fp, fp, fp, _l, fp]),
     "clc_gdn_reparam_fwd": (_i, [fp, fp, _i, _f, _f, _f, fp, fp, fp, fp]),
+    "clc_gdn_reparam_fwd_batched": (_i, [fp, _i, _i, fp]),
     "clc_gdn_reparam_bwd": (_i, [fp, fp, _i, _f, _f, fp, fp, fp, fp, _i, fp]),
     "clc_unshuffle_act_bwd": (_i, [fp, _i, fp, _i, _i, _i, fp, _i, _i, _i, _i, fp]),
     "clc_gate_fwd": (_i, [fp, fp, fp, fp, _l, fp]),

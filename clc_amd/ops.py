@@ -1327,6 +1327,10 @@ class _GDNParamFn(Function):
         sets = [(gamma, beta)] + ([(gamma2, beta2)] if gamma2 is not None else [])
         eff = []
         for g, b in sets:
+            cached = getattr(g, "_clc_gdn_eff", None) if WT_CACHE_VALID else None   # (clc_amd.train.GDNReparamCache: all modules in one launch per step)
+            if cached is not None and g.is_contiguous():
+                eff.append((g,) + tuple(cached))
+                continue
             g_eff = torch.empty((Cc, Cc), device=x.device, dtype=torch.float32)
             g_eff_t = torch.empty((Cc, Cc), device=x.device, dtype=torch.float32)
             b_eff = torch.empty((Cc,), device=x.device, dtype=torch.float32)

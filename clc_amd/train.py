@@ -252,6 +252,40 @@ class FilterTransposer:
             _lib.check(ops._L().clc_filter_transpose_batched(self.table.data_ptr(), self.n, self.total_tiles, ops._stream()), "clc_filter_transpose_batched")
 
 
+class GDNReparamCache:
+    """The effective (re-parametrised) gamma / beta of every GDN module — and gamma transposed for the data-gradient conv — refreshed by ONE
+    launch per step (clc_gdn_reparam_fwd_batched) instead of one launch per module inside the forward pass.  Like the transposed filter
+    images, the cached tensors are this step's only between refresh() and the optimizer update (ops.WT_CACHE_VALID)."""
+
+    def __init__(self, model: nn.Module, live: List[nn.Parameter]):
+        from .layers import GDN
+
+        ids = {id(p) for p in live}
+        mods = [m for m in model.modules() if isinstance(m, GDN) and id(m.gamma) in ids and id(m.beta) in ids and m.gamma.is_contiguous()]
+        self.n = len(mods)
+        if not mods:
+            return
+        dev = mods[0].gamma.device
+        entries, blocks, self.keep = [], 0, []
+        for m in mods:
+            Cc = m.gamma.shape[0]
+            gb, bb, ped = m._consts()
+            g_eff = torch.empty((Cc, Cc), device=dev, dtype=torch.float32)
+            g_eff_t = torch.empty((Cc, Cc), device=dev, dtype=torch.float32)
+            b_eff = torch.empty((Cc,), device=dev, dtype=torch.float32)
+            m.gamma._clc_gdn_eff = (g_eff, g_eff_t, b_eff)
+            self.keep.append((g_eff, g_eff_t, b_eff))
+            entries.append(_lib.GDNEntry(m.gamma.data_ptr(), m.beta.data_ptr(), g_eff.data_ptr(), g_eff_t.data_ptr(), b_eff.data_ptr(), Cc, blocks, gb, bb, ped))
+            blocks += (Cc * Cc + Cc + 255) // 256
+        self.total_blocks = blocks
+        raw = b"".join(bytes(e) for e in entries)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+
+    def refresh(self):
+        if self.n:
+            _lib.check(ops._L().clc_gdn_reparam_fwd_batched(self.table.data_ptr(), self.n, self.total_blocks, ops._stream()), "clc_gdn_reparam_fwd_batched")
+
+
 class TrainEngine:
     """One data-parallel training step of the reference loop (train_CLC.py:137-183), hipGraph-captured.
 
@@ -307,6 +341,7 @@ class TrainEngine:
         self.opt = self._make_opt(live, self.lr, self.clip)
         self.aux_opt = self._make_opt(aux, self.aux_lr, 0.0)
         self.transposer = FilterTransposer(live)
+        self.gdn_cache = GDNReparamCache(self.model, live)
         cut = self.opt.p_arena.offsets[len(late)] if (late and early) else 0
         n_el = self.opt.grad_flat.numel()
         self.early_params = early
@@ -327,6 +362,7 @@ class TrainEngine:
         self.opt.zero_grad()
         self.aux_opt.zero_grad()
         self.transposer.refresh()
+        self.gdn_cache.refresh()
         ops.WT_CACHE_VALID = True      # (the transposed filter images are this step's: see ops.WT_CACHE_VALID)
         try:
             out = self.criterion(self._model_out(x, refs), x)
@@ -342,11 +378,14 @@ class TrainEngine:
         self.opt.zero_grad()
         self.aux_opt.zero_grad()
         self.transposer.refresh()
+        self.gdn_cache.refresh()
         self.model._keep_boundary = True
+        ops.WT_CACHE_VALID = True
         try:
             out = self.criterion(self._model_out(x, refs), x)
         finally:
             self.model._keep_boundary = False
+            ops.WT_CACHE_VALID = False
         self._bt = [t for t in self.model._boundary if t is not None and t.requires_grad]
         self.model._boundary = None
         for t in self._bt:

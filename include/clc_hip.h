@@ -215,6 +215,15 @@ int clc_gdn_bwd_combine(const float* dx_direct, const float* x, const float* t, 
  * gradient rule (pass where x >= bound or the gradient pushes x up), optionally accumulating into dgamma / dbeta. */
 int clc_gdn_reparam_fwd(const float* gamma, const float* beta, int C, float gamma_bound, float beta_bound, float pedestal,
                         float* gamma_eff, float* gamma_eff_t, float* beta_eff, clc_stream_t stream);
+/* The forward re-parametrisation of MANY GDN modules in one launch: `table_dev` = n_entries device-resident entries, entry e owning the
+ * blocks [first_block, first_block + ceil((C*C + C) / 256)) of a grid of total_blocks workgroups of 256 threads. */
+typedef struct {
+  const float* gamma; const float* beta;
+  float* gamma_eff; float* gamma_eff_t; float* beta_eff;
+  int C, first_block;
+  float gamma_bound, beta_bound, pedestal;
+} clc_gdn_entry;
+int clc_gdn_reparam_fwd_batched(const clc_gdn_entry* table_dev, int n_entries, int total_blocks, clc_stream_t stream);
 int clc_gdn_reparam_bwd(const float* gamma, const float* beta, int C, float gamma_bound, float beta_bound, const float* dgamma_eff,
                         const float* dbeta_eff, float* dgamma, float* dbeta, int accumulate, clc_stream_t stream);
 /* backward of PixelShuffle(2) fused with the activation backward of the conv that was stored shuffled:
