@@ -460,13 +460,18 @@ __global__ __launch_bounds__(64) void winattn_bwd_mfma_kernel(const AttnParams p
   constexpr int T = 64, WS = 8, LDQ = HD + 4, NBW = 2 * WS - 1, NB = NBW * NBW;
   __shared__ __attribute__((aligned(16))) float Qs[T][LDQ], Ks[T][LDQ], Vs[T][LDQ], Ds[T][LDQ], St[T][LDQ];
   __shared__ float Lse[T], Dd[T], Bias[NB];
-  // relative-bias gradient bins: [half-wave][4 interleaved copies].  A bin update is an LDS read-modify-write; one copy makes the 64
-  // updates of a query tile ONE dependent chain (read -> add -> write -> next read: a full LDS round trip per step, longer than the
-  // MFMA it sits beside).  Steps r, r+1, r+2, r+3 go to four different copies, so four chains run interleaved (LDS executes a wave's
-  // accesses in issue order: the reads of a group are issued together, then the adds and writes); the copies are summed at the end
-  // in a fixed order.
-  constexpr int NC = HD == 8 ? 2 : 4;   // (head_dim 8: the kernel is occupancy-bound at 8 workgroups per CU — 4 copies cost two of them)
-  __shared__ float BinAcc[2][NC][NB];
+  // Relative-bias gradient.  In the S' register layout the bin of element (tile pair (ti, tj), register r) of a lane is
+  //   off_q(lane) + (4 (ti - tj)) * NBW - (r >> 2) * NBW - (r & 3)
+  // — the SAME for every window this workgroup visits.  So dS is accumulated in REGISTERS per (ti - tj, r) (3 x 16 per lane) over all
+  // the windows, and the bins in LDS are touched once per workgroup at the end (48 read-modify-write steps; inside a half-wave the 32
+  // lanes of a step hit 32 distinct bins, the two half-waves own separate arrays).  Before (r2, early r3) every element of every window
+  // was an LDS read-modify-write: one dependent chain per query tile (later 2-4 interleaved ones) that was longer than the MFMAs beside it.
+  __shared__ float BinAcc[2][NB];
+  float binreg[3][16];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) binreg[d][r] = 0.f;
   const int lane = threadIdx.x, li = lane & 31, h = lane >> 5;
   const int ty = lane >> 3, tx = lane & 7;
   const int head = blockIdx.y;
@@ -476,14 +481,14 @@ __global__ __launch_bounds__(64) void winattn_bwd_mfma_kernel(const AttnParams p
     const float* rb = ((p.relbias2 != nullptr && (int)blockIdx.x * p.groups_per_block >= p.half_windows) ? p.relbias2 : p.relbias) + head * NB;
     for (int i = lane; i < NB; i += 64) Bias[i] = rb[i];
   }
-  for (int i = lane; i < 2 * NC * NB; i += 64) (&BinAcc[0][0][0])[i] = 0.f;
+  for (int i = lane; i < 2 * NB; i += 64) (&BinAcc[0][0])[i] = 0.f;
   // pass 1 (lane = query i = 32 ti + li; register r of key tile tj = key 32 tj + (r&3) + 8(r>>2) + 4h)
   const int off_q = ((li >> 3) + WS - 1) * NBW + ((li & 7) - 4 * h + WS - 1);
   const float* bias_q = Bias + off_q;
   // LDS byte address of this lane's bin in copy 0.  The updates go through ds_read_b32 / ds_write_b32 written out by hand: hipcc waits
   // for EVERY volatile LDS access before issuing the next one, which turns four interleaved chains back into one.
 #if defined(__HIP_DEVICE_COMPILE__)
-  const unsigned bin_q = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&BinAcc[h][0][off_q];
+  const unsigned bin_q = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&BinAcc[h][off_q];
 #else
   const unsigned bin_q = 0;
 #endif
@@ -518,8 +523,8 @@ __global__ __launch_bounds__(64) void winattn_bwd_mfma_kernel(const AttnParams p
     __syncthreads();
 
     // ---------------- pass 1: dQ and the bias bins, one query tile at a time ----------------
-#pragma unroll 1
-    for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {   // (unrolled: binreg is indexed by ti - tj)
       f32x16 sp[2], dp[2];          // [tj]: S'[j][i], dP'[j][i] for the queries i = 32 ti + li
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -552,30 +557,14 @@ __global__ __launch_bounds__(64) void winattn_bwd_mfma_kernel(const AttnParams p
         const bool msk = (edge_y && ti != tj) || (edge_x && xmask_l);
         const int boff = (4 * ti - 4 * tj) * NBW;
 #pragma unroll
-        for (int r0 = 0; r0 < 16; r0 += NC) {
-          float ds4[NC], old4[NC];
-#pragma unroll
-          for (int q = 0; q < NC; ++q) {   // the bin reads of the group first (copy q): NC chains in flight
-            const int r = r0 + q, bo = boff - (r >> 2) * NBW - (r & 3);
-            asm volatile("ds_read_b32 %0, %1" : "=v"(old4[q]) : "v"(bin_q + (unsigned)((q * NB + bo) * 4)) : "memory");
-          }
-#pragma unroll
-          for (int q = 0; q < NC; ++q) {
-            const int r = r0 + q, bo = boff - (r >> 2) * NBW - (r & 3);
-            const float a = sp[tj][r] + bias_q[bo];
-            const float pj = msk ? 0.f : exp_fast(a - lse_i);
-            ds4[q] = pj * (dp[tj][r] - dd_i);
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the reads of the group; the compiler's own LDS reads above are covered too)
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int q = 0; q < NC; ++q) {
-            const int r = r0 + q, bo = boff - (r >> 2) * NBW - (r & 3);
-            const float upd = old4[q] + ds4[q];
-            asm volatile("ds_write_b32 %0, %1" ::"v"(bin_q + (unsigned)((q * NB + bo) * 4)), "v"(upd) : "memory");
-            const float kb = Ks[32 * tj + (r & 3) + 8 * (r >> 2) + 4 * h][colc];
-            dq = mfma_nhd<B4>(ds4[q], kb, dq);
-          }
+        for (int r = 0; r < 16; ++r) {
+          const int bo = boff - (r >> 2) * NBW - (r & 3);
+          const float a = sp[tj][r] + bias_q[bo];
+          const float pj = msk ? 0.f : exp_fast(a - lse_i);
+          const float ds = pj * (dp[tj][r] - dd_i);
+          binreg[ti - tj + 1][r] += ds;
+          const float kb = Ks[32 * tj + (r & 3) + 8 * (r >> 2) + 4 * h][colc];
+          dq = mfma_nhd<B4>(ds, kb, dq);
         }
       }
       stage_rows<HD, LDQ, B4>(St, dq, ti, lane, scale);
@@ -646,12 +635,24 @@ __global__ __launch_bounds__(64) void winattn_bwd_mfma_kernel(const AttnParams p
       for (int c = 0; c < HD; c += 4) *reinterpret_cast<f32x4*>(dst + c) = *reinterpret_cast<const f32x4*>(&St[lane][c]);
     }
   }
-  // ---- per-workgroup partial of the relative-bias gradient (the two half-wave bin sets summed in order) ----
+  // ---- per-workgroup partial of the relative-bias gradient: registers -> bins (fixed order), then the two half-wave bin sets summed ----
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int bo = (4 * (d - 1)) * NBW - (r >> 2) * NBW - (r & 3);
+      float old;
+      // (hand-written: the steps of different lanes alias — lane A's bin of step k is lane B's of step k + 1 — which the compiler cannot
+      //  know; LDS executes a wave's accesses in issue order, so read -> wait -> add -> write per step is race-free)
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(bin_q + (unsigned)(bo * 4)) : "memory");
+      const float upd = old + binreg[d][r];
+      asm volatile("ds_write_b32 %0, %1" ::"v"(bin_q + (unsigned)(bo * 4)), "v"(upd) : "memory");
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
   for (int bin = lane; bin < NB; bin += 64)
-    p.dbias_partial[((size_t)blockIdx.x * p.heads + head) * NB + bin] =
-        NC == 4 ? ((BinAcc[0][0][bin] + BinAcc[0][1][bin]) + (BinAcc[0][2][bin] + BinAcc[0][NC - 1][bin])) + ((BinAcc[1][0][bin] + BinAcc[1][1][bin]) + (BinAcc[1][2][bin] + BinAcc[1][NC - 1][bin]))
-                : (BinAcc[0][0][bin] + BinAcc[0][1][bin]) + (BinAcc[1][0][bin] + BinAcc[1][1][bin]);
+    p.dbias_partial[((size_t)blockIdx.x * p.heads + head) * NB + bin] = BinAcc[0][bin] + BinAcc[1][bin];
 }
 
 // out[i] (+)= sum_b partial[b][i]; 32 columns x 8 interleaved block groups per workgroup, combined in a fixed tree
