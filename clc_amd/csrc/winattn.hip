@@ -456,9 +456,9 @@ __global__ __launch_bounds__(64) void winattn_bwd_kernel(const AttnParams p) {
 //           (keys j and j + 4) own separate bin arrays, summed at the end: race-free and in a fixed order;
 //   pass 2, lane = key:   S = Q K^T and dP = dO V^T -> P and dS are the A operands of dV = P^T dO and dK = dS^T Q.
 template <int HD, bool B4>
-__global__ __launch_bounds__(64) void winattn_bwd_mfma_kernel(const AttnParams p) {
+__global__ __launch_bounds__(64, 2) void winattn_bwd_mfma_kernel(const AttnParams p) {
   constexpr int T = 64, WS = 8, LDQ = HD + 4, NBW = 2 * WS - 1, NB = NBW * NBW;
-  __shared__ __attribute__((aligned(16))) float Qs[T][LDQ], Ks[T][LDQ], Vs[T][LDQ], Ds[T][LDQ], St[T][LDQ];
+  __shared__ __attribute__((aligned(16))) float Qs[T][LDQ], Ks[T][LDQ], Vs[T][LDQ], Ds[T][LDQ], St[T][LDQ], St2[T][LDQ];
   __shared__ float Lse[T], Dd[T], Bias[NB];
   // Relative-bias gradient.  In the S' register layout the bin of element (tile pair (ti, tj), register r) of a lane is
   //   off_q(lane) + (4 (ti - tj)) * NBW - (r >> 2) * NBW - (r & 3)
@@ -466,7 +466,10 @@ __global__ __launch_bounds__(64) void winattn_bwd_mfma_kernel(const AttnParams p
   // the windows, and the bins in LDS are touched once per workgroup at the end (48 read-modify-write steps; inside a half-wave the 32
   // lanes of a step hit 32 distinct bins, the two half-waves own separate arrays).  Before (r2, early r3) every element of every window
   // was an LDS read-modify-write: one dependent chain per query tile (later 2-4 interleaved ones) that was longer than the MFMAs beside it.
-  __shared__ float BinAcc[2][NB];
+  // (The bins live in the dV staging image, which is dead by then: with their own 1.8 KB the head_dim-8 kernel was 1 KB over the 20 KB that
+  //  lets eight workgroups share a CU — two waves per SIMD, one round for the 2 048 workgroups of a 128x128 map.)
+  static_assert(2 * NB <= T * LDQ, "the relative-bias bins must fit the dV staging image");
+  float* const BinAcc = &St2[0][0];   // [2][NB]
   float binreg[3][16];
 #pragma unroll
   for (int d = 0; d < 3; ++d)
@@ -481,14 +484,13 @@ __global__ __launch_bounds__(64) void winattn_bwd_mfma_kernel(const AttnParams p
     const float* rb = ((p.relbias2 != nullptr && (int)blockIdx.x * p.groups_per_block >= p.half_windows) ? p.relbias2 : p.relbias) + head * NB;
     for (int i = lane; i < NB; i += 64) Bias[i] = rb[i];
   }
-  for (int i = lane; i < 2 * NB; i += 64) (&BinAcc[0][0])[i] = 0.f;
   // pass 1 (lane = query i = 32 ti + li; register r of key tile tj = key 32 tj + (r&3) + 8(r>>2) + 4h)
   const int off_q = ((li >> 3) + WS - 1) * NBW + ((li & 7) - 4 * h + WS - 1);
   const float* bias_q = Bias + off_q;
   // LDS byte address of this lane's bin in copy 0.  The updates go through ds_read_b32 / ds_write_b32 written out by hand: hipcc waits
   // for EVERY volatile LDS access before issuing the next one, which turns four interleaved chains back into one.
 #if defined(__HIP_DEVICE_COMPILE__)
-  const unsigned bin_q = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&BinAcc[h][off_q];
+  const unsigned bin_q = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)(&St2[0][0] + h * NB + off_q);
 #else
   const unsigned bin_q = 0;
 #endif
@@ -522,49 +524,46 @@ __global__ __launch_bounds__(64) void winattn_bwd_mfma_kernel(const AttnParams p
     Dd[lane] = dsum;
     __syncthreads();
 
-    // ---------------- pass 1: dQ and the bias bins, one query tile at a time ----------------
+    // ---------------- pass 1: dQ and the bias bins, one (query tile, key tile) pair at a time ----------------
+    // (one pair's S' and dP' live at a time: the saved log-sum-exp makes the key tiles independent.  Holding both key tiles — and,
+    //  in pass 2, both tiles' dK / dV until the end — took 316-400 registers: one wave per SIMD, every LDS / exp latency exposed.)
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {   // (unrolled: binreg is indexed by ti - tj)
-      f32x16 sp[2], dp[2];          // [tj]: S'[j][i], dP'[j][i] for the queries i = 32 ti + li
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { sp[t][r] = 0.f; dp[t][r] = 0.f; }
-#pragma unroll
-      for (int c0 = 0; c0 < HD; c0 += 8) {
-        const f32x4 qb = *reinterpret_cast<const f32x4*>(&Qs[32 * ti + li][c0 + 4 * h]);
-        const f32x4 db = *reinterpret_cast<const f32x4*>(&Ds[32 * ti + li][c0 + 4 * h]);
-        f32x4 ka[2], va[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          ka[t] = *reinterpret_cast<const f32x4*>(&Ks[32 * t + li][c0 + 4 * h]);
-          va[t] = *reinterpret_cast<const f32x4*>(&Vs[32 * t + li][c0 + 4 * h]);
-        }
-#pragma unroll
-        for (int ss = 0; ss < 4; ++ss)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            sp[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[t][ss], qb[ss], sp[t], 0, 0, 0);
-            dp[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[t][ss], db[ss], dp[t], 0, 0, 0);
-          }
-      }
       const float lse_i = Lse[32 * ti + li], dd_i = Dd[32 * ti + li];
       f32x16 dq;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[r] = 0.f;
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj) {
+        f32x16 sp, dp;                // S'[j][i], dP'[j][i] for the queries i = 32 ti + li and the keys of tile tj
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sp[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int c0 = 0; c0 < HD; c0 += 8) {
+          const f32x4 qb = *reinterpret_cast<const f32x4*>(&Qs[32 * ti + li][c0 + 4 * h]);
+          const f32x4 db = *reinterpret_cast<const f32x4*>(&Ds[32 * ti + li][c0 + 4 * h]);
+          const f32x4 ka = *reinterpret_cast<const f32x4*>(&Ks[32 * tj + li][c0 + 4 * h]);
+          const f32x4 va = *reinterpret_cast<const f32x4*>(&Vs[32 * tj + li][c0 + 4 * h]);
+#pragma unroll
+          for (int ss = 0; ss < 4; ++ss) {
+            sp = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[ss], qb[ss], sp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(va[ss], db[ss], dp, 0, 0, 0);
+          }
+        }
         const bool msk = (edge_y && ti != tj) || (edge_x && xmask_l);
         const int boff = (4 * ti - 4 * tj) * NBW;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int bo = boff - (r >> 2) * NBW - (r & 3);
-          const float a = sp[tj][r] + bias_q[bo];
+          const float a = sp[r] + bias_q[bo];
           const float pj = msk ? 0.f : exp_fast(a - lse_i);
-          const float ds = pj * (dp[tj][r] - dd_i);
+          const float ds = pj * (dp[r] - dd_i);
           binreg[ti - tj + 1][r] += ds;
           const float kb = Ks[32 * tj + (r & 3) + 8 * (r >> 2) + 4 * h][colc];
           dq = mfma_nhd<B4>(ds, kb, dq);
+          // (a fence per 4 registers: left alone the scheduler hoists all 16 steps' LDS reads and exps to the top of the pair, 380+
+          //  live registers — and with the register budget of two waves per SIMD it spills instead of hoisting less)
+          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
       }
       stage_rows<HD, LDQ, B4>(St, dq, ti, lane, scale);
@@ -576,66 +575,60 @@ __global__ __launch_bounds__(64) void winattn_bwd_mfma_kernel(const AttnParams p
       for (int c = 0; c < HD; c += 4) *reinterpret_cast<f32x4*>(dqp + c) = *reinterpret_cast<const f32x4*>(&St[lane][c]);
     }
 
-    // ---------------- pass 2: dK and dV, one key tile at a time ----------------
-    f32x16 dk[2], dvv[2];
+    // ---------------- pass 2: dK and dV, one (key tile, query tile) pair at a time ----------------
+    __syncthreads();   // (the dQ rows have been read out of St: this pass stages dK there and dV in St2)
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {   // (unrolled: dk / dvv must stay in registers)
-      f32x16 s2[2], dp2[2];         // [ti]: S[i][j], dP[i][j] for the keys j = 32 tj + li
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s2[t][r] = 0.f; dp2[t][r] = 0.f; }
-#pragma unroll
-      for (int c0 = 0; c0 < HD; c0 += 8) {
-        const f32x4 kb = *reinterpret_cast<const f32x4*>(&Ks[32 * tj + li][c0 + 4 * h]);
-        const f32x4 vb = *reinterpret_cast<const f32x4*>(&Vs[32 * tj + li][c0 + 4 * h]);
-        f32x4 qa[2], da[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          qa[t] = *reinterpret_cast<const f32x4*>(&Qs[32 * t + li][c0 + 4 * h]);
-          da[t] = *reinterpret_cast<const f32x4*>(&Ds[32 * t + li][c0 + 4 * h]);
-        }
-#pragma unroll
-        for (int ss = 0; ss < 4; ++ss)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            s2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[t][ss], kb[ss], s2[t], 0, 0, 0);
-            dp2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[t][ss], vb[ss], dp2[t], 0, 0, 0);
-          }
-      }
+    for (int tj = 0; tj < 2; ++tj) {
       f32x16 dkt, dvt;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dkt[r] = 0.f; dvt[r] = 0.f; }
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti) {
+        f32x16 s2, dp2;               // S[i][j], dP[i][j] for the keys j = 32 tj + li and the queries of tile ti
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s2[r] = 0.f; dp2[r] = 0.f; }
+#pragma unroll
+        for (int c0 = 0; c0 < HD; c0 += 8) {
+          const f32x4 kb = *reinterpret_cast<const f32x4*>(&Ks[32 * tj + li][c0 + 4 * h]);
+          const f32x4 vb = *reinterpret_cast<const f32x4*>(&Vs[32 * tj + li][c0 + 4 * h]);
+          const f32x4 qa = *reinterpret_cast<const f32x4*>(&Qs[32 * ti + li][c0 + 4 * h]);
+          const f32x4 da = *reinterpret_cast<const f32x4*>(&Ds[32 * ti + li][c0 + 4 * h]);
+#pragma unroll
+          for (int ss = 0; ss < 4; ++ss) {
+            s2 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[ss], kb[ss], s2, 0, 0, 0);
+            dp2 = __builtin_amdgcn_mfma_f32_32x32x2f32(da[ss], vb[ss], dp2, 0, 0, 0);
+          }
+        }
         const bool msk = (edge_y && ti != tj) || (edge_x && xmask_l);
         const int boff = (4 * ti - 4 * tj) * NBW;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int iq = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * h;    // the query of this register (half-wave uniform)
-          const float a = s2[ti][r] + bias_k[boff + (r >> 2) * NBW + (r & 3)];
+          const float a = s2[r] + bias_k[boff + (r >> 2) * NBW + (r & 3)];
           const float pij = msk ? 0.f : exp_fast(a - Lse[iq]);
-          const float ds = pij * (dp2[ti][r] - Dd[iq]);
+          const float ds = pij * (dp2[r] - Dd[iq]);
           const float dob = Ds[iq][colc], qb = Qs[iq][colc];
           dvt = mfma_nhd<B4>(pij, dob, dvt);
           dkt = mfma_nhd<B4>(ds, qb, dkt);
+          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
       }
-      dk[tj] = dkt; dvv[tj] = dvt;
+      stage_rows<HD, LDQ, B4>(St, dkt, tj, lane, 1.f);
+      stage_rows<HD, LDQ, B4>(St2, dvt, tj, lane, 1.f);
     }
-    // rows out: dK, then dV, through the staging image
+    __syncthreads();
+    {
+      float* dst = p.dqkv + (size_t)pix * p.lddq + p.C + head * HD;
 #pragma unroll
-    for (int which = 0; which < 2; ++which) {
-      __syncthreads();
-#pragma unroll
-      for (int tj = 0; tj < 2; ++tj) stage_rows<HD, LDQ, B4>(St, which == 0 ? dk[tj] : dvv[tj], tj, lane, 1.f);
-      __syncthreads();
-      float* dst = p.dqkv + (size_t)pix * p.lddq + (which + 1) * p.C + head * HD;
-#pragma unroll
-      for (int c = 0; c < HD; c += 4) *reinterpret_cast<f32x4*>(dst + c) = *reinterpret_cast<const f32x4*>(&St[lane][c]);
+      for (int c = 0; c < HD; c += 4) {
+        *reinterpret_cast<f32x4*>(dst + c) = *reinterpret_cast<const f32x4*>(&St[lane][c]);
+        *reinterpret_cast<f32x4*>(dst + p.C + c) = *reinterpret_cast<const f32x4*>(&St2[lane][c]);
+      }
     }
   }
   // ---- per-workgroup partial of the relative-bias gradient: registers -> bins (fixed order), then the two half-wave bin sets summed ----
+  __syncthreads();
+  for (int i = lane; i < 2 * NB; i += 64) BinAcc[i] = 0.f;
   __syncthreads();
 #pragma unroll
   for (int d = 0; d < 3; ++d)
@@ -652,7 +645,7 @@ __global__ __launch_bounds__(64) void winattn_bwd_mfma_kernel(const AttnParams p
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
   for (int bin = lane; bin < NB; bin += 64)
-    p.dbias_partial[((size_t)blockIdx.x * p.heads + head) * NB + bin] = BinAcc[0][bin] + BinAcc[1][bin];
+    p.dbias_partial[((size_t)blockIdx.x * p.heads + head) * NB + bin] = BinAcc[bin] + BinAcc[NB + bin];
 }
 
 // out[i] (+)= sum_b partial[b][i]; 32 columns x 8 interleaved block groups per workgroup, combined in a fixed tree
