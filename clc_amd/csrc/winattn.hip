@@ -186,7 +186,7 @@ __device__ __forceinline__ void stage_rows(float (*St)[LDQ], const f32x16& acc, 
 }
 
 template <int HD, bool B4>
-__global__ __launch_bounds__(64) void winattn_fwd_mfma_kernel(const AttnParams p) {
+__global__ __launch_bounds__(64, 4) void winattn_fwd_mfma_kernel(const AttnParams p) {
   constexpr int T = 64, WS = 8, LDQ = HD + 4, NBW = 2 * WS - 1, NB = NBW * NBW;
   __shared__ __attribute__((aligned(16))) float Qs[T][LDQ], Ks[T][LDQ], Vs[T][LDQ];
   __shared__ float Bias[NB];
