@@ -1,12 +1,12 @@
 #!/bin/bash
-# step-level A/B of one tuning setting on ONE box: bash tools/ab_tuning.sh "16:0" "16:1" [rounds]
+# step-level A/B of several tuning settings on ONE box: bash tools/ab_tuning.sh rounds "16:0" "16:1" "16:3" ...
 set -u -o pipefail
 R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT}
 cd $R
-A=$1; B=$2; N=${3:-2}
+N=$1; shift
 mkdir -p gpurun_out/ab
 for i in $(seq 1 $N); do
-  for v in "$A" "$B"; do
+  for v in "$@"; do
     CLC_TUNING=$v timeout -k 10 200 python bench.py --steps 30 --warmup 5 --no-roofline --no-cpu-baseline --no-reduced --no-parity > gpurun_out/ab/step.json 2> gpurun_out/ab/step.err || { tail -20 gpurun_out/ab/step.err; exit 1; }
     python - <<PY
 import json
