@@ -31,6 +31,7 @@ struct AttnParams {
   int windows_total;       // B*nwin; the last group may be partial (its surplus slots recompute window 0 and store nothing)
   int groups_per_block;
   const float* relbias2; int half_windows;   // paired modules: windows >= half_windows use the second bias table
+  int split;               // backward MFMA kernel on small grids: two workgroups per window group, one query / key tile each
 };
 
 // pixel index (in the un-rolled image) of token (ty,tx) of window (wy,wx)
@@ -480,8 +481,12 @@ __global__ __launch_bounds__(64, 2) void winattn_bwd_mfma_kernel(const AttnParam
   const int head = blockIdx.y;
   const float scale = rsqrtf((float)HD);
   const int nwin = p.nwin_y * p.nwin_x;
+  // Small grids (the 16x16 latent maps: 512 window-heads for 256 CUs) are latency-bound single-wave workgroups: there a window group
+  // is shared by TWO workgroups — `half` does query tile `half` in pass 1 (its 32 rows of dQ) and key tile `half` in pass 2 (its 32 rows
+  // of dK / dV) and contributes its own partial row of the relative-bias gradient.  Both load the whole window.
+  const int bxi = p.split ? (int)blockIdx.x >> 1 : (int)blockIdx.x, half = p.split ? (int)blockIdx.x & 1 : -1;
   {   // (paired modules: the launcher makes sure a workgroup's windows all belong to one module)
-    const float* rb = ((p.relbias2 != nullptr && (int)blockIdx.x * p.groups_per_block >= p.half_windows) ? p.relbias2 : p.relbias) + head * NB;
+    const float* rb = ((p.relbias2 != nullptr && bxi * p.groups_per_block >= p.half_windows) ? p.relbias2 : p.relbias) + head * NB;
     for (int i = lane; i < NB; i += 64) Bias[i] = rb[i];
   }
   // pass 1 (lane = query i = 32 ti + li; register r of key tile tj = key 32 tj + (r&3) + 8(r>>2) + 4h)
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(64, 2) void winattn_bwd_mfma_kernel(const AttnParam
   const bool xmask_l = ((li & 7) < 4) != (h == 0);
   const int colc = li & (HD - 1);               // lanes with li >= HD re-read a valid column of the B operand; their results are not stored
   for (int gi = 0; gi < p.groups_per_block; ++gi) {
-    const int grp = blockIdx.x * p.groups_per_block + gi;
+    const int grp = bxi * p.groups_per_block + gi;
     if (grp >= p.groups_total) break;
     const int widx = grp;
     const int b = widx / nwin, wr = widx - b * nwin, wy = wr / p.nwin_x, wx = wr - wy * p.nwin_x;
@@ -529,6 +534,7 @@ __global__ __launch_bounds__(64, 2) void winattn_bwd_mfma_kernel(const AttnParam
     //  in pass 2, both tiles' dK / dV until the end — took 316-400 registers: one wave per SIMD, every LDS / exp latency exposed.)
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {   // (unrolled: binreg is indexed by ti - tj)
+      if (half >= 0 && ti != half) continue;
       const float lse_i = Lse[32 * ti + li], dd_i = Dd[32 * ti + li];
       f32x16 dq;
 #pragma unroll
@@ -571,14 +577,17 @@ __global__ __launch_bounds__(64, 2) void winattn_bwd_mfma_kernel(const AttnParam
     __syncthreads();
     {
       float* dqp = p.dqkv + (size_t)pix * p.lddq + head * HD;
+      if (half < 0 || (lane >> 5) == half) {
 #pragma unroll
-      for (int c = 0; c < HD; c += 4) *reinterpret_cast<f32x4*>(dqp + c) = *reinterpret_cast<const f32x4*>(&St[lane][c]);
+        for (int c = 0; c < HD; c += 4) *reinterpret_cast<f32x4*>(dqp + c) = *reinterpret_cast<const f32x4*>(&St[lane][c]);
+      }
     }
 
     // ---------------- pass 2: dK and dV, one (key tile, query tile) pair at a time ----------------
     __syncthreads();   // (the dQ rows have been read out of St: this pass stages dK there and dV in St2)
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) {
+      if (half >= 0 && tj != half) continue;
       f32x16 dkt, dvt;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dkt[r] = 0.f; dvt[r] = 0.f; }
@@ -619,10 +628,12 @@ __global__ __launch_bounds__(64, 2) void winattn_bwd_mfma_kernel(const AttnParam
     __syncthreads();
     {
       float* dst = p.dqkv + (size_t)pix * p.lddq + p.C + head * HD;
+      if (half < 0 || (lane >> 5) == half) {
 #pragma unroll
-      for (int c = 0; c < HD; c += 4) {
-        *reinterpret_cast<f32x4*>(dst + c) = *reinterpret_cast<const f32x4*>(&St[lane][c]);
-        *reinterpret_cast<f32x4*>(dst + p.C + c) = *reinterpret_cast<const f32x4*>(&St2[lane][c]);
+        for (int c = 0; c < HD; c += 4) {
+          *reinterpret_cast<f32x4*>(dst + c) = *reinterpret_cast<const f32x4*>(&St[lane][c]);
+          *reinterpret_cast<f32x4*>(dst + p.C + c) = *reinterpret_cast<const f32x4*>(&St2[lane][c]);
+        }
       }
     }
   }
@@ -675,7 +686,11 @@ int check_geom(const char* who, int B, int H, int W, int C, int heads, int ws, i
   return 0;
 }
 
-void fill(AttnParams& p, int B, int H, int W, int C, int heads, int ws, int shift, int target_blocks, bool paired = false) {
+static bool attn_use_mfma() {
+  static const int use_mfma = getenv("CLC_ATTN_MFMA") ? atoi(getenv("CLC_ATTN_MFMA")) : 1;   // 0: VALU kernels (A/B knob)
+  return use_mfma != 0;
+}
+void fill(AttnParams& p, int B, int H, int W, int C, int heads, int ws, int shift, int target_blocks, bool paired = false, bool bwd = false) {
   p.B = B; p.H = H; p.W = W; p.C = C; p.heads = heads; p.ws = ws; p.shift = shift;
   p.nwin_y = H / ws; p.nwin_x = W / ws;
   const int T = ws * ws, G = 64 / T;
@@ -690,6 +705,9 @@ void fill(AttnParams& p, int B, int H, int W, int C, int heads, int ws, int shif
     while (half_groups % per) --per;
   }
   p.groups_per_block = per;
+  // backward on a grid that leaves most wave slots empty: two workgroups per window group (winattn_bwd_mfma_kernel)
+  const int nbx = (p.groups_total + per - 1) / per;
+  p.split = (bwd && ws == 8 && attn_use_mfma() && clc_tuning[CLC_TUNE_ATTN_SPLIT] && (long)nbx * heads <= 1024) ? 1 : 0;
 }
 
 #define DISPATCH(KERNEL, T_, hd, grid, p, st)                                                          \
@@ -703,8 +721,8 @@ void fill(AttnParams& p, int B, int H, int W, int C, int heads, int ws, int shif
 
 static int bwd_blocks_x(int B, int H, int W, int heads, int ws, bool paired) {
   AttnParams p{};
-  fill(p, B, H, W, heads /*C unused*/, heads, ws, 0, 2048, paired);
-  return (p.groups_total + p.groups_per_block - 1) / p.groups_per_block;
+  fill(p, B, H, W, heads /*C unused*/, heads, ws, 0, 2048, paired, true);
+  return ((p.groups_total + p.groups_per_block - 1) / p.groups_per_block) * (p.split ? 2 : 1);
 }
 
 extern "C" int clc_winattn_bwd_blocks(int B, int H, int W, int heads, int ws, int paired) { return bwd_blocks_x(B, H, W, heads, ws, paired != 0); }
@@ -771,12 +789,12 @@ static int winattn_bwd_impl(const float* dout, int lddo, const float* qkv, int l
   p.qkv = qkv; p.relbias = relbias; p.dout = dout; p.dqkv = dqkv; p.dbias_partial = (float*)wsb;
   p.out = const_cast<float*>(out); p.lse = const_cast<float*>(lse);
   p.ldq = ldq; p.lddo = lddo; p.lddq = lddq; p.ldo = ldo;
-  fill(p, B, H, W, C, heads, ws, shift, 2048, relbias2 != nullptr);
+  fill(p, B, H, W, C, heads, ws, shift, 2048, relbias2 != nullptr, true);
   p.relbias2 = relbias2;
-  const int nbx = (p.groups_total + p.groups_per_block - 1) / p.groups_per_block;
+  const int nbx = ((p.groups_total + p.groups_per_block - 1) / p.groups_per_block) * (p.split ? 2 : 1);   // (= clc_winattn_bwd_blocks)
   dim3 grid(nbx, heads);
   const int hd = C / heads;
-  static const int use_mfma = getenv("CLC_ATTN_MFMA") ? atoi(getenv("CLC_ATTN_MFMA")) : 1;   // 0: VALU kernels (A/B knob)
+  const bool use_mfma = attn_use_mfma();
   if (ws == 8 && use_mfma) {
     const int m4 = clc_tuning[CLC_TUNE_ATTN_4B];
     if (hd == 8) { if (m4 & 2) hipLaunchKernelGGL((winattn_bwd_mfma_kernel<8, true>), grid, dim3(64), 0, (hipStream_t)stream, p); else hipLaunchKernelGGL((winattn_bwd_mfma_kernel<8, false>), grid, dim3(64), 0, (hipStream_t)stream, p); }

@@ -4,7 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from clc_amd import ops, lib
 dev = torch.device("cuda:0"); CL = torch.channels_last; L = lib.load()
-for (N, C, H, W, heads, ws) in ((8, 64, 128, 128, 8, 8), (8, 64, 64, 64, 4, 8), (16, 128, 16, 16, 8, 8)):
+# settings: name -> (tuning key, value); default A/B: the two-workgroups-per-window backward on small grids (key 18)
+KEYS = {"16:0": (16, 0), "16:7": (16, 7), "18:0": (18, 0), "18:1": (18, 1)}
+SETTINGS = sys.argv[1:] or ["18:0", "18:1"]
+for (N, C, H, W, heads, ws) in ((8, 64, 128, 128, 8, 8), (8, 64, 64, 64, 4, 8), (8, 64, 32, 32, 2, 8), (16, 128, 16, 16, 8, 8)):
     nb = 4
     g = torch.Generator().manual_seed(0)
     qkvs = [torch.randn(N, 3 * C, H, W, generator=g).to(dev).contiguous(memory_format=CL) for _ in range(nb)]
@@ -27,8 +30,8 @@ for (N, C, H, W, heads, ws) in ((8, 64, 128, 128, 8, 8), (8, 64, 64, 64, 4, 8), 
     line = f"C{C} h{heads} {N}x{H}x{W}:"
     for label, fn in (("fwd", fwd), ("bwd", bwd)):
         graphs = []
-        for key in (0, 7):
-            L.clc_set_tuning(16, key)
+        for key in SETTINGS:
+            L.clc_set_tuning(*KEYS[key])
             fn(0); torch.cuda.synchronize()
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):
@@ -42,6 +45,7 @@ for (N, C, H, W, heads, ws) in ((8, 64, 128, 128, 8, 8), (8, 64, 64, 64, 4, 8), 
                 e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1) * 1e3 / 20)
         for key, gr, ts in graphs:
-            line += f"  {label}[16:{key}] {sorted(ts)[3]:7.1f} us"
+            line += f"  {label}[{key}] {sorted(ts)[3]:7.1f} us"
     print(line, flush=True)
 L.clc_set_tuning(16, 3)
+L.clc_set_tuning(18, 1)
