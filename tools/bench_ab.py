@@ -19,6 +19,7 @@ SHAPES = [  # N, Cin, H, W, Cout, ks, epilogue tensors (res, pre)
     (16, 640, 16, 16, 224, 3, 0, 0), (16, 512, 16, 16, 224, 3, 0, 0), (16, 384, 16, 16, 224, 3, 0, 0), (8, 704, 16, 16, 224, 3, 0, 0), (8, 448, 16, 16, 224, 3, 0, 0),   # 15..19: slice-parameter nets
     (16, 128, 16, 16, 512, 1, 0, 1), (16, 512, 16, 16, 128, 1, 1, 0), (16, 128, 16, 16, 384, 1, 0, 0), (16, 224, 16, 16, 128, 3, 0, 0), (16, 128, 16, 16, 128, 1, 1, 0), (16, 128, 16, 16, 64, 3, 0, 0),   # 20..25: slice-loop Swin / cc layers
     (8, 128, 128, 128, 12, 3, 0, 0),   # 26: the 12-channel tail of g_s
+    (8, 64, 64, 64, 64, 3, 0, 0), (8, 64, 64, 64, 64, 3, 1, 0),   # 27, 28: 64-channel 3x3 layers on the 64x64 maps
 ]
 
 
