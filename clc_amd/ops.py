@@ -742,7 +742,7 @@ class _ConvFn(Function):
         ctx.park_dx = park_dx   # GradFold that takes this layer's input gradient (a sibling layer on the same input adds it in its epilogue)
         wk2 = to_kernel_weight(w2) if w2 is not None else None
         wkx = ((to_kernel_weight(w3), b3), (to_kernel_weight(w4), b4)) if w3 is not None else None
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = _recording(ctx)
         # the activation derivative needs the pre-activation whenever the output does not determine it
         save_pre = need_grad and (act == ACT_GELU or (act in (ACT_LRELU, ACT_RELU, ACT_HALFTANH) and res is not None and not res_first))
         N, _, H, W = x.shape
@@ -894,8 +894,26 @@ def conv2d(x, w, b=None, *, stride=1, act=ACT_NONE, res=None, res_scale=1.0, shu
     (w2, b2) [+ wx = ((w3, b3), (w4, b4))]: 2 [4] filter sets on the halves [quarters] of the batch, one launch."""
     ks = w.shape[2] if w.dim() == 4 else 1
     (w3, b3), (w4, b4) = wx if wx is not None else ((None, None), (None, None))
+    _note_grad_mode()
     return _ConvFn.apply(x, w, b, res, ks, stride, act, float(res_scale), bool(shuffle), bool(res_first), w2, b2, fold_in, fold_out, out,
                          grad_slot, park_dx, gate_in, gate_out, w3, b3, w4, b4)
+
+
+# Inside Function.forward grad mode is always off and ctx.needs_input_grad only reflects the inputs' requires_grad flags — under
+# torch.no_grad() with parameters that require grad (model.eval() inference, compress() / decompress()) it still says True.  The public
+# wrappers therefore note the caller's grad mode right before .apply(); the forwards save activations for backward — and, for the
+# convolutions, allow a batch-dependent summation order (clc_conv_desc.batch_variant_ok) — only when a graph is really being recorded.
+import threading as _threading
+
+_GRAD_MODE = _threading.local()
+
+
+def _note_grad_mode():
+    _GRAD_MODE.on = torch.is_grad_enabled()
+
+
+def _recording(ctx) -> bool:
+    return bool(getattr(_GRAD_MODE, "on", True)) and any(ctx.needs_input_grad)
 
 
 # The [Cin][T][Cout] filter images clc_amd.train.FilterTransposer attaches to the parameters (`_clc_wt`) are refreshed at the START of an
@@ -1000,6 +1018,7 @@ def residual_unit(x, units):
 
 def linear(x, w, b=None, *, act=ACT_NONE, res=None, w2=None, b2=None, fold_in=None, fold_out=None, out=None, gate_in=None, gate_out=None):
     """nn.Linear on channels (tokens are pixels): x [N,Cin,H,W] pixel-major, w [Cout,Cin]."""
+    _note_grad_mode()
     return _ConvFn.apply(x, w, b, res, 1, 1, act, 1.0, False, False, w2, b2, fold_in, fold_out, out, None, None, gate_in, gate_out)
 
 
@@ -1279,7 +1298,7 @@ class _GDNFn(Function):
     def forward(ctx, x, gamma, beta, res, inverse):
         _own(ctx)
         N, Cc, H, W = x.shape
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = _recording(ctx)
         v = new_act(N, Cc, H, W, x) if need_grad else None
         g = gamma if gamma.is_contiguous() else gamma.contiguous()
         y = conv_raw(x, g, beta, ks=1, in_op=IN_SQUARE, norm=NORM_IGDN if inverse else NORM_GDN, mul=x, y_pre=v, res=res)
@@ -1310,6 +1329,7 @@ class _GDNFn(Function):
 
 
 def gdn(x, gamma_eff, beta_eff, inverse=False, res=None):
+    _note_grad_mode()
     return _GDNFn.apply(x, gamma_eff, beta_eff, res, bool(inverse))
 
 
@@ -1323,7 +1343,7 @@ class _GDNParamFn(Function):
     def forward(ctx, x, gamma, beta, res, inverse, gamma_bound, beta_bound, pedestal, gamma2=None, beta2=None):
         _own(ctx)
         N, Cc, H, W = x.shape
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = _recording(ctx)
         sets = [(gamma, beta)] + ([(gamma2, beta2)] if gamma2 is not None else [])
         eff = []
         for g, b in sets:
@@ -1395,6 +1415,7 @@ class _GDNParamFn(Function):
 
 
 def gdn_param(x, gamma, beta, gamma_bound, beta_bound, pedestal, inverse=False, res=None, gamma2=None, beta2=None):
+    _note_grad_mode()
     return _GDNParamFn.apply(x, gamma, beta, res, bool(inverse), float(gamma_bound), float(beta_bound), float(pedestal), gamma2, beta2)
 
 
@@ -1412,7 +1433,7 @@ class _LayerNormFn(Function):
         rows = N * H * W
         y = new_act(N, Cc, H, W, x)
         ctx.fold_in = fold_in
-        need = any(ctx.needs_input_grad)
+        need = _recording(ctx)
         mean = torch.empty(rows, device=x.device, dtype=torch.float32) if need else None
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if need else None
         mp, rp = (mean.data_ptr(), rstd.data_ptr()) if need else (None, None)
@@ -1472,6 +1493,7 @@ class _LayerNormFn(Function):
 
 
 def layernorm(x, gamma, beta, fold_in=None, grad_slot=None, gamma2=None, beta2=None):
+    _note_grad_mode()
     return _LayerNormFn.apply(x, gamma, beta, fold_in, grad_slot, gamma2, beta2)
 
 
@@ -1488,7 +1510,7 @@ class _WinAttnFn(Function):
         qkv, qp, N, H, W, C3, ldq = nhwc(qkv)
         Cc = C3 // 3
         out = new_act(N, Cc, H, W, qkv)
-        need = any(ctx.needs_input_grad)
+        need = _recording(ctx)
         lse = torch.empty(N * H * W * heads, device=qkv.device, dtype=torch.float32) if need else None
         tabs = [relbias] + ([relbias2] if relbias2 is not None else [])
         rbs = [t if t.is_contiguous() else t.contiguous() for t in tabs]
@@ -1541,6 +1563,7 @@ class _WinAttnFn(Function):
 
 
 def window_attention(qkv, relbias, heads, ws, shift, relbias2=None):
+    _note_grad_mode()
     return _WinAttnFn.apply(qkv, relbias, int(heads), int(ws), bool(shift), relbias2)
 
 

@@ -801,3 +801,61 @@ def test_fused_residual_unit_matches_three_layers(dev, sets, n):
     with torch.no_grad():
         y1 = units[0](x.detach()[:1].contiguous(memory_format=torch.channels_last))
     assert torch.equal(y1, y[:1].detach())
+
+
+def test_window_attention_kernel_variants_agree(dev):
+    """The round-3 variants of the 8x8-window kernels — 4-block MFMAs for the N = head_dim products (tuning key 16, bit mask) and the
+    two-workgroups-per-window backward of small grids (key 18) — against the plain variants on the same inputs: same values to fp32
+    summation order, forward, dqkv and the relative-bias gradient, for head_dim 8 and 16, shifted windows."""
+    from clc_amd import lib as _clib
+    from clc_amd import ops
+
+    L = _clib.load()
+    for C, heads in ((64, 8), (64, 4)):
+        qkv = _dev(_rand((2, 3 * C, 32, 32), 11), dev, grad=True)
+        rb = _dev(_rand((heads, 15, 15), 12, 0.5), dev, grad=True)
+        gy = _dev(_rand((2, C, 32, 32), 13), dev)
+        res = {}
+        old16, old18 = L.clc_set_tuning(16, 0), L.clc_set_tuning(18, 0)
+        try:
+            for k16, k18 in ((0, 0), (7, 0), (7, 1), (0, 1)):
+                L.clc_set_tuning(16, k16)
+                L.clc_set_tuning(18, k18)
+                y = ops.window_attention(qkv, rb, heads, 8, True)
+                gq, gb = torch.autograd.grad(y, [qkv, rb], gy)
+                res[(k16, k18)] = (y.detach().clone(), gq.clone(), gb.clone())
+        finally:
+            L.clc_set_tuning(16, old16)
+            L.clc_set_tuning(18, old18)
+        base = res[(0, 0)]
+        for key, r in res.items():
+            for name, a, b in zip(("fwd", "dqkv", "drelbias"), r, base):
+                assert (a - b).abs().max().item() <= 2e-5 * max(1e-6, b.abs().max().item()), (C, heads, key, name)
+
+
+def test_training_forward_long_k_layers_on_128x128_tiles(dev):
+    """clc_conv_desc.batch_variant_ok (set for forward passes that record an autograd graph): the slice-parameter nets' long-K 3x3 layers
+    leave the split-K family for 128x128 LDS tiles with a grid-sized K split (fixed-order finish launch: bias, activation, saved
+    pre-activation, two filter sets).  Same values as the inference path to fp32 summation order and as torch; run-to-run bit-identical;
+    the inference path (no grad) is untouched, so an image's bits there do not depend on the batch."""
+    import torch.nn.functional as F
+    from clc_amd import ops
+
+    g = torch.Generator().manual_seed(21)
+    x = (torch.randn(16, 640, 16, 16, generator=g) * 0.5).to(dev).contiguous(memory_format=torch.channels_last)
+    w1 = (torch.randn(224, 640, 3, 3, generator=g) * 0.02).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w2 = (torch.randn(224, 640, 3, 3, generator=g) * 0.02).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    b1, b2 = torch.randn(224, generator=g).to(dev).requires_grad_(True), torch.randn(224, generator=g).to(dev).requires_grad_(True)
+    xg = x.clone().requires_grad_(True)
+    y_train = ops.conv2d(xg, w1, b1, act=ops.ACT_LRELU, w2=w2, b2=b2)          # records a graph -> batch_variant_ok
+    y_again = ops.conv2d(xg, w1, b1, act=ops.ACT_LRELU, w2=w2, b2=b2)
+    with torch.no_grad():
+        y_eval = ops.conv2d(x, w1, b1, act=ops.ACT_LRELU, w2=w2, b2=b2)         # the codec / eval path
+        y_one = ops.conv2d(x[:2].contiguous(memory_format=torch.channels_last), w1, b1, act=ops.ACT_LRELU)
+        want = torch.cat((F.leaky_relu(F.conv2d(x[:8], w1, b1, padding=1), 0.01), F.leaky_relu(F.conv2d(x[8:], w2, b2, padding=1), 0.01)))
+    assert torch.equal(y_train, y_again)
+    scale = want.abs().max().item()
+    assert (y_train - want).abs().max().item() <= 3e-5 * scale and (y_eval - want).abs().max().item() <= 3e-5 * scale
+    assert torch.equal(y_one, y_eval[:2])                                       # inference: batch-independent bits
+    (y_train.square().sum()).backward()                                         # and the ordinary backward still runs on its outputs
+    assert torch.isfinite(w1.grad).all() and torch.isfinite(xg.grad).all()
