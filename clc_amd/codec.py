@@ -37,8 +37,16 @@ MAGIC = b"CLC1"
 # ------------------------------------------------------------------------------------------------ container
 
 
-KERNEL_CONFIG_TAG = 5   # bumped whenever the kernels of the context model change their summation order (the decoder must re-derive the
-                        # encoder's float means / scales bit for bit: decode with the build that encoded, or one carrying the same tag)
+class KernelConfigMismatch(ValueError):
+    """the container was written by context-model kernels of another summation order than the ones that would decode it"""
+
+
+def kernel_config_tag() -> int:
+    """Tag of the context-model kernels this process would run NOW (clc_kernel_config_tag: the build's kernel generation, or a hash of
+    the order-affecting tuning keys when CLC_TUNING / clc_set_tuning / set_precision moved one off its default).  Never 0."""
+    from . import lib
+
+    return int(lib.load().clc_kernel_config_tag())
 
 
 def pack(strings, shape, image_hw, n_refs: int = 0, model_id: int = 0) -> bytes:
@@ -49,11 +57,23 @@ def pack(strings, shape, image_hw, n_refs: int = 0, model_id: int = 0) -> bytes:
     arithmetic decoder, so the decoder only stays in sync when it reproduces the encoder's means / scales bit for bit (the
     reference has the same property across devices and library versions; it records nothing)."""
     y, z = strings[0][0], strings[1][0]
-    return MAGIC + struct.pack("<BBBBHHHHII", 1, model_id, n_refs, KERNEL_CONFIG_TAG, image_hw[0], image_hw[1], int(shape[0]), int(shape[1]), len(y), len(z)) + z + y
+    return MAGIC + struct.pack("<BBBBHHHHII", 1, model_id, n_refs, kernel_config_tag(), image_hw[0], image_hw[1], int(shape[0]), int(shape[1]), len(y), len(z)) + z + y
 
 
-def unpack(blob: bytes):
-    """-> (strings, shape, meta) as decompress() takes them."""
+def check_kernel_config(meta, what="container"):
+    """Raise KernelConfigMismatch unless `meta` (from unpack) carries the tag of the kernels that are about to decode.  Tag 0 (files
+    written before the tag existed) never matches: those builds summed in other orders."""
+    tag, now = int(meta.get("kernel_config_tag", 0)), kernel_config_tag()
+    if tag != now:
+        raise KernelConfigMismatch(f"{what} was encoded under kernel-config tag {tag}, this build / tuning state decodes under tag {now}: the "
+                                   "context model would leave the encoder's bit-exact means / scales and the arithmetic decoder would "
+                                   "desynchronise silently.  Decode with the build (and CLC_TUNING / precision mode) that encoded, or "
+                                   "pass strict=False to read the streams anyway.")
+
+
+def unpack(blob: bytes, strict: bool = True):
+    """-> (strings, shape, meta) as decompress() takes them.  strict (default): refuse a container whose kernel-config tag is not this
+    build's (KernelConfigMismatch); strict=False returns it with meta["same_kernel_config"] = False for inspection."""
     if len(blob) < 24 or blob[:4] != MAGIC:
         raise ValueError("not a CLC1 container (shorter than its 24-byte header, or wrong magic)")
     ver, model_id, n_refs, tag, H, W, zh, zw, ny, nz = struct.unpack("<BBBBHHHHII", blob[4:24])
@@ -62,8 +82,16 @@ def unpack(blob: bytes):
     if len(blob) != 24 + ny + nz:
         raise ValueError("truncated / oversized container")
     z, y = blob[24:24 + nz], blob[24 + nz:24 + nz + ny]
-    return [[y], [z]], torch.Size([zh, zw]), {"image_hw": (H, W), "n_refs": n_refs, "model_id": model_id, "kernel_config_tag": tag,
-                                              "same_kernel_config": tag in (0, KERNEL_CONFIG_TAG)}
+    meta = {"image_hw": (H, W), "n_refs": n_refs, "model_id": model_id, "kernel_config_tag": tag, "same_kernel_config": tag == kernel_config_tag()}
+    if strict:
+        check_kernel_config(meta)
+    return [[y], [z]], torch.Size([zh, zw]), meta
+
+
+def unpack_item(blob: bytes, strict: bool = True) -> dict:
+    """unpack() as the dict CodecEngine.decompress takes; the header's meta rides along and is checked again where decoding starts."""
+    strings, shape, meta = unpack(blob, strict)
+    return {"strings": strings, "shape": shape, "meta": meta}
 
 
 def write_file(path, strings, shape, image_hw, n_refs=0, model_id=0):
@@ -73,9 +101,9 @@ def write_file(path, strings, shape, image_hw, n_refs=0, model_id=0):
     return len(blob)
 
 
-def read_file(path):
+def read_file(path, strict: bool = True):
     with open(path, "rb") as f:
-        return unpack(f.read())
+        return unpack(f.read(), strict)
 
 
 # --------------------------------------------------------------------------------------------------- engine
@@ -272,8 +300,11 @@ class CodecEngine:
 
     @torch.no_grad()
     def decompress(self, items: Sequence[dict], ref_frames: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
-        """items: outputs of compress() (or unpack()ed containers) for B images of one shape -> x_hat [B,3,H,W] clamped to [0,1]."""
+        """items: outputs of compress() (or unpack_item()ed containers, whose kernel-config tag is checked here) for B images of one shape -> x_hat [B,3,H,W] clamped to [0,1]."""
         m = self.model
+        for k, it in enumerate(items):      # items that came out of a container carry its header: refuse another kernel generation's
+            if it.get("meta") is not None:
+                check_kernel_config(it["meta"], f"item {k}")
         refs = list(ref_frames) if ref_frames else None
         if not getattr(m, "use_ref", True) or not hasattr(m, "ref_encoder"):
             refs = None

@@ -73,6 +73,7 @@ struct ConvParams {
   int ksplit; float* partial;   // conv_igemm_dma2_kernel: K range split over `ksplit` workgroups per tile (blockIdx.z = class * ksplit + split), raw partial tiles to `partial`
   int reg_epi;                 // conv_igemm_dma2_kernel: per-wave register epilogue (epilogue_regs) instead of the C tile through LDS
   int batch_variant_ok;        // clc_conv_desc.batch_variant_ok
+  int bf16;                    // reduced-precision mode for THIS launch: set by clc_conv2d for the LDS-tiled family on maps larger than 16x16 only
   int ablate;                  // CLC_TUNE_ABLATE (diagnostic builds of the timing only, results are WRONG): 1 = no MFMAs, 2 = no result stores, 4 = no operand DMA
 };
 
@@ -1330,7 +1331,7 @@ int launch(const ConvParams& p, int classes, hipStream_t st) {
   if (use_dma && p.in_op == CLC_IN_NONE && p.xs == nullptr && (BM >= 128 || dma_small) && clc_tuning[CLC_TUNE_DMA_LOOP] == 2)
     return p.ks == 1 && p.stride == 1
                ? (p.transposed ? launch_dma2_t<BM, BN, WM, WN, true, 1>(p, classes, st) : launch_dma2_t<BM, BN, WM, WN, false, 1>(p, classes, st))
-               : (clc_tuning[CLC_TUNE_BF16]   // reduced-precision mode: the 3x3 layers of the LDS-tiled family (maps larger than 16x16 = the transforms)
+               : (p.bf16   // reduced-precision mode: the 3x3 layers of the LDS-tiled family (maps larger than 16x16 = the transforms)
                       ? (p.transposed ? launch_dma2_t<BM, BN, WM, WN, true, 3, 0, true>(p, classes, st) : launch_dma2_t<BM, BN, WM, WN, false, 3, 0, true>(p, classes, st))
                       : (p.transposed ? launch_dma2_t<BM, BN, WM, WN, true, 3>(p, classes, st) : launch_dma2_t<BM, BN, WM, WN, false, 3>(p, classes, st)));
   if (use_dma && p.in_op == CLC_IN_NONE && p.xs == nullptr && (BM >= 128 || dma_small))   // no input prologue -> the tiles can go straight to LDS
@@ -1508,7 +1509,7 @@ static int fill_params(const clc_conv_desc* d, ConvParams& p, int& classes) {
   p.M = d->N * d->OH * d->OW;
   if (d->transposed && d->stride == 2) { classes = 4; p.M = d->N * (d->OH / 2) * (d->OW / 2); }
   p.w2 = d->w2; p.bias2 = d->bias2; p.group_rows = 0; p.pre_deriv = d->pre_deriv;
-  p.dma_place = clc_tuning[CLC_TUNE_DMA_PLACE]; p.xcd_map = 0; p.ablate = clc_tuning[CLC_TUNE_ABLATE]; p.reg_epi = 0; p.ksplit = 1; p.partial = nullptr; p.batch_variant_ok = d->batch_variant_ok;
+  p.dma_place = clc_tuning[CLC_TUNE_DMA_PLACE]; p.xcd_map = 0; p.ablate = clc_tuning[CLC_TUNE_ABLATE]; p.reg_epi = 0; p.ksplit = 1; p.partial = nullptr; p.batch_variant_ok = d->batch_variant_ok; p.bf16 = 0;
   p.res_gate = d->res ? d->res_gate : nullptr; p.ldg = d->ldg; p.rg_act = d->res_gate_act; p.rg_pre = d->res_gate_pre;
   p.out_gate = d->out_gate; p.ldog = d->ldog; p.og_act = d->out_gate_act; p.og_pre = d->out_gate_pre;
   CLC_CHECK(!d->out_gate || !d->shuffle, "clc_conv2d: out_gate with shuffle");
@@ -1596,6 +1597,11 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
     if (C > 32 && wg32 > 256) return launch_splitk<64>(p, classes, st);
     return launch_splitk<32>(p, classes, st);
   }
+  // Reduced-precision mode (CLC_TUNE_BF16): from here on only — the contract of set_precision("bf16") is "maps larger than 16x16; the
+  // entropy-parameter nets, the context model and with it the codec stay f32".  Every small_map branch above (split-K family, the
+  // heavy data gradients and the heavy128 forward of the slice-parameter nets, 3x3 layers with few channels on <= 32x32 maps) has
+  // returned by now with p.bf16 = 0.
+  p.bf16 = clc_tuning[CLC_TUNE_BF16] != 0 && img_pix > 256;
   if (img_pix <= 1024) {
     if (C >= 64) {
       use_split(p, d, classes);
@@ -1615,7 +1621,9 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   // 64-channel 3x3 layers (the ResidualBlocks of the ConvTransBlocks) with enough rows for 512 tiles of 256: each wave then owns a
   // 64 x 32 block (two accumulators, 12 fragment reads and 6 DMA pieces per 32 MFMAs instead of 8 and 3 per 16): 98.1 -> 91.0 us on
   // 64 -> 64 @ 8x128x128, same bits (the K order of an output element does not depend on the tile, so the choice may look at M)
-  if (clc_tuning[CLC_TUNE_TILE256] && d->ks == 3 && C > 32 && C <= 64 && p.M >= 256 * 512) return launch<256, 64, 4, 2>(p, classes, st);
+  // (filter sets: the set is chosen per workgroup, so a tile must not straddle two of them — fill_params guarantees multiples of 128 only)
+  if (clc_tuning[CLC_TUNE_TILE256] && d->ks == 3 && C > 32 && C <= 64 && p.M >= 256 * 512 && (!p.group_rows || p.group_rows % 256 == 0))
+    return launch<256, 64, 4, 2>(p, classes, st);
   if (C > 32) return launch<128, 64, 4, 2>(p, classes, st);
   // the 12-channel tail of the synthesis transform (and any <= 32-channel 3x3 layer on >= 65 536 rows): 128 x 32 tiles, a wave owns 64 x 32
   // (two accumulators per B fragment) — 149.5 -> 120.3 us on 128 -> 12 @ 8x128x128, same bits (the same reasoning as the 256 x 64 rule)

@@ -14,13 +14,13 @@ namespace {
 constexpr int kChunk = 4096;
 
 __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const clc_param_entry* __restrict__ table, const int2* __restrict__ chunks,
-                                                        float* __restrict__ partials) {
+                                                        float* __restrict__ partials, float grad_scale) {
   __shared__ float sm[4];
   const int2 ch = chunks[blockIdx.x];
   const clc_param_entry e = table[ch.x];
   const long beg = (long)ch.y, end = min(e.n, beg + kChunk);
   float s = 0.f;
-  for (long i = beg + threadIdx.x; i < end; i += 256) { const float g = e.g[i]; s = fmaf(g, g, s); }
+  for (long i = beg + threadIdx.x; i < end; i += 256) { const float g = e.g[i] * grad_scale; s = fmaf(g, g, s); }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const clc_param_entry*
 
 __global__ __launch_bounds__(256) void adamw_kernel(const clc_param_entry* __restrict__ table, const int2* __restrict__ chunks,
                                                   const float* __restrict__ total_sqnorm, float max_norm, const float* __restrict__ lr_dev, float omb1,
-                                                  float beta2, float omb2, float eps, float wd, const float* __restrict__ step) {
+                                                  float beta2, float omb2, float eps, float wd, const float* __restrict__ step, float grad_scale) {
   const int2 ch = chunks[blockIdx.x];
   const clc_param_entry e = table[ch.x];
   const long beg = (long)ch.y, end = min(e.n, beg + kChunk);
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const clc_param_entry* __res
   // as torch.optim.AdamW's host code does, not 49 M times in float
   const float step_size = lr / step[1], bc2_sqrt = step[2];
   for (long i = beg + threadIdx.x; i < end; i += 256) {
-    float g = e.g[i] * clip;
+    float g = (e.g[i] * grad_scale) * clip;   // grad_scale = 1 / world: the rank mean of a summed all-reduce, folded in here
     if (isnan(g)) g = 0.f; else if (isinf(g)) g = g > 0.f ? 3.402823466e+38f : -3.402823466e+38f;  // nan_to_num_
     float p = e.p[i] * (1.f - lr * wd);
     const float m0 = e.m[i];
@@ -67,19 +67,19 @@ __global__ void adam_tick_kernel(float* state, double beta1, double beta2) {
 extern "C" int clc_optim_chunk_elems(void) { return kChunk; }
 
 extern "C" int clc_grad_sqnorm_partials(const clc_param_entry* table_dev, const int32_t* chunks_dev, int n_chunks, float* partials,
-                                        clc_stream_t stream) {
+                                        float grad_scale, clc_stream_t stream) {
   CLC_CHECK(table_dev && chunks_dev && partials && n_chunks > 0, "clc_grad_sqnorm_partials: bad args");
-  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table_dev, (const int2*)chunks_dev, partials);
+  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table_dev, (const int2*)chunks_dev, partials, grad_scale);
   CLC_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int clc_adamw_step(const clc_param_entry* table_dev, const int32_t* chunks_dev, int n_chunks, const float* total_sqnorm_dev,
                               float max_norm, const float* lr_dev, double beta1, double beta2, float eps, float weight_decay,
-                              const float* step_dev, clc_stream_t stream) {
+                              const float* step_dev, float grad_scale, clc_stream_t stream) {
   CLC_CHECK(table_dev && chunks_dev && step_dev && lr_dev && n_chunks > 0, "clc_adamw_step: bad args");
   hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table_dev, (const int2*)chunks_dev, total_sqnorm_dev,
-                     max_norm, lr_dev, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay, step_dev);
+                     max_norm, lr_dev, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay, step_dev, grad_scale);
   CLC_LAUNCH_CHECK();
   return 0;
 }

@@ -33,12 +33,36 @@ void clc_set_error(const char* fmt, ...) {
 extern "C" const char* clc_last_error(void) { return g_err; }
 extern "C" int clc_version(void) { return 200; }
 
-int clc_tuning[19] = {2, 1, 1, 0, 1024, 64, 1, 8, 1, 1, 1, 1, 0, 1, 0, 1, 3, 1, 1};   // (CLC_TUNE_COUNT entries: csrc/common.h, which this host-only file cannot include)
+#define CLC_TUNING_DEFAULTS {2, 1, 1, 0, 1024, 64, 1, 8, 1, 1, 1, 1, 0, 1, 0, 1, 3, 1, 1}
+int clc_tuning[19] = CLC_TUNING_DEFAULTS;   // (CLC_TUNE_COUNT entries: csrc/common.h, which this host-only file cannot include)
+static const int clc_tuning_default[19] = CLC_TUNING_DEFAULTS;
 extern "C" int clc_set_tuning(int key, int value) {
   if (key < 0 || key >= (int)(sizeof(clc_tuning) / sizeof(clc_tuning[0]))) { clc_set_error("clc_set_tuning: key %d out of range", key); return -1; }
   const int old = clc_tuning[key];
   clc_tuning[key] = value;
   return old;
+}
+extern "C" int clc_get_tuning(int key) {
+  if (key < 0 || key >= (int)(sizeof(clc_tuning) / sizeof(clc_tuning[0]))) { clc_set_error("clc_get_tuning: key %d out of range", key); return -1; }
+  return clc_tuning[key];
+}
+// Which generation of context-model kernels (summation orders) this build + its current tuning state runs: the codec's container tag.
+// The slice loop is autoregressive through the arithmetic decoder, so a decoder only stays in sync with an encoder that produced the
+// same float means / scales bit for bit.  kGeneration is bumped by hand whenever a kernel the codec path launches changes the order
+// in which it sums; the tuning keys that select between kernels of DIFFERENT order (kernel family limits, the reduced-precision mode,
+// the forward halves of the attention tiling, the diagnostic ablation) are folded in when they are off their defaults.
+extern "C" int clc_kernel_config_tag(void) {
+  const int kGeneration = 6;
+  static const int order_keys[] = {0, 4, 5, 12, 14, 16};
+  uint32_t h = 2166136261u ^ (uint32_t)kGeneration;
+  bool dflt = true;
+  for (int k : order_keys) {
+    int v = clc_tuning[k], d = clc_tuning_default[k];
+    if (k == 16) { v &= 5; d &= 5; }   // bit 2 selects a BACKWARD kernel only
+    if (v != d) dflt = false;
+    h = (h ^ (uint32_t)v) * 16777619u;
+  }
+  return dflt ? kGeneration : (int)(128u | (h & 127u));   // 1..127: default tuning of generation g; 128..255: a non-default order
 }
 
 namespace {

@@ -78,6 +78,8 @@ SIGNATURES = {
     "clc_last_error": (C.c_char_p, []),
     "clc_version": (_i, []),
     "clc_set_tuning": (_i, [_i, _i]),
+    "clc_get_tuning": (_i, [_i]),
+    "clc_kernel_config_tag": (_i, []),
     "clc_conv2d": (_i, [C.POINTER(ConvDesc), fp]),
     "clc_conv2d_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
     "clc_conv2d_wgrad_workspace_bytes": (_sz, [C.POINTER(WgradDesc)]),
@@ -151,8 +153,8 @@ SIGNATURES = {
     "clc_maxpool2d": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, fp]),
     "clc_adaptive_pool2d": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, _i, fp]),
     "clc_optim_chunk_elems": (_i, []),
-    "clc_grad_sqnorm_partials": (_i, [fp, fp, _i, fp, fp]),
-    "clc_adamw_step": (_i, [fp, fp, _i, fp, _f, fp, _d, _d, _f, _f, fp, fp]),
+    "clc_grad_sqnorm_partials": (_i, [fp, fp, _i, fp, _f, fp]),
+    "clc_adamw_step": (_i, [fp, fp, _i, fp, _f, fp, _d, _d, _f, _f, fp, _f, fp]),
     "clc_adam_tick": (_i, [fp, _d, _d, fp]),
     "clc_scalar_add": (_i, [fp, _f, fp]),
     "clc_rans_encode_bound": (_l, [_l]),

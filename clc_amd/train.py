@@ -100,7 +100,9 @@ class GradSync:
     """Gradient mean over ranks as a few large all-reduces over a flat fp32 buffer (RCCL on GPU, gloo in CPU tests).
 
     xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is bound by one link, so small buckets
-    only add latency — default bucket = 64 MiB.  ``start()`` launches asynchronously, ``finish()`` waits and scales.
+    only add latency — default bucket = 64 MiB.  ``start()`` launches asynchronously, ``finish()`` waits and scales — unless the
+    consumer folds the 1 / world factor into a pass it makes anyway (``fold_scale``: FusedAdamW's norm / update kernels take it
+    as ``grad_scale``, which saves a read-modify-write pass over the whole arena per step).
     """
 
     def __init__(self, flat: torch.Tensor, bucket_bytes: int = 64 << 20, group=None, phases=None):
@@ -117,6 +119,7 @@ class GradSync:
             self.phases.append([flat[i: min(i + n, b)] for i in range(a, b, n)])
         self.buckets = [bk for ph in self.phases for bk in ph]
         self.pending = []
+        self.fold_scale = False   # True: finish() leaves the SUM in place, the optimizer applies 1 / world (TrainEngine._discover)
 
     def start(self, phase=None):
         if self.world == 1:
@@ -130,7 +133,8 @@ class GradSync:
         for w in self.pending:
             w.wait()
         self.pending = []
-        self.flat.mul_(1.0 / self.world)
+        if not self.fold_scale:
+            self.flat.mul_(1.0 / self.world)
 
 
 def broadcast_parameters(module: nn.Module, src: int = 0, group=None):
@@ -158,6 +162,7 @@ class FusedAdamW:
                 raise ValueError("FusedAdamW needs dense (contiguous or channels_last) parameters")
         self.params = params
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_norm
+        self.grad_scale = 1.0     # 1 / world when the gradient arena holds the rank SUM (GradSync.fold_scale)
         self.p_arena = FlatArena([p.data for p in params])
         self.g_arena = FlatArena([p.data for p in params])
         with torch.no_grad():
@@ -212,11 +217,12 @@ class FusedAdamW:
         _lib.check(L.clc_adam_tick(self.step_dev.data_ptr(), float(self.betas[0]), float(self.betas[1]), st), "clc_adam_tick")
         sq = None
         if self.max_norm > 0:
-            _lib.check(L.clc_grad_sqnorm_partials(self.table.data_ptr(), self.chunks.data_ptr(), self.n_chunks, self.partials.data_ptr(), st), "clc_grad_sqnorm_partials")
+            _lib.check(L.clc_grad_sqnorm_partials(self.table.data_ptr(), self.chunks.data_ptr(), self.n_chunks, self.partials.data_ptr(), float(self.grad_scale), st),
+                       "clc_grad_sqnorm_partials")
             _lib.check(L.clc_sum_partials(self.partials.data_ptr(), self.n_chunks, 1.0, self.sqnorm.data_ptr(), 0, st), "clc_sum_partials")
             sq = self.sqnorm.data_ptr()
         _lib.check(L.clc_adamw_step(self.table.data_ptr(), self.chunks.data_ptr(), self.n_chunks, sq, float(self.max_norm), self.lr_dev.data_ptr(),
-                                    float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), self.step_dev.data_ptr(), st), "clc_adamw_step")
+                                    float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd), self.step_dev.data_ptr(), float(self.grad_scale), st), "clc_adamw_step")
 
 
 # ------------------------------------------------------------------------------------ the engine
@@ -299,13 +305,16 @@ class TrainEngine:
                  clip_max_norm: float = 1.0, use_graph: bool = True, with_optimizer: bool = True, train_mode: bool = True, side_stream: bool = True,
                  criterion=None, optimizer_factory=None, precision: Optional[str] = None):
         """criterion / optimizer_factory: replaceable parts (defaults: the reference's RD loss and the fused HIP AdamW) — the
-        multi-process CPU test drives the step structure with plain-torch stand-ins.
+        multi-process CPU test drives the step structure with plain-torch stand-ins.  A custom criterion sees the reference forward's
+        FULL output dict (`x_hat`, `likelihoods`, `para{means, scales, y}`, CLC_run.py:593-597); only the built-in RateDistortionLoss,
+        which reads `x_hat` and the likelihoods alone, lets the model skip assembling `para`.
         precision: None (leave the process-wide setting alone), "f32" or "bf16" — clc_amd.set_precision() is applied around every step
         of this engine (the captured hipGraph keeps the kernels it was captured with)."""
         if precision not in (None, "f32", "bf16"):
             raise ValueError("precision must be None, 'f32' or 'bf16'")
         self.precision = precision
         self.model, self.criterion = model, (criterion or RateDistortionLoss(lmbda, loss_type))
+        self.lean_outputs = criterion is None
         self._make_opt = optimizer_factory or (lambda params, lr, max_norm: FusedAdamW(params, lr=lr, max_norm=max_norm))
         self.lr, self.aux_lr, self.clip = lr, aux_lr, clip_max_norm
         self.use_graph, self.with_optimizer = use_graph, with_optimizer
@@ -349,10 +358,14 @@ class TrainEngine:
         # (wire_clm: the reference latents also feed h_a, so (y, ref_features) no longer separates the encoders from the rest)
         self.two_phase = bool(cut) and hasattr(self.model, "_boundary_ok") and not getattr(self.model, "wire_clm", False)
         self.aux_sync = GradSync(self.aux_opt.grad_flat)
+        # the rank mean's 1 / world rides in the optimizer's own passes over the gradients where the optimizer can take it
+        for sync, opt in ((self.sync, self.opt), (self.aux_sync, self.aux_opt)):
+            if self.with_optimizer and sync.world > 1 and hasattr(opt, "grad_scale"):
+                opt.grad_scale, sync.fold_scale = 1.0 / sync.world, True
 
     def _model_out(self, x, refs):
-        # (the criterion reads x_hat and the likelihoods only: the concatenated means / scales of the output dict are not assembled)
-        self.model._lean_outputs = True
+        # (the built-in criterion reads x_hat and the likelihoods only: the concatenated means / scales of the output dict are not assembled)
+        self.model._lean_outputs = self.lean_outputs
         try:
             return self.model(x, refs)
         finally:

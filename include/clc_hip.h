@@ -39,6 +39,12 @@ int clc_version(void);
 /* A/B switch between kernel variants that compute the same bits (key 0: K-loop timing of the LDS-DMA convolution, 1 or 2;
  * key 1: stream-K filter gradients, 0 or 1); returns the previous value.  Benchmark tooling only. */
 int clc_set_tuning(int key, int value);
+int clc_get_tuning(int key);
+/* The codec container's kernel-configuration tag (clc_amd/codec.py): which generation of context-model summation orders this build,
+ * in its CURRENT tuning state, runs.  1..127 = default tuning of that generation; 128..255 = a hash of the order-affecting keys
+ * when any is off its default.  A stream decodes only under the tag it was encoded with (the slice loop is autoregressive through
+ * the arithmetic decoder: CLC_run.py:738-814 has the same property across devices and records nothing). */
+int clc_kernel_config_tag(void);
 
 /* ---- activation / epilogue codes ---------------------------------------------------- */
 enum { CLC_ACT_NONE = 0, CLC_ACT_LRELU = 1, CLC_ACT_RELU = 2, CLC_ACT_GELU = 3, CLC_ACT_HALFTANH = 4 /* 0.5*tanh(v), LRP head */,
@@ -379,19 +385,21 @@ int clc_avgpool2(const float* x, int ldx, float* out, int B, int H, int W, int C
  * table of (param, grad, m, v, numel) entries resident on the device. */
 typedef struct { float* p; float* g; float* m; float* v; long n; } clc_param_entry;
 /* chunks_dev: n_chunks pairs (entry index, element offset); one workgroup per chunk of
- * clc_optim_chunk_elems() elements.  partials: n_chunks floats (sum g^2 per chunk). */
+ * clc_optim_chunk_elems() elements.  partials: n_chunks floats (sum (grad_scale * g)^2 per chunk).
+ * grad_scale: 1 on one GPU; 1 / world after a SUMMED gradient all-reduce (the rank mean of run_ddp.sh:1-7 / DDP, folded into
+ * the two passes that read the gradients anyway instead of a pass of its own over the arena). */
 int clc_optim_chunk_elems(void);
 int clc_grad_sqnorm_partials(const clc_param_entry* table_dev, const int32_t* chunks_dev, int n_chunks, float* partials,
-                             clc_stream_t stream);
+                             float grad_scale, clc_stream_t stream);
 /* state_dev[3] = {t, 1 - beta1^t, sqrt(1 - beta2^t)}: t += 1 and the two bias corrections of torch.optim.AdamW, evaluated in
  * double on the device (one thread) so the optimizer step stays graph-replayable. */
 int clc_adam_tick(float* state_dev, double beta1, double beta2, clc_stream_t stream);
-/* g <- nan_to_num(g * min(1, max_norm/(sqrt(*total_sqnorm_dev)+1e-6))) ; AdamW update with the step state
+/* g <- nan_to_num(g * grad_scale * min(1, max_norm/(sqrt(*total_sqnorm_dev)+1e-6))) ; AdamW update with the step state
  * read from step_dev[3] (clc_adam_tick) and the learning rate from *lr_dev (device float) so a
  * captured launch is graph-replayable AND follows the MultiStepLR schedule (train_CLC.py:453,497). */
 int clc_adamw_step(const clc_param_entry* table_dev, const int32_t* chunks_dev, int n_chunks, const float* total_sqnorm_dev,
                    float max_norm, const float* lr_dev, double beta1, double beta2, float eps, float weight_decay,
-                   const float* step_dev, clc_stream_t stream);
+                   const float* step_dev, float grad_scale, clc_stream_t stream);
 int clc_scalar_add(float* x_dev, float v, clc_stream_t stream);
 
 /* ---- entropy coder (HOST, bit-exact) --------------------------------------------------- *

@@ -1,0 +1,59 @@
+"""`python bench.py --gpus N` (N > 1) must launch its own ranks (the driver runs it bare; /root/reference/run_ddp.sh:7 is the recipe it
+mirrors: `python -m torch.distributed.run --nproc_per_node=8 ...`).  CPU-side checks: argument assembly, the JSON line of rank 0
+arriving on the launcher's stdout, and the children's exit code becoming the launcher's."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_launcher_command_assembly():
+    import bench
+
+    cmd = bench.launcher_command(4, 29999, ["--gpus", "4", "--steps", "7", "--warmup", "2"])
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]   # the script's own arguments, unchanged, after the script
+
+
+def _run(args, **env):
+    e = dict(os.environ, PYTHONPATH=ROOT, **env)
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    e.pop("LOCAL_RANK", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=300, env=e, cwd=ROOT)
+
+
+def test_bare_gpus2_launches_two_ranks_and_relays_rank0_json():
+    r = _run(["--gpus", "2", "--launch-selftest"])
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout          # ONE JSON line: rank 0's
+    rep = json.loads(lines[0])
+    assert rep == {"launch_selftest": True, "n_gpus": 2, "ranks_seen": 2}
+    assert "launching the ranks" in r.stderr and "torch.distributed.run" in r.stderr
+
+
+def test_child_failure_becomes_the_launchers_exit_code():
+    """no GPU here: every rank stops with `bench.py needs an MI355X` -> torchrun fails -> the launcher must fail too (and print no JSON)"""
+    import torch
+
+    if torch.cuda.is_available():
+        import pytest
+
+        pytest.skip("needs a box without a GPU")
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "1"])
+    assert r.returncode != 0
+    assert "needs an MI355X" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+
+
+def test_world_size_mismatch_is_an_error():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, PYTHONPATH=ROOT, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

@@ -19,7 +19,7 @@ def test_container_roundtrip(tmp_path):
     assert len(blob) == 24 + 20 + 12 and blob[:4] == b"CLC1"
     s2, sh2, meta = codec.unpack(blob)
     assert s2 == strings and tuple(sh2) == (4, 6)
-    assert meta == {"image_hw": (200, 300), "n_refs": 3, "model_id": 1, "kernel_config_tag": codec.KERNEL_CONFIG_TAG, "same_kernel_config": True}
+    assert meta == {"image_hw": (200, 300), "n_refs": 3, "model_id": 1, "kernel_config_tag": codec.kernel_config_tag(), "same_kernel_config": True}
     n = codec.write_file(tmp_path / "a.clc", strings, shape, (200, 300), 3, 1)
     assert n == len(blob) and os.path.getsize(tmp_path / "a.clc") == n
     s3, sh3, meta3 = codec.read_file(tmp_path / "a.clc")
@@ -71,7 +71,7 @@ def test_engine_matches_model_codec(dev, kind, R):
         assert torch.equal(x_hat2, x_hat[perm])
         # through the container
         blobs = [codec.pack(o["strings"], o["shape"], (256, 256), n_refs=R) for o in outs]
-        items = [dict(zip(("strings", "shape"), codec.unpack(b)[:2])) for b in blobs]
+        items = [codec.unpack_item(b) for b in blobs]      # (the header's tag travels with the item and is checked by decompress)
         assert torch.equal(eng.decompress(items, refs), x_hat)
         results[use_graph] = (outs, x_hat)
     assert torch.equal(results[True][1], results[False][1])

@@ -105,6 +105,34 @@ def test_adamw_inf_without_clip_saturates(dev):
     assert torch.allclose(p.detach().cpu(), p_ref.detach(), rtol=1e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("world", [2, 8, 3])
+def test_adamw_grad_scale_is_the_rank_mean(dev, world):
+    """N > 1: the gradient arena holds the rank SUM after the all-reduce and the 1 / world of DDP's mean (run_ddp.sh:1-7) is folded
+    into the norm and update kernels (`grad_scale`) instead of a pass of its own.  For a power-of-two world that is the SAME bits as
+    scaling first (the product is exact); for world 3 it must agree to rounding."""
+    from clc_amd.train import FusedAdamW
+
+    cpu = _make_params(dev)
+    mk = lambda: [torch.nn.Parameter(p.clone().to(dev).contiguous(memory_format=CL) if p.dim() == 4 else p.clone().to(dev)) for p in cpu]
+    pa, pb = mk(), mk()
+    a, b = FusedAdamW(pa, lr=1e-3, max_norm=1.0), FusedAdamW(pb, lr=1e-3, max_norm=1.0)
+    b.grad_scale = 1.0 / world
+    for step, scale in enumerate([1.0, 1e-4, 0.3], start=1):
+        gs = _grads(cpu, step, scale)
+        for p, q, g in zip(pa, pb, gs):
+            p.grad.copy_(g.to(dev))                 # the mean ...
+            q.grad.copy_((g * world).to(dev))       # ... and the sum an all-reduce leaves behind
+        a.step()
+        b.step()
+    torch.cuda.synchronize()
+    if world in (2, 8):
+        assert torch.equal(a.p_arena.flat, b.p_arena.flat) and torch.equal(a.m, b.m) and torch.equal(a.v, b.v)
+        assert torch.equal(a.g_arena.flat, b.g_arena.flat)   # the gradient left in place is the scaled, clipped one
+    else:
+        torch.testing.assert_close(a.p_arena.flat, b.p_arena.flat, rtol=1e-6, atol=1e-9)
+        torch.testing.assert_close(a.g_arena.flat, b.g_arena.flat, rtol=1e-6, atol=1e-12)
+
+
 def test_aux_loss_and_aux_step(dev):
     """EntropyBottleneck.loss() (aux loss, train_CLC.py:181) and its quantiles gradient vs the oracle leaf, then three aux-optimizer
     steps (AdamW on *.quantiles, lr 1e-3, train_CLC.py:100-104,182-183) vs torch.optim.AdamW."""

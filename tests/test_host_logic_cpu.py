@@ -153,7 +153,36 @@ def test_container_header_errors_and_kernel_tag():
     blob = codec.pack([[b"yyyy"], [b"zz"]], (4, 4), (256, 256), n_refs=1)
     strings, shape, meta = codec.unpack(blob)
     assert strings == [[b"yyyy"], [b"zz"]] and tuple(shape) == (4, 4) and meta["image_hw"] == (256, 256) and meta["n_refs"] == 1
-    assert meta["kernel_config_tag"] == codec.KERNEL_CONFIG_TAG and meta["same_kernel_config"]
+    tag = codec.kernel_config_tag()
+    assert 0 < tag < 128 and meta["kernel_config_tag"] == tag and meta["same_kernel_config"]
     for bad in (b"", b"CLC1", blob[:23], b"XXXX" + blob[4:], blob + b"!"):
         with pytest.raises(ValueError):
             codec.unpack(bad)
+    # a container of another kernel generation — or of a build from before the tag existed (0) — is REFUSED where decoding starts:
+    # the context model would leave the encoder's bit-exact means / scales and the arithmetic decoder would run off silently
+    for other in (0, tag + 1):
+        old = blob[:7] + bytes([other]) + blob[8:]
+        with pytest.raises(codec.KernelConfigMismatch):
+            codec.unpack(old)
+        with pytest.raises(codec.KernelConfigMismatch):
+            codec.unpack_item(old)
+        s2, _, m2 = codec.unpack(old, strict=False)      # inspection stays possible
+        assert s2 == strings and m2["kernel_config_tag"] == other and not m2["same_kernel_config"]
+        with pytest.raises(codec.KernelConfigMismatch):
+            codec.check_kernel_config(m2)
+    # order-affecting tuning keys are part of the tag: the reduced-precision mode (key 14) and the attention tiling of the forward
+    # pass (key 16, bits 1 and 4) select kernels that sum in another order; bit 2 of key 16 is a backward kernel and is not
+    from clc_amd import lib
+
+    L = lib.load()
+    for key, val, changes in ((14, 1, True), (16, 7, True), (16, 1, False), (4, 256, True), (13, 0, False)):
+        prev = L.clc_set_tuning(key, val)
+        try:
+            t2 = codec.kernel_config_tag()
+            assert (t2 != tag) == changes and (t2 >= 128) == changes, (key, val, t2)
+            if changes:
+                with pytest.raises(codec.KernelConfigMismatch):
+                    codec.unpack(blob)                    # written under the default tuning, read under another
+        finally:
+            L.clc_set_tuning(key, prev)
+    assert codec.kernel_config_tag() == tag and L.clc_get_tuning(16) == 3

@@ -23,3 +23,22 @@ def test_two_ranks_on_one_device_reproduce_the_single_rank_run(dev, tmp_path):
     line = next(l for l in b.stdout.splitlines() if l.startswith("REHEARSAL "))
     rep = json.loads(line[len("REHEARSAL "):])
     assert rep["ranks"] == 2 and rep["bit_identical_to_1rank"] and rep["ranks_agree"] and len(rep["losses_2rank"]) == 2
+
+
+def test_bench_gpus2_self_launches_two_ranks(dev):
+    """The driver's multi-GPU command line, bare: `python bench.py --gpus 2` must start its own two ranks (fresh child processes,
+    /root/reference/run_ddp.sh:7), run the three-graph step with the gradient exchange, and put rank 0's JSON line on stdout.
+    One-GPU box: both ranks on cuda:0, exchange over gloo (CLC_SINGLE_DEVICE / CLC_DIST_BACKEND); the roofline leg — an eager step
+    with the all-reduce inside — runs on both ranks as it will under RCCL."""
+    env = dict(os.environ, PYTHONPATH=ROOT, CLC_SINGLE_DEVICE="1", CLC_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rep = json.loads(lines[0])
+    assert rep["n_gpus"] == 2 and rep["config"]["ranks_seen"] == 2 and rep["config"]["global_batch"] == 8
+    assert rep["scaling"] == "weak" and rep["value"] > 0 and rep["config"]["parallelism"] == "dp2"
+    assert "roofline" in rep and rep["roofline"]["frac"] > 0

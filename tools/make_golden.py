@@ -243,6 +243,81 @@ def codec_goldens(ref):
         print("codec", name, "y bytes", len(enc["strings"][0][0]), "z bytes", len(enc["strings"][1][0]), "bpp", float(out["bpp"]))
 
 
+def pins_goldens(ref):
+    """Reference-held arithmetic of the hot path's entry / exit points, executed as the reference wrote it -> tests/golden/pins.npz:
+      likelihood   CLC._likelihood / _standardized_cumulative (models/CLC_run.py:718-736, the model's own copy of the Gaussian-bin
+                   likelihood) on a grid that covers sigma below the 0.11 bound, sigma at the scale-table thresholds and |v| from 0 to 40
+      rd loss      class RateDistortionLoss (train_CLC.py:36-59), both distortion types (its `ms_ssim` import resolved to the oracle's
+                   restatement of pytorch_msssim — that leaf stays unpinned; the bpp term, the MSE term and the weighting are pinned)
+      optimizers   configure_optimizers (train_CLC.py:81-117) on the genuine CLC(N=64, R=1): which parameter names go to the main / aux
+                   AdamW, in which order, with which hyper-parameters
+      eval         compute_psnr / compute_bpp / pad / crop (eval_CLC.py:133-166) on 200x300 and 512x768 inputs."""
+    import types
+
+    from oracle.loss import ms_ssim as oracle_ms_ssim
+
+    out = {}
+    # ---- (a) the model's own _likelihood
+    m = ref.CLC(N=64, num_ref_frames=1).eval()
+    g = torch.Generator().manual_seed(2024)
+    table = leaves.get_scale_table()
+    nxt = lambda t, d: torch.nextafter(t, torch.full_like(t, d))
+    sig = torch.cat([torch.tensor([0.0, 1e-4, 0.05, 0.1099, 0.11, 0.1101, 0.5, 1.0, 7.5, 64.0, 256.0, 300.0]), table, nxt(table, 1e9), nxt(table, -1e9)])
+    val = torch.cat([torch.tensor([0.0, 0.25, 0.5, 0.75, 1.0, 1.5, 2.0, 3.0, 5.0, 8.0, 12.0, 20.0, 40.0]), torch.rand(19, generator=g) * 6])
+    S, V = torch.meshgrid(sig, val, indexing="ij")
+    means = (torch.rand(S.shape, generator=g) - 0.5) * 4
+    sign = torch.where(torch.rand(S.shape, generator=g) < 0.5, -1.0, 1.0)
+    inputs = means + sign * V
+    with torch.no_grad():
+        lik = m._likelihood(inputs, S.contiguous(), means)
+        lik_nomean = m._likelihood(inputs, S.contiguous())
+    out.update(lik_inputs=inputs.numpy(), lik_scales=S.contiguous().numpy(), lik_means=means.numpy(), lik=lik.numpy(), lik_nomean=lik_nomean.numpy())
+    # ---- (b) RateDistortionLoss
+    ns = ref_shim.extract_reference_functions("train_CLC.py", ["compute_msssim", "RateDistortionLoss", "configure_optimizers"], {"ms_ssim": oracle_ms_ssim})
+    tgt = synthetic_image(2, 176, 192, 31, smooth=True)
+    xh = (tgt + 0.03 * torch.randn(tgt.shape, generator=g)).clamp(0, 1)
+    ly = torch.rand(2, 320, 11, 12, generator=g).clamp_min(1e-9) ** 2
+    lz = torch.rand(2, 192, 3, 3, generator=g).clamp_min(1e-9)
+    ly[0, 0, 0, :4] = 1e-9
+    out.update(rd_x_hat=xh.numpy(), rd_target=tgt.numpy(), rd_lik_y=ly.numpy(), rd_lik_z=lz.numpy())
+    for typ in ("mse", "ms_ssim"):
+        for lm in (0.0067, 0.05):
+            with torch.no_grad():
+                r = ns["RateDistortionLoss"](lmbda=lm, type=typ)({"x_hat": xh, "likelihoods": {"y": ly, "z": lz}}, tgt)
+            for k, v in r.items():
+                out[f"rd_{typ}_{lm}_{k}"] = np.float64(v.double().item())
+                out[f"rd_{typ}_{lm}_{k}_f32"] = np.float32(v.item())
+    # ---- (c) configure_optimizers
+    args = types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3)
+    opt, aux = ns["configure_optimizers"](m, args)
+    names = {id(p): n for n, p in m.named_parameters()}
+    desc = lambda o: {"class": type(o).__name__, "names": [names[id(p)] for p in o.param_groups[0]["params"]],
+                      **{k: (list(v) if isinstance(v, tuple) else v) for k, v in o.param_groups[0].items() if k in ("lr", "betas", "eps", "weight_decay", "amsgrad")}}
+    out["optimizers_json"] = np.array(json.dumps({"main": desc(opt), "aux": desc(aux), "n_groups": [len(opt.param_groups), len(aux.param_groups)]}))
+    # ---- (d) eval helpers
+    ev = ref_shim.extract_reference_functions("eval_CLC.py", ["compute_psnr", "compute_bpp", "pad", "crop"])
+    for tag, (h, w) in (("200x300", (200, 300)), ("512x768", (512, 768)), ("256x256", (256, 256)), ("1x129", (1, 129))):
+        x = torch.rand(1, 3, h, w, generator=torch.Generator().manual_seed(1000 + h + w))   # (tests re-draw it; pad_x_200x300 below is stored)
+        xp, padding = ev["pad"](x, 128)
+        back = ev["crop"](xp, padding)
+        assert torch.equal(back, x)
+        out[f"pad_{tag}_padding"] = np.array(padding, dtype=np.int64)
+        out[f"pad_{tag}_shape"] = np.array(xp.shape, dtype=np.int64)
+        out[f"pad_{tag}_sha256"] = np.array(hashlib.sha256(xp.numpy().tobytes()).hexdigest())
+        out[f"pad_{tag}_in_sha256"] = np.array(hashlib.sha256(x.numpy().tobytes()).hexdigest())
+    xs = torch.rand(1, 3, 200, 300, generator=torch.Generator().manual_seed(77))
+    out["pad_x_200x300"] = xs.numpy()
+    xp, padding = ev["pad"](xs, 128)
+    out["pad_x_200x300_padded"] = xp.numpy()
+    out["pad_x_200x300_padding"] = np.array(padding, dtype=np.int64)
+    a, b = xh, tgt
+    out["psnr"] = np.float64(ev["compute_psnr"](a, b))
+    out["bpp"] = np.float64(ev["compute_bpp"]({"x_hat": xh, "likelihoods": {"y": ly, "z": lz}}))
+    np.savez_compressed(os.path.join(OUT, "pins.npz"), **out)
+    print("pins:", len(out), "arrays; lik grid", tuple(lik.shape), "rd", {k: float(v) for k, v in out.items() if k.startswith("rd_mse_0.0067") and not k.endswith("f32")},
+          "psnr", float(out["psnr"]), "bpp", float(out["bpp"]))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_shim.import_reference_models()
@@ -255,6 +330,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "dormant":
         dormant_goldens(ref)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "pins":
+        pins_goldens(ref)
+        return
     graph_goldens(ref)
     codec_goldens(ref)
     block_goldens(ref)
@@ -262,6 +340,7 @@ def main():
     rans_goldens()
     clm_goldens()
     patch_matching_goldens()
+    pins_goldens(ref)
 
 
 if __name__ == "__main__":

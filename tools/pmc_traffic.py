@@ -7,9 +7,12 @@ Counters are in KiB.  gfx950 correction applied as the guide prescribes: FETCH_S
 The window is a full hipGraph-replayed training step in the trace (between two grad_sqnorm_kernel launches)."""
 import csv
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def step_rows(path):
@@ -52,7 +55,7 @@ def main():
                     "kernel_launches_per_step": sum(kernels[k]["launches_per_step"] for k in ks)}
     total = sum(v["fetch_bytes_per_step"] + v["write_bytes_per_step"] for v in kernels.values())
     json.dump({"note": "bytes at the L2's memory side (Infinity-Cache hits included), one training step (bs 8, 256x256, n_refs 1); "
-                       "FETCH_SIZE doubled per the gfx950 correction", "total_bytes_per_step": total, "families": fam, "kernels": kernels},
+                       "FETCH_SIZE doubled per the gfx950 correction", "csrc_sha16": __import__("bench").csrc_digest(), "total_bytes_per_step": total, "families": fam, "kernels": kernels},
               open(out, "w"), indent=1)
     print(f"total {total / 1e9:.2f} GB/step")
     for k, v in list(kernels.items())[:14]:

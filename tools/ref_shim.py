@@ -78,11 +78,13 @@ def import_reference_file(relpath: str, name: str):
     return mod
 
 
-def extract_reference_functions(relpath: str, names):
-    """AST-extract plain functions from a reference file that cannot be imported as a module
-    (models/Patch_Matching.py: `from turtle import shape`, cv2, compressai_local ...) and exec them with torch/np/F/nn/time
-    in scope.  `.cuda()` is patched to the identity by the caller (see tools/make_golden.py)."""
+def extract_reference_functions(relpath: str, names, extra_ns=None):
+    """AST-extract plain functions / classes from a reference file that cannot be imported as a module
+    (models/Patch_Matching.py: `from turtle import shape`, cv2, compressai_local ...; train_CLC.py / eval_CLC.py: tensorboard, torchvision,
+    the dataset modules) and exec them with torch/np/F/nn/time/math/optim in scope (+ extra_ns, e.g. the `ms_ssim` the file imports from
+    pytorch_msssim).  `.cuda()` is patched to the identity by the caller (see tools/make_golden.py)."""
     import ast
+    import math
     import time
 
     import numpy as np
@@ -92,9 +94,10 @@ def extract_reference_functions(relpath: str, names):
 
     src = open(os.path.join(REFERENCE_ROOT, relpath)).read()
     tree = ast.parse(src)
-    ns = {"torch": torch, "np": np, "nn": nn, "F": F, "time": time}
+    ns = {"torch": torch, "np": np, "nn": nn, "F": F, "time": time, "math": math, "optim": torch.optim}
+    ns.update(extra_ns or {})
     for node in tree.body:
-        if isinstance(node, ast.FunctionDef) and node.name in names:
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)) and node.name in names:
             code = compile(ast.Module(body=[node], type_ignores=[]), relpath, "exec")
             exec(code, ns)
     missing = [n for n in names if n not in ns]
