@@ -53,10 +53,30 @@ def test_forward_parity(dev, kind, R):
     assert abs(bpp_o - bpp_p) <= 1e-4, (bpp_o, bpp_p)
     psnr_o, psnr_p = _psnr(a["x_hat"], x), _psnr(b["x_hat"].cpu(), x)
     assert abs(psnr_o - psnr_p) <= 0.01, (psnr_o, psnr_p)
-    # elementwise: everything except (rare) rounding-boundary flips must agree
+    # elementwise: everything except (rare) rounding-boundary flips must agree (bar 0.5 % of the pixels; measured: none)
     d = (b["x_hat"].cpu() - a["x_hat"]).abs()
     frac_bad = (d > 1e-3 * a["x_hat"].abs().max()).float().mean().item()
-    assert frac_bad < 0.02, frac_bad
+    assert frac_bad < 5e-3, frac_bad
+
+
+def test_forward_parity_over_a_sample_of_images(dev):
+    """north_star's bars (|d bpp| <= 1e-4, |d PSNR| <= 0.01 dB) on a SAMPLE of seeded images, as bench.py's `parity` object states them: the
+    mean is held against the bar, and no single image may be off by more than the footprint of one hyper-latent rounding flip (1e-3 bpp) —
+    so that one latent within float error of a rounding boundary on one image neither hides a real error nor dictates a kernel choice."""
+    from oracle.loss import compute_bpp
+    from oracle.recipe import synthetic_image
+
+    o, p = _pair("clc", 1, dev)
+    dbpp, dpsnr = [], []
+    for sd in (100, 110, 120, 130):
+        x, r = synthetic_image(1, 256, 256, sd, smooth=True), [synthetic_image(1, 256, 256, sd + 1, smooth=True)]
+        with torch.no_grad():
+            a = o(x, r)
+            b = p(x.to(dev), [r[0].to(dev)])
+        dbpp.append(abs(compute_bpp(a) - compute_bpp({"x_hat": b["x_hat"].cpu(), "likelihoods": {k: v.cpu() for k, v in b["likelihoods"].items()}})))
+        dpsnr.append(abs(_psnr(a["x_hat"], x) - _psnr(b["x_hat"].cpu(), x)))
+    assert sum(dbpp) / len(dbpp) <= 1e-4 and max(dbpp) <= 1e-3, dbpp
+    assert sum(dpsnr) / len(dpsnr) <= 0.01 and max(dpsnr) <= 0.02, dpsnr
 
 
 def test_forward_parity_other_shapes(dev):
@@ -85,11 +105,12 @@ def test_forward_parity_other_shapes(dev):
         assert abs(_psnr(a["x_hat"], x) - _psnr(b["x_hat"].cpu(), x)) <= 0.01
 
 
-def _grad_parity(o, p, tol=5e-3, min_checked=600, flips=0):
-    """every parameter gradient of the product vs the oracle's, relative to the gradient's largest element.
+def _grad_parity(o, p, tol=1e-3, min_checked=600, flips=0, flip_tol=5e-2):
+    """every parameter gradient of the product vs the oracle's, relative to the gradient's largest element (bar 1e-3; measured worst
+    1.6e-4 — a 10x regression fails).
     flips: number of latent elements whose STE-rounded symbol differs between the two runs (round(y - mu) is discontinuous: an
     argument within float error of .5 lands on either side, and that y_hat element then differs by 1.0).  Each flip perturbs the
-    gradients of the layers downstream of it; with flips > 0 at most 4 * flips parameters may exceed `tol`, none 10 * tol."""
+    gradients of the layers downstream of it; with flips > 0 at most 4 * flips parameters may exceed `tol`, none `flip_tol`."""
     og = dict(o.named_parameters())
     checked, worst, over = 0, 0.0, []
     for n, prm in p.named_parameters():
@@ -107,7 +128,7 @@ def _grad_parity(o, p, tol=5e-3, min_checked=600, flips=0):
         checked += 1
         if err >= tol:
             over.append((n, err))
-        assert err < (10 * tol if flips else tol), f"{n}: grad rel err {err:.3e} (symbol flips: {flips})"
+        assert err < (flip_tol if flips else tol), f"{n}: grad rel err {err:.3e} (symbol flips: {flips})"
     assert len(over) <= 4 * flips, (flips, over)
     assert checked > min_checked, checked
     return checked, worst
