@@ -1,0 +1,343 @@
+// fused_mlp.hip — the MLP of a Swin block (Linear(64 -> 256), GELU, Linear(256 -> 64), + residual) as ONE launch forward and ONE launch
+// for its whole data gradient, with the 256-channel hidden tensor never written by the forward pass (gfx950).
+//
+//   y = x_res + W2 . gelu(W1 . x + b1) + b2                      /root/reference/models/CLC_run.py:185-187, 190-192 (Block.mlp, `x + mlp(ln2(x))`)
+//
+// As two launches of the 1x1 convolution kernels a block on a 8 x 128 x 128 map moved 1.07 GB through HBM in the forward pass alone, 402 MB
+// of it the hidden tensor and its stored GELU derivative (written by fc1, re-read by fc2 and by three gradient kernels): the layers sit at
+// the chip's FLOP : byte balance point and ran at 47 % of the MFMA peak / 67 % of the achievable HBM rate.  Here the hidden tensor lives in
+// the accumulator registers:
+//
+//   * every wave owns 32 pixels and ALL channels; there is no barrier and no LDS traffic for activations in the main loop — the waves of a
+//     workgroup drift apart, so one wave's GELU (VALU) and stores run under another wave's MFMAs;
+//   * the MFMA roles are swapped with respect to conv_igemm.hip: A = filter rows (channels), B = pixels.  The 32 x 32 result block of lane
+//     (pixel j = lane & 31, half h = lane >> 5) then holds channels i = (r & 3) + 8 (r >> 2) + 4 h in register r, i.e. FOUR CONSECUTIVE
+//     channels in four consecutive registers:
+//       - the epilogues load / store 16 B per lane (dwordx4) instead of 16 dword accesses per block;
+//       - register r of a finished block IS the B operand of the next GEMM's MFMA step that contracts the channel pair
+//         {8 (r >> 2) + (r & 3), + 4}: the second GEMM runs straight out of the first one's accumulators (after bias + GELU in
+//         registers) — no LDS round trip, no layout change;
+//   * that pair order is exactly the K order of the tiled kernels (K-tile, 8-group t, step s -> pair {8 t + s, 8 t + 4 + s}), and the
+//     same epilogue expressions are used, so the fused launch produces THE SAME BITS as the two-launch chain (checked by the tests): the
+//     codec may use either, whatever the batch size;
+//   * both filters (2 x 64 KB) are resident in LDS for the lifetime of a persistent workgroup, as slot-swizzled [K-tile][row][32] images
+//     (conv_igemm_dma_kernel's layout: conflict-free ds_read_b128 fragments), deposited once by LDS-DMA.
+//
+// Backward (`clc_mlp_bwd`), per 32-pixel wave tile and 32-channel block hb of the hidden layer:
+//   h  = W1[hb] x + b1          recomputed from the saved LayerNorm output (+ 8.6 GFLOP per 8 x 128 x 128 block; - 670 MB of traffic)
+//   u  = W2^T[hb] dy
+//   dh = u . gelu'(h),  g = gelu(h)      -> HBM (the dy operand of fc1's and the x operand of fc2's filter gradient, which stay on the
+//                                           grouped stream-K kernels)
+//   dx += W1^T[:, hb] dh                  straight from the dh registers; W1^T is read column-wise (ds_read_b32) from the W1 image
+// Same K orders and epilogue expressions as the unfused data-gradient kernels -> same bits again.
+#include "common.h"
+
+namespace {
+
+constexpr unsigned kOOB = 0x80000000u;
+constexpr int CI = 64, CH = 256, CO = 64;   // the Swin blocks of the ConvTransBlocks: trans_dim 64, hidden 4 x 64
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct MlpParams {
+  const float* x; const float* w1; const float* b1; const float* w2; const float* b2; const float* res; float* y;
+  const float* dy; const float* w2t; float* dx; float* dh; float* g;
+  int ldx, ldr, ldy, lddy, lddx;
+  int M, tiles;
+  unsigned x_bytes, res_bytes, y_bytes, dy_bytes, dx_bytes, hid_bytes;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t srd(const float* ptr, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 ld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ void st4(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+}
+
+// Deposit a [rows][kcols] K-contiguous filter as a slot-swizzled [kcols / 32][rows][32] LDS image: the 16-B chunk c of row r of a
+// K-tile sits in slot c ^ ((r >> 1) & 7).  One LDS-DMA wave-instruction = 8 rows x 128 B; instructions are dealt round-robin to the waves.
+template <int NW>
+__device__ __forceinline__ void fill_image(float* img, const float* src, int rows, int kcols, int wave, int lane) {
+  const __amdgpu_buffer_rsrc_t sr = srd(src, (unsigned)rows * (unsigned)kcols * 4u);
+  const int per_kt = rows >> 3, n = (kcols >> 5) * per_kt;
+  for (int ii = wave; ii < n; ii += NW) {
+    const int kt = ii / per_kt, r0 = (ii - kt * per_kt) << 3;
+    const int row = r0 + (lane >> 3), chunk = (lane & 7) ^ ((row >> 1) & 7);
+    const unsigned off = ((unsigned)row * (unsigned)kcols + (unsigned)(kt * 32 + chunk * 4)) * 4u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(sr, (__attribute__((address_space(3))) void*)(img + ((kt * rows + r0) << 5)), 16, off, 0, 0, 0);
+#endif
+  }
+}
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// ---------------------------------------------------------------------------------------------------------------- forward
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void mlp_fwd_kernel(const MlpParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* W1s = smem;                    // [2][256][32]  fc1: rows = hidden, K = input channels
+  float* W2s = W1s + 2 * CH * 32;       // [8][64][32]   fc2: rows = output channels, K = hidden
+  float* b1s = W2s + 8 * CO * 32;       // [256]
+  float* b2s = b1s + CH;                // [64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+  fill_image<NW>(W1s, p.w1, CH, CI, wave, lane);
+  fill_image<NW>(W2s, p.w2, CO, CH, wave, lane);
+  for (int i = tid; i < CH; i += 64 * NW) b1s[i] = p.b1 ? p.b1[i] : 0.f;
+  for (int i = tid; i < CO; i += 64 * NW) b2s[i] = p.b2 ? p.b2[i] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t xr = srd(p.x, p.x_bytes), rr = srd(p.res ? p.res : p.x, p.res ? p.res_bytes : p.x_bytes), yr = srd(p.y, p.y_bytes);
+  const int sw = (li >> 1) & 7;
+  int fo[4];
+#pragma unroll
+  for (int t8 = 0; t8 < 4; ++t8) fo[t8] = ((2 * t8 + h) ^ sw) << 2;
+  const float* W1l = W1s + (li << 5);   // this lane's row inside a 32-row block of an image
+  const float* W2l = W2s + (li << 5);
+
+  for (int t = blockIdx.x; t < p.tiles; t += gridDim.x) {
+    const int p0 = (t * NW + wave) * 32;
+    if (p0 >= p.M) continue;            // wave-uniform; there is no barrier below
+    const unsigned pix = (unsigned)(p0 + li);
+    f32x4 xf[2][4];
+    {
+      const unsigned xo = (pix * (unsigned)p.ldx + 4u * h) * 4u;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int t8 = 0; t8 < 4; ++t8) xf[kt][t8] = ld4(xr, xo + (unsigned)(kt * 32 + 8 * t8) * 4u);
+    }
+    f32x16 yacc[2];
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) yacc[ob][r] = 0.f;
+
+#pragma unroll 2
+    for (int hb = 0; hb < 8; ++hb) {
+      f32x16 hacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int t8 = 0; t8 < 4; ++t8) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(W1l + ((kt * CH + hb * 32) << 5) + fo[t8]);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) hacc = MFMA(a[s], xf[kt][t8][s], hacc);
+        }
+      // bias + GELU in the accumulator registers (register 4 q + s = hidden channel hb * 32 + 8 q + 4 h + s)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + hb * 32 + 8 * q + 4 * h);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float v = hacc[4 * q + s] + bq[s];
+          float cdf, pdf;
+          gelu_parts(v, cdf, pdf);
+          hacc[4 * q + s] = v * cdf;
+        }
+      }
+      // fc2: K-tile hb of the hidden layer, its B operands are the registers just computed
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(W2l + ((hb * CO + ob * 32) << 5) + fo[q]);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) yacc[ob] = MFMA(a[s], hacc[4 * q + s], yacc[ob]);
+        }
+    }
+    // epilogue: y = (acc + b2) + 1 * res, 16 B per lane
+#pragma unroll
+    for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = ob * 32 + 8 * q + 4 * h;
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(b2s + c0);
+        f32x4 v;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = yacc[ob][4 * q + s] + bq[s];
+        if (p.res) {
+          const f32x4 rv = ld4(rr, (pix * (unsigned)p.ldr + (unsigned)c0) * 4u);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) v[s] += 1.0f * rv[s];
+        }
+        st4(v, yr, (pix * (unsigned)p.ldy + (unsigned)c0) * 4u);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- backward
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const MlpParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* W1s = smem;                    // [2][256][32]  fc1 filter: rows = hidden, K = input channels (also read column-wise for dx)
+  float* Wts = W1s + 2 * CH * 32;       // [2][256][32]  fc2 filter transposed: rows = hidden, K = output channels
+  float* b1s = Wts + 2 * CH * 32;       // [256]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+  fill_image<NW>(W1s, p.w1, CH, CI, wave, lane);
+  fill_image<NW>(Wts, p.w2t, CH, CO, wave, lane);
+  for (int i = tid; i < CH; i += 64 * NW) b1s[i] = p.b1 ? p.b1[i] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t xr = srd(p.x, p.x_bytes), dyr = srd(p.dy, p.dy_bytes), dxr = srd(p.dx, p.dx_bytes);
+  const __amdgpu_buffer_rsrc_t dhr = srd(p.dh, p.hid_bytes), gr = srd(p.g, p.hid_bytes);
+  const int sw = (li >> 1) & 7;
+  int fo[4];
+#pragma unroll
+  for (int t8 = 0; t8 < 4; ++t8) fo[t8] = ((2 * t8 + h) ^ sw) << 2;
+  const float* W1l = W1s + (li << 5);
+  const float* Wtl = Wts + (li << 5);
+  // column reads of the W1 image for dx = W1^T dh: element (hidden row R = hb * 32 + 8 q + 4 h + s, input channel ib * 32 + li) sits at
+  // ((ib * 256 + R) << 5) + (((li >> 2) ^ ((R >> 1) & 7)) << 2) + (li & 3), and (R >> 1) & 7 = (4 q + 2 h + (s >> 1)) & 7
+  int co_[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      co_[q][s] = ((8 * q + 4 * h + s) << 5) + ((((li >> 2) ^ ((4 * q + 2 * h + (s >> 1)) & 7))) << 2) + (li & 3);
+
+  for (int t = blockIdx.x; t < p.tiles; t += gridDim.x) {
+    const int p0 = (t * NW + wave) * 32;
+    if (p0 >= p.M) continue;
+    const unsigned pix = (unsigned)(p0 + li);
+    f32x4 xf[2][4], df[2][4];
+    {
+      const unsigned xo = (pix * (unsigned)p.ldx + 4u * h) * 4u, yo = (pix * (unsigned)p.lddy + 4u * h) * 4u;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int t8 = 0; t8 < 4; ++t8) {
+          xf[kt][t8] = ld4(xr, xo + (unsigned)(kt * 32 + 8 * t8) * 4u);
+          df[kt][t8] = ld4(dyr, yo + (unsigned)(kt * 32 + 8 * t8) * 4u);
+        }
+    }
+    f32x16 dxacc[2];
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dxacc[ib][r] = 0.f;
+
+#pragma unroll 1
+    for (int hb = 0; hb < 8; ++hb) {
+      f32x16 hacc, uacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { hacc[r] = 0.f; uacc[r] = 0.f; }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int t8 = 0; t8 < 4; ++t8) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(W1l + ((kt * CH + hb * 32) << 5) + fo[t8]);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(Wtl + ((kt * CH + hb * 32) << 5) + fo[t8]);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            hacc = MFMA(a[s], xf[kt][t8][s], hacc);
+            uacc = MFMA(b[s], df[kt][t8][s], uacc);
+          }
+        }
+      const unsigned ho = (pix * (unsigned)CH + (unsigned)(hb * 32 + 4 * h)) * 4u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + hb * 32 + 8 * q + 4 * h);
+        f32x4 gv, dv;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float v = hacc[4 * q + s] + bq[s];
+          float cdf, pdf;
+          gelu_parts(v, cdf, pdf);
+          gv[s] = v * cdf;
+          dv[s] = (uacc[4 * q + s] + 0.f) * (cdf + v * pdf);   // (the unfused data-gradient epilogue adds its absent bias as 0.f first)
+          uacc[4 * q + s] = dv[s];
+        }
+        st4(gv, gr, ho + (unsigned)(8 * q) * 4u);
+        st4(dv, dhr, ho + (unsigned)(8 * q) * 4u);
+      }
+      // dx += W1^T[:, hb] dh
+      const float* colb = W1s + ((hb * 32) << 5);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int ib = 0; ib < 2; ++ib) dxacc[ib] = MFMA(colb[((ib * CH) << 5) + co_[q][s]], uacc[4 * q + s], dxacc[ib]);
+    }
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = dxacc[ib][4 * q + s] + 0.f;
+        st4(v, dxr, (pix * (unsigned)p.lddx + (unsigned)(ib * 32 + 8 * q + 4 * h)) * 4u);
+      }
+  }
+}
+
+}  // namespace
+
+static int mlp_fill(const clc_mlp_desc* d, MlpParams& p, bool bwd, const char* who) {
+  CLC_CHECK(d && d->x && d->w1 && d->w2, "%s: null pointer", who);
+  CLC_CHECK(d->Cin == CI && d->Chid == CH && d->Cout == CO, "%s: built for Linear(64 -> 256) GELU Linear(256 -> 64) (got %d -> %d -> %d)", who, d->Cin, d->Chid, d->Cout);
+  CLC_CHECK(d->M > 0 && d->M % 32 == 0 && d->M < (1L << 24), "%s: the pixel count must be a positive multiple of 32 (got %ld)", who, d->M);
+  auto ok = [](const void* ptr, int ld, int c) { return ptr == nullptr || (aligned16(ptr) && ld % 4 == 0 && ld >= c); };
+  CLC_CHECK(ok(d->x, d->ldx, CI) && aligned16(d->w1) && aligned16(d->w2), "%s: operands must be 16-B aligned with leading dimensions that are multiples of 4", who);
+  auto bytes = [](long M, int ld, int c) { return ((size_t)(M - 1) * ld + c) * 4; };
+  CLC_CHECK(bytes(d->M, d->ldx, CI) < (1ull << 31) && bytes(d->M, CH, CH) < (1ull << 31), "%s: tensor larger than 2 GiB", who);
+  p.x = d->x; p.ldx = d->ldx; p.w1 = d->w1; p.b1 = d->b1; p.w2 = d->w2; p.b2 = d->b2; p.M = (int)d->M;
+  p.x_bytes = (unsigned)bytes(d->M, d->ldx, CI);
+  p.res = nullptr; p.y = nullptr; p.dy = nullptr; p.w2t = nullptr; p.dx = nullptr; p.dh = nullptr; p.g = nullptr;
+  p.ldr = p.ldy = p.lddy = p.lddx = 0; p.res_bytes = p.y_bytes = p.dy_bytes = p.dx_bytes = p.hid_bytes = 0;
+  if (!bwd) {
+    CLC_CHECK(d->y && ok(d->y, d->ldy, CO) && ok(d->res, d->ldr, CO), "%s: y / res missing or unaligned", who);
+    CLC_CHECK(bytes(d->M, d->ldy, CO) < (1ull << 31) && (!d->res || bytes(d->M, d->ldr, CO) < (1ull << 31)), "%s: tensor larger than 2 GiB", who);
+    p.y = d->y; p.ldy = d->ldy; p.y_bytes = (unsigned)bytes(d->M, d->ldy, CO);
+    p.res = d->res; p.ldr = d->ldr; p.res_bytes = d->res ? (unsigned)bytes(d->M, d->ldr, CO) : 0;
+  } else {
+    CLC_CHECK(d->dy && d->w2t && d->dx && d->dh && d->g, "%s: dy / w2t / dx / dh / g missing", who);
+    CLC_CHECK(ok(d->dy, d->lddy, CO) && ok(d->dx, d->lddx, CI) && aligned16(d->w2t) && aligned16(d->dh) && aligned16(d->g), "%s: gradient operands unaligned", who);
+    CLC_CHECK(bytes(d->M, d->lddy, CO) < (1ull << 31) && bytes(d->M, d->lddx, CI) < (1ull << 31), "%s: tensor larger than 2 GiB", who);
+    p.dy = d->dy; p.lddy = d->lddy; p.dy_bytes = (unsigned)bytes(d->M, d->lddy, CO);
+    p.w2t = d->w2t; p.dx = d->dx; p.lddx = d->lddx; p.dx_bytes = (unsigned)bytes(d->M, d->lddx, CI);
+    p.dh = d->dh; p.g = d->g; p.hid_bytes = (unsigned)bytes(d->M, CH, CH);
+  }
+  return 0;
+}
+
+// waves per workgroup: 32 pixels per wave; enough workgroups to give every CU one
+static int mlp_waves(long M) { return M >= 65536 ? 8 : (M >= 32768 ? 4 : 2); }
+
+template <int NW>
+static int mlp_launch(MlpParams& p, bool bwd, hipStream_t st) {
+  p.tiles = (p.M + 32 * NW - 1) / (32 * NW);
+  const int grid = p.tiles < 256 ? p.tiles : 256;   // persistent: one workgroup per CU (129 KB of LDS), filters deposited once
+  const size_t lds_f = (size_t)(2 * CH * 32 + 8 * CO * 32 + CH + CO) * sizeof(float), lds_b = (size_t)(4 * CH * 32 + CH) * sizeof(float);
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+  }
+  if (bwd) hipLaunchKernelGGL(mlp_bwd_kernel<NW>, dim3(grid), dim3(64 * NW), lds_b, st, p);
+  else hipLaunchKernelGGL(mlp_fwd_kernel<NW>, dim3(grid), dim3(64 * NW), lds_f, st, p);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+
+static int mlp_dispatch(const clc_mlp_desc* d, bool bwd, clc_stream_t stream, const char* who) {
+  MlpParams p;
+  if (mlp_fill(d, p, bwd, who) < 0) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  switch (mlp_waves(d->M)) {
+    case 8: return mlp_launch<8>(p, bwd, st);
+    case 4: return mlp_launch<4>(p, bwd, st);
+    default: return mlp_launch<2>(p, bwd, st);
+  }
+}
+
+extern "C" int clc_mlp_fwd(const clc_mlp_desc* d, clc_stream_t stream) { return mlp_dispatch(d, false, stream, "clc_mlp_fwd"); }
+extern "C" int clc_mlp_bwd(const clc_mlp_desc* d, clc_stream_t stream) { return mlp_dispatch(d, true, stream, "clc_mlp_bwd"); }

@@ -339,6 +339,11 @@ class Block(nn.Module):
             f1 = ops.GradFold() if x.requires_grad else None
             x = self.msa(self.ln1(x, fold_in=f1, grad_slot=grad_slot), res=x, fold_out=f1)
             f2 = ops.GradFold() if x.requires_grad else None
+            if ops.mlp_fusable(x, self.mlp[0].weight, self.mlp[2].weight):
+                # large maps: fc1 + GELU + fc2 + residual in ONE launch, the 256-channel hidden tensor never leaves the registers; the
+                # backward pass recomputes it from the LayerNorm output (csrc/fused_mlp.hip) — same bits as the two launches below
+                return ops.mlp(self.ln2(x, fold_in=f2), self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias,
+                               res=x, fold_out=f2, out=out)
             g = ops.ActGate()
             h = self.mlp[0](self.ln2(x, fold_in=f2), act=ACT_GELU, gate_out=g)
             return self.mlp[2](h, res=x, fold_out=f2, out=out, gate_in=g)

@@ -53,6 +53,12 @@ class RUDesc(C.Structure):
                 ("saved_y", fp), ("saved_t2", fp), ("saved_t1", fp)]
 
 
+class MlpDesc(C.Structure):
+    _fields_ = [("x", fp), ("ldx", C.c_int), ("w1", fp), ("b1", fp), ("w2", fp), ("b2", fp), ("res", fp), ("ldr", C.c_int),
+                ("y", fp), ("ldy", C.c_int), ("M", C.c_long), ("Cin", C.c_int), ("Chid", C.c_int), ("Cout", C.c_int),
+                ("dy", fp), ("lddy", C.c_int), ("w2t", fp), ("dx", fp), ("lddx", C.c_int), ("dh", fp), ("g", fp)]
+
+
 class GDNEntry(C.Structure):
     _fields_ = [("gamma", fp), ("beta", fp), ("gamma_eff", fp), ("gamma_eff_t", fp), ("beta_eff", fp), ("C", C.c_int), ("first_block", C.c_int),
                 ("gamma_bound", C.c_float), ("beta_bound", C.c_float), ("pedestal", C.c_float)]
@@ -150,6 +156,8 @@ SIGNATURES = {
     "clc_avgpool2": (_i, [fp, _i, fp, _i, _i, _i, _i, fp]),
     "clc_residual_unit_fwd": (_i, [C.POINTER(RUDesc), fp]),
     "clc_residual_unit_dgrad": (_i, [C.POINTER(RUDesc), fp]),
+    "clc_mlp_fwd": (_i, [C.POINTER(MlpDesc), fp]),
+    "clc_mlp_bwd": (_i, [C.POINTER(MlpDesc), fp]),
     "clc_maxpool2d": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, fp]),
     "clc_adaptive_pool2d": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, _i, fp]),
     "clc_optim_chunk_elems": (_i, []),

@@ -1016,6 +1016,102 @@ def residual_unit(x, units):
     return _ResidualUnitFn.apply(x, len(units), *[t for u in units for t in u])
 
 
+# ----------------------------------------------------------------------------- fused Swin-block MLP (csrc/fused_mlp.hip)
+
+FUSED_MLP = int(os.environ.get("CLC_FUSED_MLP", "1"))              # 0: fc1 + GELU and fc2 as two clc_conv2d launches (A/B knob; same bits)
+FUSED_MLP_MIN_PIX = int(os.environ.get("CLC_FUSED_MLP_MIN", "32768"))   # pixels from which the persistent fused kernel pays (one workgroup per CU)
+
+
+def mlp_fusable(x, w1, w2, pair=None) -> bool:
+    """Linear(64 -> 256) GELU Linear(256 -> 64) on a map with enough pixels to give every CU a workgroup (the ConvTransBlocks' Swin blocks
+    on 128x128 / 64x64 maps at batch 8; the kernels produce the bits of the two-launch chain, so the choice may look at the batch)."""
+    if not FUSED_MLP or pair is not None or x.dim() != 4 or x.shape[1] != 64 or tuple(w1.shape) != (256, 64) or tuple(w2.shape) != (64, 256):
+        return False
+    M = x.shape[0] * x.shape[2] * x.shape[3]
+    return M >= FUSED_MLP_MIN_PIX and M % 32 == 0 and M < (1 << 24)
+
+
+def mlp_fwd_raw(x, w1, b1, w2, b2, res=None, out=None):
+    """One clc_mlp_fwd launch: out = res + fc2(gelu(fc1(x)))."""
+    _require_gpu(x, "mlp")
+    x, xp, N, H, W, Cin, ldx = nhwc(x)
+    if out is None:
+        out = new_act(N, w2.shape[0], H, W, x)
+    o, op, *_r, ldy = nhwc(out)
+    assert o is out, "mlp: output buffer must be pixel-major"
+    d = _lib.MlpDesc()
+    d.x, d.ldx, d.w1, d.w2 = xp, ldx, w1.data_ptr(), w2.data_ptr()
+    d.b1 = b1.data_ptr() if b1 is not None else None
+    d.b2 = b2.data_ptr() if b2 is not None else None
+    keep = [x, out]
+    if res is not None:
+        r, rp, *_r, ldr = nhwc(res)
+        d.res, d.ldr = rp, ldr
+        keep.append(r)
+    d.y, d.ldy, d.M, d.Cin, d.Chid, d.Cout = op, ldy, N * H * W, Cin, w1.shape[0], w2.shape[0]
+    _prof_hint(2.0 * N * H * W * 2 * Cin * w1.shape[0], f"mlp fwd {Cin}->{w1.shape[0]}->{w2.shape[0]} {N}x{H}x{W}")
+    _lib.check(_L().clc_mlp_fwd(C.byref(d), _stream()), "clc_mlp_fwd")
+    return out
+
+
+def mlp_bwd_raw(x, dy, w1, b1, w2t):
+    """One clc_mlp_bwd launch -> (dx, dh, g): the block's input gradient, and the two [N,256,H,W] tensors its filter gradients contract
+    (dh = d(fc1 pre-activation), g = gelu(fc1(x)) recomputed)."""
+    x, xp, N, H, W, Cin, ldx = nhwc(x)
+    dy, dp, *_r, lddy = nhwc(dy)
+    Ch = w1.shape[0]
+    dx, dh, g = new_act(N, Cin, H, W, x), new_act(N, Ch, H, W, x), new_act(N, Ch, H, W, x)
+    d = _lib.MlpDesc()
+    d.x, d.ldx, d.w1, d.w2 = xp, ldx, w1.data_ptr(), w1.data_ptr()   # (w2 itself is not read backward: its transposed image is)
+    d.b1 = b1.data_ptr() if b1 is not None else None
+    d.M, d.Cin, d.Chid, d.Cout = N * H * W, Cin, Ch, dy.shape[1]
+    d.dy, d.lddy, d.w2t, d.dx, d.lddx, d.dh, d.g = dp, lddy, w2t.data_ptr(), dx.data_ptr(), Cin, dh.data_ptr(), g.data_ptr()
+    # algorithmic work = the two data gradients (the recomputed fc1 is this path's overhead, not counted)
+    _prof_hint(2.0 * N * H * W * 2 * Cin * Ch, f"mlp dgrad {Cin}->{Ch}->{dy.shape[1]} {N}x{H}x{W}")
+    _lib.check(_L().clc_mlp_bwd(C.byref(d), _stream()), "clc_mlp_bwd")
+    return dx, dh, g
+
+
+class _MlpFn(Function):
+    """y = res + fc2(gelu(fc1(x))): ONE launch forward (hidden tensor kept in registers), ONE launch for the data gradient with the hidden
+    tensor recomputed from x, and the two layers' ordinary (grouped, deferred) filter-gradient problems.  The residual's gradient is parked
+    on `fold_out` (the LayerNorm in front adds it in its backward kernel), as _ConvFn does for fc2."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, res, fold_out, out_buf):
+        _own(ctx)
+        y = mlp_fwd_raw(x, w1, b1, w2, b2, res, out_buf)
+        if out_buf is not None:
+            y = out_buf.detach()
+        ctx.fold_out, ctx.has_res = fold_out, res is not None
+        ctx.has_b = (b1 is not None, b2 is not None)
+        ctx.save_for_backward(x, w1, b1, w2, b2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        _reown(ctx)
+        x, w1, b1, w2, b2 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dres = None
+        if ctx.has_res and need[5]:
+            if not (ctx.fold_out is not None and ctx.fold_out.park(dy, 1.0)):
+                dres = dy
+        dx, dh, g = mlp_bwd_raw(x, dy, w1, b1, _wt_of(w2))
+        dw1 = db1 = dw2 = db2 = None
+        if need[1] or (ctx.has_b[0] and need[2]):
+            dw1, db1 = _ConvFn._wgrad(x, dh, w1, b1, ctx.has_b[0], need[1], ctx.has_b[0] and need[2], 1, 1, 0, {})
+        if need[3] or (ctx.has_b[1] and need[4]):
+            dw2, db2 = _ConvFn._wgrad(g, dy, w2, b2, ctx.has_b[1], need[3], ctx.has_b[1] and need[4], 1, 1, 0, {})
+        return (dx if need[0] else None), dw1, db1, dw2, db2, dres, None, None
+
+
+def mlp(x, w1, b1, w2, b2, *, res=None, fold_out=None, out=None):
+    """x + fc2(gelu(fc1(LN(x)))) of a Swin block, fused (see mlp_fusable)."""
+    _note_grad_mode()
+    return _MlpFn.apply(x, w1, b1, w2, b2, res, fold_out, out)
+
+
 def linear(x, w, b=None, *, act=ACT_NONE, res=None, w2=None, b2=None, fold_in=None, fold_out=None, out=None, gate_in=None, gate_out=None):
     """nn.Linear on channels (tokens are pixels): x [N,Cin,H,W] pixel-major, w [Cout,Cin]."""
     _note_grad_mode()

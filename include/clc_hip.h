@@ -440,6 +440,34 @@ int clc_residual_unit_fwd(const clc_ru_desc* d, clc_stream_t stream);
  * gradients; layer 3's is dy gated by saved_y, which clc_conv2d_wgrad applies itself) and  y <- dx  (including the identity branch). */
 int clc_residual_unit_dgrad(const clc_ru_desc* d, clc_stream_t stream);
 
+/* ---- fused Swin-block MLP, round 4 ----
+ * `x + mlp(ln2(x))` of Block (/root/reference/models/CLC_run.py:185-187, 190-192) for the ConvTransBlocks' Swin blocks (trans_dim 64):
+ *   clc_mlp_fwd   y = res + W2 . gelu(W1 . x + b1) + b2     x [M][64] (leading dimension ldx) -> y [M][64] (ldy), res optional (ldr);
+ *                 w1 [256][64], w2 [64][256] (nn.Linear layout = clc_conv2d's 1x1 filter layout).  The 256-channel hidden tensor is
+ *                 never written: it goes from the first GEMM's accumulator registers straight into the second GEMM's operands.
+ *   clc_mlp_bwd   the block's whole DATA gradient from (x, dy) with the hidden tensor RECOMPUTED (fc1 again from the saved input):
+ *                 dh [M][256] = (W2^T dy) . gelu'(h)  and  g [M][256] = gelu(h)  (dense; the dy / x operands of fc1's / fc2's
+ *                 filter gradients, which stay on clc_conv2d_wgrad*), dx [M][64] (lddx) = W1^T dh.  w2t = clc_filter_transpose(w2)
+ *                 ([256][64]).
+ * Same summation order per output element and same epilogue expressions as the clc_conv2d launches they replace (fc1 + GELU with the
+ * stored derivative, fc2 + residual; their transposed / out_gate forms backward): THE SAME BITS, so either path may serve the codec.
+ * M = pixels (N * H * W of a pixel-major tensor), a multiple of 32.  Persistent workgroups, filters resident in LDS (129 KB). */
+typedef struct {
+  const float* x; int ldx;
+  const float* w1; const float* b1;
+  const float* w2; const float* b2;
+  const float* res; int ldr;
+  float* y; int ldy;
+  long M; int Cin, Chid, Cout;          /* 64, 256, 64 */
+  /* clc_mlp_bwd only */
+  const float* dy; int lddy;
+  const float* w2t;
+  float* dx; int lddx;
+  float* dh; float* g;
+} clc_mlp_desc;
+int clc_mlp_fwd(const clc_mlp_desc* d, clc_stream_t stream);
+int clc_mlp_bwd(const clc_mlp_desc* d, clc_stream_t stream);
+
 /* ---- reference-retrieval feature extractor: the pooling layers of torchvision's ResNet50 as the reference uses it ----
  * clc_maxpool2d        nn.MaxPool2d(ks, stride, pad) of resnet50.maxpool (/root/reference/dataloader_ref_cluster.py:41-44, dataloader_CLC.py:275),
  *                      pixel-major in / out, C and the leading dimensions multiples of 4.

@@ -859,3 +859,58 @@ def test_training_forward_long_k_layers_on_128x128_tiles(dev):
     assert torch.equal(y_one, y_eval[:2])                                       # inference: batch-independent bits
     (y_train.square().sum()).backward()                                         # and the ordinary backward still runs on its outputs
     assert torch.isfinite(w1.grad).all() and torch.isfinite(xg.grad).all()
+
+
+@pytest.mark.parametrize("N,H,W,strided", [(8, 64, 64, False), (2, 128, 128, True), (8, 128, 128, False), (1, 64, 96, True)])
+def test_fused_mlp_same_bits_as_two_launches(dev, N, H, W, strided):
+    """clc_mlp_fwd / clc_mlp_bwd (csrc/fused_mlp.hip: `x + fc2(gelu(fc1(LN x)))` of a Swin block in one launch, its data gradient with the
+    hidden tensor recomputed in one more) against (a) the two-launch chain of 1x1 convolutions it replaces — THE SAME BITS forward, for
+    dx, d(res) and all four parameter gradients — and (b) plain torch fp32.  2 / 4 / 8 waves per workgroup (6 144 .. 131 072 pixels), a
+    destination and an incoming gradient that are channel ranges of wider buffers (ConvTransBlock's conv1_2 input)."""
+    from clc_amd import layers, ops
+
+    torch.manual_seed(7)
+    fc1, fc2 = layers.Linear(64, 256).to(dev), layers.Linear(256, 64).to(dev)
+    with torch.no_grad():
+        fc1.bias.normal_(0, 0.3)
+        fc2.bias.normal_(0, 0.3)
+    x0 = (torch.randn(N, 64, H, W, device=dev) * 1.5).contiguous(memory_format=CL)
+    r0 = torch.randn(N, 64, H, W, device=dev).contiguous(memory_format=CL)
+    gy = torch.randn(N, 64, H, W, device=dev).contiguous(memory_format=CL)
+    wide = torch.randn(N, 128, H, W, device=dev).contiguous(memory_format=CL)
+    old_min = ops.FUSED_MLP_MIN_PIX
+    ops.FUSED_MLP_MIN_PIX = 1024
+    try:
+        assert ops.mlp_fusable(x0, fc1.weight, fc2.weight)
+        res = {}
+        for mode in ("fused", "chain"):
+            for prm in list(fc1.parameters()) + list(fc2.parameters()):
+                prm.grad = None
+            x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+            out = ops.new_act(N, 128, H, W, x0)[:, 64:] if strided else None
+            if mode == "fused":
+                y = ops.mlp(x, fc1.weight, fc1.bias, fc2.weight, fc2.bias, res=r, out=out)
+            else:
+                g = ops.ActGate()
+                y = fc2(fc1(x, act=ops.ACT_GELU, gate_out=g), res=r, out=out, gate_in=g)
+            dy = (wide[:, 64:] if strided else gy)
+            y.backward(dy)
+            torch.cuda.synchronize()
+            res[mode] = (y.detach().clone(), x.grad.clone(), r.grad.clone(), [prm.grad.clone() for prm in list(fc1.parameters()) + list(fc2.parameters())])
+    finally:
+        ops.FUSED_MLP_MIN_PIX = old_min
+    (yf, dxf, drf, pf), (yc, dxc, drc, pc) = res["fused"], res["chain"]
+    assert torch.equal(yf, yc), f"forward differs from the two-launch chain: max {(yf - yc).abs().max().item():.3e}"
+    assert torch.equal(dxf, dxc), f"dx differs: max {(dxf - dxc).abs().max().item():.3e}"
+    assert torch.equal(drf, drc)
+    for a, b, name in zip(pf, pc, ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")):
+        assert torch.equal(a, b), f"{name} gradient differs: max {(a - b).abs().max().item():.3e}"
+    # plain torch fp32 on the same values
+    with torch.no_grad():
+        hp = F.conv2d(x0, fc1.weight[:, :, None, None], fc1.bias)
+        want = F.conv2d(F.gelu(hp), fc2.weight[:, :, None, None], fc2.bias) + r0
+    _close(yf, want, 2e-5, "fused mlp forward vs torch")
+    xt = x0.clone().requires_grad_(True)
+    yt = F.conv2d(F.gelu(F.conv2d(xt, fc1.weight.detach()[:, :, None, None], fc1.bias.detach())), fc2.weight.detach()[:, :, None, None], fc2.bias.detach())
+    yt.backward(wide[:, 64:] if strided else gy)
+    _close(dxf, xt.grad, 1e-4, "fused mlp dx vs torch")

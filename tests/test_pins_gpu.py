@@ -25,18 +25,19 @@ def test_hip_gaussian_likelihood_vs_reference_model_method(dev, pins):
 
     to4 = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).reshape(1, 32, 12, 17).contiguous(memory_format=CL)   # 204 = 12 * 17 grid rows per column
     x, s, m = (to4(pins[k]).to(dev) for k in ("lik_inputs", "lik_scales", "lik_means"))
-    want = to4(pins["lik"]).clamp_min(1e-9)
+    FLOOR = float(np.float32(1e-9))        # the bound is a float32 buffer (likelihood_lower_bound.bound): 9.99999972e-10
+    want = to4(pins["lik"]).clamp_min(FLOOR)
     got, y_hat = ops.gaussian_likelihood(x, s, m, torch.zeros_like(x), True)
     got = got.cpu()
-    assert torch.isfinite(got).all() and float(got.min()) >= 1e-9
+    assert torch.isfinite(got).all() and float(got.min()) >= FLOOR
     big = want >= 1e-5
     rel = ((got - want).abs() / want)[big]
     assert float(rel.max()) <= 2e-6, f"bin-mass region: max relative error {float(rel.max()):.3e}"
-    tail = (~big) & (want > 1e-9)
+    tail = (~big) & (want > FLOOR)
     assert int(tail.sum()) > 50
     assert float((torch.log(got[tail]) - torch.log(want[tail])).abs().max()) <= 2e-3
-    floor = want == 1e-9
-    assert int(floor.sum()) > 100 and float((got[floor] - 1e-9).abs().max()) <= 1e-12
+    floor = want == FLOOR
+    assert int(floor.sum()) > 100 and float((got[floor] - FLOOR).abs().max()) <= 1e-15
 
 
 def _rd_inputs(pins, dev):
