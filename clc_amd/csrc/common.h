@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include "../../include/clc_hip.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -74,6 +75,27 @@ __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
   const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
   const float erf_abs = 1.0f - poly * eh;                                     // erf(|x|/sqrt2), eh = exp(-z^2)
   cdf = 0.5f + copysignf(0.5f * erf_abs, x);
+  pdf = 0.39894228040143267794f * eh;
+}
+// Two values at once on the packed-f32 VALU instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two IEEE operations per lane and
+// issue slot): the same operations in the same order as gelu_parts, element for element -> the same bits, 21 instructions per pair
+// instead of 2 x 19.  f32 MFMAs and VALU work do not overlap on gfx950 (the f32 matrix rate is the vector rate), so an epilogue's GELU
+// is paid in full: fc1 of a Swin MLP spends a quarter of its MFMA time in it.
+__device__ __forceinline__ void gelu_parts2(f32x2 x, f32x2& cdf, f32x2& pdf) {
+  const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+  const f32x2 z = ax * 0.70710678118654752440f;
+  const f32x2 d = __builtin_elementwise_fma((f32x2){0.3275911f, 0.3275911f}, z, (f32x2){1.0f, 1.0f});
+  const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  const f32x2 e = (-0.72134752044448170368f * x) * x;
+  const f32x2 eh = {exp2_fast(e[0]), exp2_fast(e[1])};
+  f32x2 q = __builtin_elementwise_fma(t, (f32x2){1.061405429f, 1.061405429f}, (f32x2){-1.453152027f, -1.453152027f});
+  q = __builtin_elementwise_fma(t, q, (f32x2){1.421413741f, 1.421413741f});
+  q = __builtin_elementwise_fma(t, q, (f32x2){-0.284496736f, -0.284496736f});
+  q = __builtin_elementwise_fma(t, q, (f32x2){0.254829592f, 0.254829592f});
+  const f32x2 poly = t * q;
+  const f32x2 erf_abs = 1.0f - poly * eh;
+  const f32x2 hh = 0.5f * erf_abs;
+  cdf = (f32x2){0.5f + copysignf(hh[0], x[0]), 0.5f + copysignf(hh[1], x[1])};
   pdf = 0.39894228040143267794f * eh;
 }
 __device__ __forceinline__ float gelu_f(float x) {

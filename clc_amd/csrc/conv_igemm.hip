@@ -289,11 +289,14 @@ __device__ __forceinline__ void epilogue_regs(const ConvParams& p, const RegEpi&
       // fc1 of the Swin MLPs: gelu'(v) is stored for the backward pass and gelu(v) is the result — one evaluation of the
       // erf / exp parts for both (the same expressions gelu_f / gelu_grad_f evaluate)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float cdf, pdf;
-        gelu_parts(v[r], cdf, pdf);
-        st32(cdf + v[r] * pdf, e.pre_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldp) * 4u);
-        v[r] = v[r] * cdf;
+      for (int r = 0; r < 16; r += 2) {   // (two values per packed-f32 instruction: gelu_parts2, same bits as gelu_parts)
+        f32x2 cdf, pdf;
+        const f32x2 vv = {v[r], v[r + 1]};
+        gelu_parts2(vv, cdf, pdf);
+        const f32x2 dd = cdf + vv * pdf, gg = vv * cdf;
+        st32(dd[0], e.pre_r, o, (unsigned)(CLC_ROWIDX(r) * p.ldp) * 4u);
+        st32(dd[1], e.pre_r, o, (unsigned)(CLC_ROWIDX(r + 1) * p.ldp) * 4u);
+        v[r] = gg[0]; v[r + 1] = gg[1];
       }
       act_done = true;
     } else if (p.pre_deriv) {
@@ -323,7 +326,13 @@ __device__ __forceinline__ void epilogue_regs(const ConvParams& p, const RegEpi&
       break;
     case CLC_ACT_GELU:
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = gelu_f(v[r]);
+      for (int r = 0; r < 16; r += 2) {
+        f32x2 cdf, pdf;
+        const f32x2 vv = {v[r], v[r + 1]};
+        gelu_parts2(vv, cdf, pdf);
+        const f32x2 gg = vv * cdf;
+        v[r] = gg[0]; v[r + 1] = gg[1];
+      }
       break;
     case CLC_ACT_NONE: break;
     default:

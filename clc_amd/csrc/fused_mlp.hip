@@ -42,6 +42,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct MlpParams {
   const float* x; const float* w1; const float* b1; const float* w2; const float* b2; const float* res; float* y;
   const float* dy; const float* w2t; float* dx; float* dh; float* g;
+  float* hsave;                 // [M][256] fc1 pre-activation: written by the forward pass (optional), read instead of recomputed backward
   int ldx, ldr, ldy, lddy, lddx;
   int M, tiles;
   unsigned x_bytes, res_bytes, y_bytes, dy_bytes, dx_bytes, hid_bytes;
@@ -76,8 +77,16 @@ __device__ __forceinline__ void fill_image(float* img, const float* src, int row
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 // ---------------------------------------------------------------------------------------------------------------- forward
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void mlp_fwd_kernel(const MlpParams p) {
+// Measured on the way (8 x 128 x 128, one launch, graph-replayed; tools/bench_mlp.py with CLC_TUNING=12:x):
+//   * f32 MFMAs and VALU instructions do NOT overlap on this hardware (the f32 matrix rate IS the vector rate): the GELU's ~19 VALU
+//     instructions per value add their full time (20 us of 111) whether they are interleaved with the MFMAs or not, with one or two
+//     waves per SIMD.  A software pipeline that issued the next block's fc1 MFMAs between the GELU of the current one was SLOWER
+//     (111.7 vs 98.6 us) than the plain loop: nothing to hide, more registers and hazards;
+//   * consecutive MFMAs on ONE accumulator pay the dependent-issue latency (a block of 32 dependent 32x32x2 MFMAs ran at ~83 % of the
+//     independent rate), so two hidden blocks are computed side by side and every MFMA alternates between two accumulators;
+//   * LDS fragment reads cost nothing measurable (ablated: 105 vs 111 us).
+template <int NW, int ABL = 0>   // ABL: timing diagnostics of CLC_TUNE_ABLATE (results WRONG): 1 = no GELU arithmetic, 2 = no fc1 MFMAs, 4 = no LDS fragment reads
+__global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_kernel(const MlpParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W1s = smem;                    // [2][256][32]  fc1: rows = hidden, K = input channels
   float* W2s = W1s + 2 * CH * 32;       // [8][64][32]   fc2: rows = output channels, K = hidden
@@ -88,71 +97,107 @@ __global__ __launch_bounds__(64 * NW) void mlp_fwd_kernel(const MlpParams p) {
   fill_image<NW>(W2s, p.w2, CO, CH, wave, lane);
   for (int i = tid; i < CH; i += 64 * NW) b1s[i] = p.b1 ? p.b1[i] : 0.f;
   for (int i = tid; i < CO; i += 64 * NW) b2s[i] = p.b2 ? p.b2[i] : 0.f;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
 
   const __amdgpu_buffer_rsrc_t xr = srd(p.x, p.x_bytes), rr = srd(p.res ? p.res : p.x, p.res ? p.res_bytes : p.x_bytes), yr = srd(p.y, p.y_bytes);
+  const __amdgpu_buffer_rsrc_t hr = srd(p.hsave ? p.hsave : p.y, p.hsave ? p.hid_bytes : p.y_bytes);
   const int sw = (li >> 1) & 7;
   int fo[4];
 #pragma unroll
   for (int t8 = 0; t8 < 4; ++t8) fo[t8] = ((2 * t8 + h) ^ sw) << 2;
   const float* W1l = W1s + (li << 5);   // this lane's row inside a 32-row block of an image
   const float* W2l = W2s + (li << 5);
+  const float* b1l = b1s + 4 * h;
+  auto load_x = [&](int t, f32x4 (&xf)[2][4]) {   // a tile past the end reads zeros through the SRD's range check
+    const int p0 = (t * NW + wave) * 32;
+    const unsigned xo = ((unsigned)(p0 + li) * (unsigned)p.ldx + 4u * h) * 4u;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int t8 = 0; t8 < 4; ++t8) xf[kt][t8] = ld4(xr, p0 < p.M ? xo + (unsigned)(kt * 32 + 8 * t8) * 4u : kOOB);
+  };
+  f32x4 xf[2][4], xn[2][4];
+  load_x(blockIdx.x, xn);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the filter images' DMA pieces and the first pixels)
+  __syncthreads();
 
   for (int t = blockIdx.x; t < p.tiles; t += gridDim.x) {
     const int p0 = (t * NW + wave) * 32;
-    if (p0 >= p.M) continue;            // wave-uniform; there is no barrier below
     const unsigned pix = (unsigned)(p0 + li);
-    f32x4 xf[2][4];
-    {
-      const unsigned xo = (pix * (unsigned)p.ldx + 4u * h) * 4u;
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int t8 = 0; t8 < 4; ++t8) xf[kt][t8] = ld4(xr, xo + (unsigned)(kt * 32 + 8 * t8) * 4u);
-    }
+      for (int t8 = 0; t8 < 4; ++t8) xf[kt][t8] = xn[kt][t8];
+    load_x(t + gridDim.x, xn);          // the next tile's pixels: in flight under this tile's 512 MFMAs
+    if (p0 >= p.M) continue;            // wave-uniform; there is no barrier below
     f32x16 yacc[2];
 #pragma unroll
     for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
       for (int r = 0; r < 16; ++r) yacc[ob][r] = 0.f;
 
-#pragma unroll 2
-    for (int hb = 0; hb < 8; ++hb) {
-      f32x16 hacc;
+#pragma unroll 1
+    for (int hp = 0; hp < 4; ++hp) {    // two 32-channel blocks of the hidden layer side by side
+      f32x16 hacc[2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
+        for (int r = 0; r < 16; ++r) hacc[b][r] = 0.f;
+      const float* w1b = W1l + ((hp * 64) << 5);
 #pragma unroll
-        for (int t8 = 0; t8 < 4; ++t8) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(W1l + ((kt * CH + hb * 32) << 5) + fo[t8]);
+      for (int j = 0; j < 8; ++j) {       // K-steps (kt, t8) in the tiled kernels' order
+        f32x4 a[2];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) hacc = MFMA(a[s], xf[kt][t8][s], hacc);
+        for (int b = 0; b < 2; ++b) a[b] = (ABL & 4) ? xf[b][j & 3] : *reinterpret_cast<const f32x4*>(w1b + (((j >> 2) * CH + b * 32) << 5) + fo[j & 3]);
+        if (ABL & 2) { asm volatile("" ::"v"(a[0]), "v"(a[1])); continue; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) hacc[b] = MFMA(a[b][s], xf[j >> 2][j & 3][s], hacc[b]);
+      }
+      // bias + GELU in the accumulator registers (register 4 q + s of block b = hidden channel (2 hp + b) * 32 + 8 q + 4 h + s)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 bq = *reinterpret_cast<const f32x4*>(b1l + (2 * hp + b) * 32 + 8 * q);
+          f32x4 v;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) v[s] = hacc[b][4 * q + s] + bq[s];
+          if (p.hsave) st4(v, hr, (pix * (unsigned)CH + (unsigned)((2 * hp + b) * 32 + 8 * q + 4 * h)) * 4u);   // (training, save mode)
+#pragma unroll
+          for (int s = 0; s < 4; s += 2) {
+            if (ABL & 1) { hacc[b][4 * q + s] = v[s]; hacc[b][4 * q + s + 1] = v[s + 1]; continue; }
+            f32x2 cdf, pdf;
+            const f32x2 vv = {v[s], v[s + 1]};
+            gelu_parts2(vv, cdf, pdf);
+            const f32x2 gg = vv * cdf;
+            hacc[b][4 * q + s] = gg[0]; hacc[b][4 * q + s + 1] = gg[1];
+          }
         }
-      // bias + GELU in the accumulator registers (register 4 q + s = hidden channel hb * 32 + 8 q + 4 h + s)
+      // fc2: K-tiles 2 hp, 2 hp + 1 of the hidden layer; B operands = the registers just computed
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + hb * 32 + 8 * q + 4 * h);
+      for (int b = 0; b < 2; ++b) {
+        const float* w2b = W2l + (((2 * hp + b) * CO) << 5);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const float v = hacc[4 * q + s] + bq[s];
-          float cdf, pdf;
-          gelu_parts(v, cdf, pdf);
-          hacc[4 * q + s] = v * cdf;
+        for (int q = 0; q < 4; ++q) {
+          f32x4 a[2];
+#pragma unroll
+          for (int ob = 0; ob < 2; ++ob) a[ob] = (ABL & 4) ? xf[ob][q] : *reinterpret_cast<const f32x4*>(w2b + ((ob * 32) << 5) + fo[q]);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) yacc[ob] = MFMA(a[ob][s], hacc[b][4 * q + s], yacc[ob]);
         }
       }
-      // fc2: K-tile hb of the hidden layer, its B operands are the registers just computed
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int ob = 0; ob < 2; ++ob) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(W2l + ((hb * CO + ob * 32) << 5) + fo[q]);
-#pragma unroll
-          for (int s = 0; s < 4; ++s) yacc[ob] = MFMA(a[s], hacc[4 * q + s], yacc[ob]);
-        }
     }
     // epilogue: y = (acc + b2) + 1 * res, 16 B per lane
+    f32x4 rv[2][4];
+    if (p.res) {
+#pragma unroll
+      for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rv[ob][q] = ld4(rr, (pix * (unsigned)p.ldr + (unsigned)(ob * 32 + 8 * q + 4 * h)) * 4u);
+    }
 #pragma unroll
     for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
@@ -163,9 +208,8 @@ __global__ __launch_bounds__(64 * NW) void mlp_fwd_kernel(const MlpParams p) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) v[s] = yacc[ob][4 * q + s] + bq[s];
         if (p.res) {
-          const f32x4 rv = ld4(rr, (pix * (unsigned)p.ldr + (unsigned)c0) * 4u);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) v[s] += 1.0f * rv[s];
+          for (int s = 0; s < 4; ++s) v[s] += 1.0f * rv[ob][q][s];
         }
         st4(v, yr, (pix * (unsigned)p.ldy + (unsigned)c0) * 4u);
       }
@@ -173,8 +217,11 @@ __global__ __launch_bounds__(64 * NW) void mlp_fwd_kernel(const MlpParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------- backward
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const MlpParams p) {
+// LOADH: the forward pass saved the fc1 pre-activation (clc_mlp_desc.h): it is read back (134 MB per 8 x 128 x 128 block, on a kernel that is
+// MFMA / VALU-bound either way) instead of recomputed (256 of a tile's 768 MFMAs).
+// Two hidden blocks side by side, as forward: consecutive MFMAs never share an accumulator.
+template <int NW, bool LOADH>
+__global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const MlpParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W1s = smem;                    // [2][256][32]  fc1 filter: rows = hidden, K = input channels (also read column-wise for dx)
   float* Wts = W1s + 2 * CH * 32;       // [2][256][32]  fc2 filter transposed: rows = hidden, K = output channels
@@ -187,7 +234,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const MlpParams p) {
   __syncthreads();
 
   const __amdgpu_buffer_rsrc_t xr = srd(p.x, p.x_bytes), dyr = srd(p.dy, p.dy_bytes), dxr = srd(p.dx, p.dx_bytes);
-  const __amdgpu_buffer_rsrc_t dhr = srd(p.dh, p.hid_bytes), gr = srd(p.g, p.hid_bytes);
+  const __amdgpu_buffer_rsrc_t dhr = srd(p.dh, p.hid_bytes), gr = srd(p.g, p.hid_bytes), hr = srd(LOADH ? p.hsave : p.g, p.hid_bytes);
   const int sw = (li >> 1) & 7;
   int fo[4];
 #pragma unroll
@@ -205,7 +252,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const MlpParams p) {
 
   for (int t = blockIdx.x; t < p.tiles; t += gridDim.x) {
     const int p0 = (t * NW + wave) * 32;
-    if (p0 >= p.M) continue;
+    if (p0 >= p.M) continue;            // wave-uniform; no barrier below
     const unsigned pix = (unsigned)(p0 + li);
     f32x4 xf[2][4], df[2][4];
     {
@@ -214,7 +261,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const MlpParams p) {
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int t8 = 0; t8 < 4; ++t8) {
-          xf[kt][t8] = ld4(xr, xo + (unsigned)(kt * 32 + 8 * t8) * 4u);
+          if (!LOADH) xf[kt][t8] = ld4(xr, xo + (unsigned)(kt * 32 + 8 * t8) * 4u);
           df[kt][t8] = ld4(dyr, yo + (unsigned)(kt * 32 + 8 * t8) * 4u);
         }
     }
@@ -225,47 +272,76 @@ __global__ __launch_bounds__(64 * NW) void mlp_bwd_kernel(const MlpParams p) {
       for (int r = 0; r < 16; ++r) dxacc[ib][r] = 0.f;
 
 #pragma unroll 1
-    for (int hb = 0; hb < 8; ++hb) {
-      f32x16 hacc, uacc;
+    for (int hp = 0; hp < 4; ++hp) {
+      f32x16 hacc[2], uacc[2];
+      const unsigned ho = (pix * (unsigned)CH + (unsigned)(hp * 64 + 4 * h)) * 4u;
+      f32x4 hv[2][4];
+      if (LOADH) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { hacc[r] = 0.f; uacc[r] = 0.f; }
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int t8 = 0; t8 < 4; ++t8) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(W1l + ((kt * CH + hb * 32) << 5) + fo[t8]);
-          const f32x4 b = *reinterpret_cast<const f32x4*>(Wtl + ((kt * CH + hb * 32) << 5) + fo[t8]);
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            hacc = MFMA(a[s], xf[kt][t8][s], hacc);
-            uacc = MFMA(b[s], df[kt][t8][s], uacc);
-          }
-        }
-      const unsigned ho = (pix * (unsigned)CH + (unsigned)(hb * 32 + 4 * h)) * 4u;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + hb * 32 + 8 * q + 4 * h);
-        f32x4 gv, dv;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const float v = hacc[4 * q + s] + bq[s];
-          float cdf, pdf;
-          gelu_parts(v, cdf, pdf);
-          gv[s] = v * cdf;
-          dv[s] = (uacc[4 * q + s] + 0.f) * (cdf + v * pdf);   // (the unfused data-gradient epilogue adds its absent bias as 0.f first)
-          uacc[4 * q + s] = dv[s];
-        }
-        st4(gv, gr, ho + (unsigned)(8 * q) * 4u);
-        st4(dv, dhr, ho + (unsigned)(8 * q) * 4u);
+          for (int q = 0; q < 4; ++q) hv[b][q] = ld4(hr, ho + (unsigned)(b * 32 + 8 * q) * 4u);
       }
-      // dx += W1^T[:, hb] dh
-      const float* colb = W1s + ((hb * 32) << 5);
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { hacc[b][r] = 0.f; uacc[b][r] = 0.f; }
+      const int rowb = (hp * 64) << 5;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {       // K-steps (kt, t8) in the tiled kernels' order
+        const int ko = (((j >> 2) * CH) << 5) + rowb + fo[j & 3];
+        f32x4 a[2], c[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          if (!LOADH) a[b] = *reinterpret_cast<const f32x4*>(W1l + ko + ((b * 32) << 5));
+          c[b] = *reinterpret_cast<const f32x4*>(Wtl + ko + ((b * 32) << 5));
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int ib = 0; ib < 2; ++ib) dxacc[ib] = MFMA(colb[((ib * CH) << 5) + co_[q][s]], uacc[4 * q + s], dxacc[ib]);
+          for (int b = 0; b < 2; ++b) {
+            if (!LOADH) hacc[b] = MFMA(a[b][s], xf[j >> 2][j & 3][s], hacc[b]);
+            uacc[b] = MFMA(c[b][s], df[j >> 2][j & 3][s], uacc[b]);
+          }
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v;
+          if (LOADH) v = hv[b][q];
+          else {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(b1s + hp * 64 + b * 32 + 8 * q + 4 * h);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) v[s] = hacc[b][4 * q + s] + bq[s];
+          }
+          f32x4 gv, dv;
+#pragma unroll
+          for (int s = 0; s < 4; s += 2) {
+            f32x2 cdf, pdf;
+            const f32x2 vv = {v[s], v[s + 1]};
+            gelu_parts2(vv, cdf, pdf);
+            const f32x2 gg = vv * cdf, dd = cdf + vv * pdf;
+            const f32x2 uu = {uacc[b][4 * q + s] + 0.f, uacc[b][4 * q + s + 1] + 0.f};   // (the unfused data-gradient epilogue adds its absent bias as 0.f first)
+            const f32x2 dh2 = uu * dd;
+            gv[s] = gg[0]; gv[s + 1] = gg[1];
+            dv[s] = dh2[0]; dv[s + 1] = dh2[1];
+            uacc[b][4 * q + s] = dh2[0]; uacc[b][4 * q + s + 1] = dh2[1];
+          }
+          st4(gv, gr, ho + (unsigned)(b * 32 + 8 * q) * 4u);
+          st4(dv, dhr, ho + (unsigned)(b * 32 + 8 * q) * 4u);
+        }
+      // dx += W1^T[:, hidden blocks 2 hp, 2 hp + 1] dh   (K-tiles in order, the two input-channel blocks alternate)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float* colb = W1s + rowb + ((b * 32) << 5);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) dxacc[ib] = MFMA(colb[((ib * CH) << 5) + co_[q][s]], uacc[b][4 * q + s], dxacc[ib]);
+      }
     }
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib)
@@ -291,8 +367,10 @@ static int mlp_fill(const clc_mlp_desc* d, MlpParams& p, bool bwd, const char* w
   CLC_CHECK(bytes(d->M, d->ldx, CI) < (1ull << 31) && bytes(d->M, CH, CH) < (1ull << 31), "%s: tensor larger than 2 GiB", who);
   p.x = d->x; p.ldx = d->ldx; p.w1 = d->w1; p.b1 = d->b1; p.w2 = d->w2; p.b2 = d->b2; p.M = (int)d->M;
   p.x_bytes = (unsigned)bytes(d->M, d->ldx, CI);
-  p.res = nullptr; p.y = nullptr; p.dy = nullptr; p.w2t = nullptr; p.dx = nullptr; p.dh = nullptr; p.g = nullptr;
-  p.ldr = p.ldy = p.lddy = p.lddx = 0; p.res_bytes = p.y_bytes = p.dy_bytes = p.dx_bytes = p.hid_bytes = 0;
+  p.res = nullptr; p.y = nullptr; p.dy = nullptr; p.w2t = nullptr; p.dx = nullptr; p.dh = nullptr; p.g = nullptr; p.hsave = d->h;
+  CLC_CHECK(!d->h || aligned16(d->h), "%s: h unaligned", who);
+  p.hid_bytes = (unsigned)bytes(d->M, CH, CH);
+  p.ldr = p.ldy = p.lddy = p.lddx = 0; p.res_bytes = p.y_bytes = p.dy_bytes = p.dx_bytes = 0;
   if (!bwd) {
     CLC_CHECK(d->y && ok(d->y, d->ldy, CO) && ok(d->res, d->ldr, CO), "%s: y / res missing or unaligned", who);
     CLC_CHECK(bytes(d->M, d->ldy, CO) < (1ull << 31) && (!d->res || bytes(d->M, d->ldr, CO) < (1ull << 31)), "%s: tensor larger than 2 GiB", who);
@@ -304,7 +382,7 @@ static int mlp_fill(const clc_mlp_desc* d, MlpParams& p, bool bwd, const char* w
     CLC_CHECK(bytes(d->M, d->lddy, CO) < (1ull << 31) && bytes(d->M, d->lddx, CI) < (1ull << 31), "%s: tensor larger than 2 GiB", who);
     p.dy = d->dy; p.lddy = d->lddy; p.dy_bytes = (unsigned)bytes(d->M, d->lddy, CO);
     p.w2t = d->w2t; p.dx = d->dx; p.lddx = d->lddx; p.dx_bytes = (unsigned)bytes(d->M, d->lddx, CI);
-    p.dh = d->dh; p.g = d->g; p.hid_bytes = (unsigned)bytes(d->M, CH, CH);
+    p.dh = d->dh; p.g = d->g;
   }
   return 0;
 }
@@ -320,10 +398,22 @@ static int mlp_launch(MlpParams& p, bool bwd, hipStream_t st) {
   static PerDeviceOnce attr_once;
   if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
   }
-  if (bwd) hipLaunchKernelGGL(mlp_bwd_kernel<NW>, dim3(grid), dim3(64 * NW), lds_b, st, p);
-  else hipLaunchKernelGGL(mlp_fwd_kernel<NW>, dim3(grid), dim3(64 * NW), lds_f, st, p);
+  const int abl = clc_tuning[CLC_TUNE_ABLATE];
+  if (bwd && p.hsave) hipLaunchKernelGGL((mlp_bwd_kernel<NW, true>), dim3(grid), dim3(64 * NW), lds_b, st, p);
+  else if (bwd) hipLaunchKernelGGL((mlp_bwd_kernel<NW, false>), dim3(grid), dim3(64 * NW), lds_b, st, p);
+  else if (NW == 8 && abl) {   // timing diagnostics (wrong results): see the template argument
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<8, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+    if (abl == 1) hipLaunchKernelGGL((mlp_fwd_kernel<8, 1>), dim3(grid), dim3(512), lds_f, st, p);
+    else if (abl == 2) hipLaunchKernelGGL((mlp_fwd_kernel<8, 2>), dim3(grid), dim3(512), lds_f, st, p);
+    else if (abl == 4) hipLaunchKernelGGL((mlp_fwd_kernel<8, 4>), dim3(grid), dim3(512), lds_f, st, p);
+    else hipLaunchKernelGGL((mlp_fwd_kernel<8, 5>), dim3(grid), dim3(512), lds_f, st, p);
+  } else hipLaunchKernelGGL(mlp_fwd_kernel<NW>, dim3(grid), dim3(64 * NW), lds_f, st, p);
   CLC_LAUNCH_CHECK();
   return 0;
 }

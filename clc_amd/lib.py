@@ -56,7 +56,7 @@ class RUDesc(C.Structure):
 class MlpDesc(C.Structure):
     _fields_ = [("x", fp), ("ldx", C.c_int), ("w1", fp), ("b1", fp), ("w2", fp), ("b2", fp), ("res", fp), ("ldr", C.c_int),
                 ("y", fp), ("ldy", C.c_int), ("M", C.c_long), ("Cin", C.c_int), ("Chid", C.c_int), ("Cout", C.c_int),
-                ("dy", fp), ("lddy", C.c_int), ("w2t", fp), ("dx", fp), ("lddx", C.c_int), ("dh", fp), ("g", fp)]
+                ("dy", fp), ("lddy", C.c_int), ("w2t", fp), ("dx", fp), ("lddx", C.c_int), ("dh", fp), ("g", fp), ("h", fp)]
 
 
 class GDNEntry(C.Structure):

@@ -1020,6 +1020,8 @@ def residual_unit(x, units):
 
 FUSED_MLP = int(os.environ.get("CLC_FUSED_MLP", "1"))              # 0: fc1 + GELU and fc2 as two clc_conv2d launches (A/B knob; same bits)
 FUSED_MLP_MIN_PIX = int(os.environ.get("CLC_FUSED_MLP_MIN", "32768"))   # pixels from which the persistent fused kernel pays (one workgroup per CU)
+MLP_SAVE_H = int(os.environ.get("CLC_MLP_SAVE_H", "1"))            # training: 1 = the forward pass stores fc1's pre-activation and the backward kernel reads it;
+                                                                   # 0 = nothing stored, the backward kernel recomputes it from the LayerNorm output (same bits)
 
 
 def mlp_fusable(x, w1, w2, pair=None) -> bool:
@@ -1031,8 +1033,8 @@ def mlp_fusable(x, w1, w2, pair=None) -> bool:
     return M >= FUSED_MLP_MIN_PIX and M % 32 == 0 and M < (1 << 24)
 
 
-def mlp_fwd_raw(x, w1, b1, w2, b2, res=None, out=None):
-    """One clc_mlp_fwd launch: out = res + fc2(gelu(fc1(x)))."""
+def mlp_fwd_raw(x, w1, b1, w2, b2, res=None, out=None, h_out=None):
+    """One clc_mlp_fwd launch: out = res + fc2(gelu(fc1(x))); h_out ([N,256,H,W], optional) receives fc1's pre-activation."""
     _require_gpu(x, "mlp")
     x, xp, N, H, W, Cin, ldx = nhwc(x)
     if out is None:
@@ -1049,14 +1051,17 @@ def mlp_fwd_raw(x, w1, b1, w2, b2, res=None, out=None):
         d.res, d.ldr = rp, ldr
         keep.append(r)
     d.y, d.ldy, d.M, d.Cin, d.Chid, d.Cout = op, ldy, N * H * W, Cin, w1.shape[0], w2.shape[0]
+    if h_out is not None:
+        assert h_out.is_contiguous(memory_format=CL)
+        d.h = h_out.data_ptr()
     _prof_hint(2.0 * N * H * W * 2 * Cin * w1.shape[0], f"mlp fwd {Cin}->{w1.shape[0]}->{w2.shape[0]} {N}x{H}x{W}")
     _lib.check(_L().clc_mlp_fwd(C.byref(d), _stream()), "clc_mlp_fwd")
     return out
 
 
-def mlp_bwd_raw(x, dy, w1, b1, w2t):
+def mlp_bwd_raw(x, dy, w1, b1, w2t, h_saved=None):
     """One clc_mlp_bwd launch -> (dx, dh, g): the block's input gradient, and the two [N,256,H,W] tensors its filter gradients contract
-    (dh = d(fc1 pre-activation), g = gelu(fc1(x)) recomputed)."""
+    (dh = d(fc1 pre-activation), g = gelu(fc1(x)) — fc1(x) read from h_saved, or recomputed from x when that is None)."""
     x, xp, N, H, W, Cin, ldx = nhwc(x)
     dy, dp, *_r, lddy = nhwc(dy)
     Ch = w1.shape[0]
@@ -1066,6 +1071,8 @@ def mlp_bwd_raw(x, dy, w1, b1, w2t):
     d.b1 = b1.data_ptr() if b1 is not None else None
     d.M, d.Cin, d.Chid, d.Cout = N * H * W, Cin, Ch, dy.shape[1]
     d.dy, d.lddy, d.w2t, d.dx, d.lddx, d.dh, d.g = dp, lddy, w2t.data_ptr(), dx.data_ptr(), Cin, dh.data_ptr(), g.data_ptr()
+    if h_saved is not None:
+        d.h = h_saved.data_ptr()
     # algorithmic work = the two data gradients (the recomputed fc1 is this path's overhead, not counted)
     _prof_hint(2.0 * N * H * W * 2 * Cin * Ch, f"mlp dgrad {Cin}->{Ch}->{dy.shape[1]} {N}x{H}x{W}")
     _lib.check(_L().clc_mlp_bwd(C.byref(d), _stream()), "clc_mlp_bwd")
@@ -1080,24 +1087,25 @@ class _MlpFn(Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, res, fold_out, out_buf):
         _own(ctx)
-        y = mlp_fwd_raw(x, w1, b1, w2, b2, res, out_buf)
+        hs = new_act(x.shape[0], w1.shape[0], x.shape[2], x.shape[3], x) if (MLP_SAVE_H and _recording(ctx)) else None
+        y = mlp_fwd_raw(x, w1, b1, w2, b2, res, out_buf, hs)
         if out_buf is not None:
             y = out_buf.detach()
         ctx.fold_out, ctx.has_res = fold_out, res is not None
         ctx.has_b = (b1 is not None, b2 is not None)
-        ctx.save_for_backward(x, w1, b1, w2, b2)
+        ctx.save_for_backward(x, w1, b1, w2, b2, hs)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         _reown(ctx)
-        x, w1, b1, w2, b2 = ctx.saved_tensors
+        x, w1, b1, w2, b2, hs = ctx.saved_tensors
         need = ctx.needs_input_grad
         dres = None
         if ctx.has_res and need[5]:
             if not (ctx.fold_out is not None and ctx.fold_out.park(dy, 1.0)):
                 dres = dy
-        dx, dh, g = mlp_bwd_raw(x, dy, w1, b1, _wt_of(w2))
+        dx, dh, g = mlp_bwd_raw(x, dy, w1, b1, _wt_of(w2), hs)
         dw1 = db1 = dw2 = db2 = None
         if need[1] or (ctx.has_b[0] and need[2]):
             dw1, db1 = _ConvFn._wgrad(x, dh, w1, b1, ctx.has_b[0], need[1], ctx.has_b[0] and need[2], 1, 1, 0, {})

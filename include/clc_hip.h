@@ -464,6 +464,9 @@ typedef struct {
   const float* w2t;
   float* dx; int lddx;
   float* dh; float* g;
+  /* optional, both directions: h [M][256] dense = the fc1 PRE-activation (W1 x + b1).  clc_mlp_fwd writes it when non-NULL (training,
+   * "save" mode); clc_mlp_bwd then reads it instead of recomputing it (256 of a tile's 768 MFMAs for 134 MB of traffic per 8x128x128). */
+  float* h;
 } clc_mlp_desc;
 int clc_mlp_fwd(const clc_mlp_desc* d, clc_stream_t stream);
 int clc_mlp_bwd(const clc_mlp_desc* d, clc_stream_t stream);

@@ -861,8 +861,9 @@ def test_training_forward_long_k_layers_on_128x128_tiles(dev):
     assert torch.isfinite(w1.grad).all() and torch.isfinite(xg.grad).all()
 
 
+@pytest.mark.parametrize("save_h", [1, 0])
 @pytest.mark.parametrize("N,H,W,strided", [(8, 64, 64, False), (2, 128, 128, True), (8, 128, 128, False), (1, 64, 96, True)])
-def test_fused_mlp_same_bits_as_two_launches(dev, N, H, W, strided):
+def test_fused_mlp_same_bits_as_two_launches(dev, N, H, W, strided, save_h):
     """clc_mlp_fwd / clc_mlp_bwd (csrc/fused_mlp.hip: `x + fc2(gelu(fc1(LN x)))` of a Swin block in one launch, its data gradient with the
     hidden tensor recomputed in one more) against (a) the two-launch chain of 1x1 convolutions it replaces — THE SAME BITS forward, for
     dx, d(res) and all four parameter gradients — and (b) plain torch fp32.  2 / 4 / 8 waves per workgroup (6 144 .. 131 072 pixels), a
@@ -878,8 +879,8 @@ def test_fused_mlp_same_bits_as_two_launches(dev, N, H, W, strided):
     r0 = torch.randn(N, 64, H, W, device=dev).contiguous(memory_format=CL)
     gy = torch.randn(N, 64, H, W, device=dev).contiguous(memory_format=CL)
     wide = torch.randn(N, 128, H, W, device=dev).contiguous(memory_format=CL)
-    old_min = ops.FUSED_MLP_MIN_PIX
-    ops.FUSED_MLP_MIN_PIX = 1024
+    old_min, old_save = ops.FUSED_MLP_MIN_PIX, ops.MLP_SAVE_H
+    ops.FUSED_MLP_MIN_PIX, ops.MLP_SAVE_H = 1024, save_h   # (save_h: fc1's pre-activation stored forward / recomputed backward)
     try:
         assert ops.mlp_fusable(x0, fc1.weight, fc2.weight)
         res = {}
@@ -898,7 +899,7 @@ def test_fused_mlp_same_bits_as_two_launches(dev, N, H, W, strided):
             torch.cuda.synchronize()
             res[mode] = (y.detach().clone(), x.grad.clone(), r.grad.clone(), [prm.grad.clone() for prm in list(fc1.parameters()) + list(fc2.parameters())])
     finally:
-        ops.FUSED_MLP_MIN_PIX = old_min
+        ops.FUSED_MLP_MIN_PIX, ops.MLP_SAVE_H = old_min, old_save
     (yf, dxf, drf, pf), (yc, dxc, drc, pc) = res["fused"], res["chain"]
     assert torch.equal(yf, yc), f"forward differs from the two-launch chain: max {(yf - yc).abs().max().item():.3e}"
     assert torch.equal(dxf, dxc), f"dx differs: max {(dxf - dxc).abs().max().item():.3e}"
