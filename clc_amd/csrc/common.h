@@ -28,7 +28,9 @@ enum { CLC_TUNE_DMA_LOOP = 0 /* 1: conv_igemm_dma_kernel, 2: conv_igemm_dma2_ker
        CLC_TUNE_ATTN_4B = 16 /* window attention: the N = head_dim products on 4-block 16x16x1 MFMAs; bit mask: 1 = head_dim 16, 2 = head_dim-8 backward, 4 = head_dim-8 forward (off: see winattn.hip) */,
        CLC_TUNE_HEAVY128 = 17 /* long-K 3x3 layers on <= 16x16 maps (the slice-parameter nets): 128x128 LDS tiles with the K range split to fill the chip */,
        CLC_TUNE_ATTN_SPLIT = 18 /* attention backward on small grids (<= 1024 workgroups): two workgroups per window group, one tile each */,
-       CLC_TUNE_COUNT = 19 };
+       CLC_TUNE_MLP_PK = 19 /* fused Swin MLP forward: GELU on the packed-f32 VALU instructions (same bits either way) */,
+       CLC_TUNE_W1X1 = 20 /* large-map 1x1 layers whose filter fits in LDS on the wave-private kernel (conv_w1x1_kernel); same bits */,
+       CLC_TUNE_COUNT = 21 };
 extern int clc_tuning[CLC_TUNE_COUNT];
 
 #define CLC_CHECK(cond, ...)            \

@@ -85,7 +85,8 @@ __device__ __forceinline__ void fill_image(float* img, const float* src, int row
 //   * consecutive MFMAs on ONE accumulator pay the dependent-issue latency (a block of 32 dependent 32x32x2 MFMAs ran at ~83 % of the
 //     independent rate), so two hidden blocks are computed side by side and every MFMA alternates between two accumulators;
 //   * LDS fragment reads cost nothing measurable (ablated: 105 vs 111 us).
-template <int NW, int ABL = 0>   // ABL: timing diagnostics of CLC_TUNE_ABLATE (results WRONG): 1 = no GELU arithmetic, 2 = no fc1 MFMAs, 4 = no LDS fragment reads
+// SAVE: store fc1's pre-activation (training, save mode).  PK: GELU on the packed-f32 instructions (gelu_parts2; same bits).
+template <int NW, int ABL = 0, bool SAVE = false, bool PK = true>   // ABL: timing diagnostics of CLC_TUNE_ABLATE (results WRONG): 1 = no GELU arithmetic, 2 = no fc1 MFMAs, 4 = no LDS fragment reads
 __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_kernel(const MlpParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W1s = smem;                    // [2][256][32]  fc1: rows = hidden, K = input channels
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_kernel(const MlpParams p) 
   for (int i = tid; i < CO; i += 64 * NW) b2s[i] = p.b2 ? p.b2[i] : 0.f;
 
   const __amdgpu_buffer_rsrc_t xr = srd(p.x, p.x_bytes), rr = srd(p.res ? p.res : p.x, p.res ? p.res_bytes : p.x_bytes), yr = srd(p.y, p.y_bytes);
-  const __amdgpu_buffer_rsrc_t hr = srd(p.hsave ? p.hsave : p.y, p.hsave ? p.hid_bytes : p.y_bytes);
+  const __amdgpu_buffer_rsrc_t hr = srd(SAVE ? p.hsave : p.y, SAVE ? p.hid_bytes : p.y_bytes);
   const int sw = (li >> 1) & 7;
   int fo[4];
 #pragma unroll
@@ -163,15 +164,24 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_kernel(const MlpParams p) 
           f32x4 v;
 #pragma unroll
           for (int s = 0; s < 4; ++s) v[s] = hacc[b][4 * q + s] + bq[s];
-          if (p.hsave) st4(v, hr, (pix * (unsigned)CH + (unsigned)((2 * hp + b) * 32 + 8 * q + 4 * h)) * 4u);   // (training, save mode)
+          if (SAVE) st4(v, hr, (pix * (unsigned)CH + (unsigned)((2 * hp + b) * 32 + 8 * q + 4 * h)) * 4u);   // (training, save mode)
 #pragma unroll
           for (int s = 0; s < 4; s += 2) {
             if (ABL & 1) { hacc[b][4 * q + s] = v[s]; hacc[b][4 * q + s + 1] = v[s + 1]; continue; }
-            f32x2 cdf, pdf;
-            const f32x2 vv = {v[s], v[s + 1]};
-            gelu_parts2(vv, cdf, pdf);
-            const f32x2 gg = vv * cdf;
-            hacc[b][4 * q + s] = gg[0]; hacc[b][4 * q + s + 1] = gg[1];
+            if (PK) {
+              f32x2 cdf, pdf;
+              const f32x2 vv = {v[s], v[s + 1]};
+              gelu_parts2(vv, cdf, pdf);
+              const f32x2 gg = vv * cdf;
+              hacc[b][4 * q + s] = gg[0]; hacc[b][4 * q + s + 1] = gg[1];
+            } else {
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                float cdf, pdf;
+                gelu_parts(v[s + e], cdf, pdf);
+                hacc[b][4 * q + s + e] = v[s + e] * cdf;
+              }
+            }
           }
         }
       // fc2: K-tiles 2 hp, 2 hp + 1 of the hidden layer; B operands = the registers just computed
@@ -397,23 +407,27 @@ static int mlp_launch(MlpParams& p, bool bwd, hipStream_t st) {
   const size_t lds_f = (size_t)(2 * CH * 32 + 8 * CO * 32 + CH + CO) * sizeof(float), lds_b = (size_t)(4 * CH * 32 + CH) * sizeof(float);
   static PerDeviceOnce attr_once;
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+    auto optin = [&](auto kern) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f); };
+    optin(&mlp_fwd_kernel<NW, 0, true, true>); optin(&mlp_fwd_kernel<NW, 0, false, true>);
+    optin(&mlp_fwd_kernel<NW, 0, true, false>); optin(&mlp_fwd_kernel<NW, 0, false, false>);
+    if (NW == 8) { optin(&mlp_fwd_kernel<8, 1>); optin(&mlp_fwd_kernel<8, 2>); optin(&mlp_fwd_kernel<8, 4>); optin(&mlp_fwd_kernel<8, 5>); }
   }
   const int abl = clc_tuning[CLC_TUNE_ABLATE];
+  auto fwd = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_f, st, p); };
   if (bwd && p.hsave) hipLaunchKernelGGL((mlp_bwd_kernel<NW, true>), dim3(grid), dim3(64 * NW), lds_b, st, p);
   else if (bwd) hipLaunchKernelGGL((mlp_bwd_kernel<NW, false>), dim3(grid), dim3(64 * NW), lds_b, st, p);
   else if (NW == 8 && abl) {   // timing diagnostics (wrong results): see the template argument
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<8, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<8, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
-    if (abl == 1) hipLaunchKernelGGL((mlp_fwd_kernel<8, 1>), dim3(grid), dim3(512), lds_f, st, p);
-    else if (abl == 2) hipLaunchKernelGGL((mlp_fwd_kernel<8, 2>), dim3(grid), dim3(512), lds_f, st, p);
-    else if (abl == 4) hipLaunchKernelGGL((mlp_fwd_kernel<8, 4>), dim3(grid), dim3(512), lds_f, st, p);
-    else hipLaunchKernelGGL((mlp_fwd_kernel<8, 5>), dim3(grid), dim3(512), lds_f, st, p);
-  } else hipLaunchKernelGGL(mlp_fwd_kernel<NW>, dim3(grid), dim3(64 * NW), lds_f, st, p);
+    if (abl == 1) fwd(&mlp_fwd_kernel<8, 1>);
+    else if (abl == 2) fwd(&mlp_fwd_kernel<8, 2>);
+    else if (abl == 4) fwd(&mlp_fwd_kernel<8, 4>);
+    else fwd(&mlp_fwd_kernel<8, 5>);
+  } else if (clc_tuning[CLC_TUNE_MLP_PK]) {
+    if (p.hsave) fwd(&mlp_fwd_kernel<NW, 0, true, true>); else fwd(&mlp_fwd_kernel<NW, 0, false, true>);
+  } else {
+    if (p.hsave) fwd(&mlp_fwd_kernel<NW, 0, true, false>); else fwd(&mlp_fwd_kernel<NW, 0, false, false>);
+  }
   CLC_LAUNCH_CHECK();
   return 0;
 }
