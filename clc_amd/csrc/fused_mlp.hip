@@ -76,6 +76,30 @@ __device__ __forceinline__ void fill_image(float* img, const float* src, int row
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// Store one 32-pixel x 32-channel block that a wave holds in the accumulator layout (lane (pixel li, half h): the 16-B quads q = 0..3 at
+// channels 8 q + 4 h) as FULL 128-B lines.  Stored straight from that layout every instruction would write 32-B pieces of 32 different
+// lines — measured on the plain 1x1 layers (conv_w1x1_kernel, built and removed in round 4): 1.7 TB/s where whole-line stores reach
+// 3.5-4 TB/s, and the 268 MB of dh / g per 8 x 128 x 128 block made the backward kernel store-bound.  So the block goes through a 2 KB
+// wave-private LDS scratch, 16 pixels at a time (chunk c of pixel p in slot c ^ (p & 7): conflict-free both ways), and comes back with
+// 8 lanes per pixel.  No barrier: one wave's LDS operations execute in program order.
+__device__ __forceinline__ void store_block_lines(float* scratch, const f32x4 (&v)[4], __amdgpu_buffer_rsrc_t dst, unsigned pix0, unsigned ld, unsigned ch0,
+                                                  int lane, int li, int h) {
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) {
+    if ((li >> 4) == rd) {
+      float* row = scratch + ((li & 15) << 5);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(row + ((((2 * q + h) ^ (li & 7))) << 2)) = v[q];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int pl = 8 * k + (lane >> 3), j = lane & 7;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(scratch + (pl << 5) + ((j ^ (pl & 7)) << 2));
+      st4(t, dst, ((pix0 + (unsigned)(16 * rd + pl)) * ld + ch0 + (unsigned)(j * 4)) * 4u);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- forward
 // Measured on the way (8 x 128 x 128, one launch, graph-replayed; tools/bench_mlp.py with CLC_TUNING=12:x):
 //   * f32 MFMAs and VALU instructions do NOT overlap on this hardware (the f32 matrix rate IS the vector rate): the GELU's ~19 VALU
@@ -237,6 +261,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const MlpParams p) 
   float* Wts = W1s + 2 * CH * 32;       // [2][256][32]  fc2 filter transposed: rows = hidden, K = output channels
   float* b1s = Wts + 2 * CH * 32;       // [256]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+  float* scratch = b1s + CH + wave * 512;   // 2 KB per wave: store_block_lines
   fill_image<NW>(W1s, p.w1, CH, CI, wave, lane);
   fill_image<NW>(Wts, p.w2t, CH, CO, wave, lane);
   for (int i = tid; i < CH; i += 64 * NW) b1s[i] = p.b1 ? p.b1[i] : 0.f;
@@ -315,7 +340,8 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const MlpParams p) 
           }
       }
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < 2; ++b) {
+        f32x4 gq[4], dq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           f32x4 v;
@@ -338,9 +364,12 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const MlpParams p) 
             dv[s] = dh2[0]; dv[s + 1] = dh2[1];
             uacc[b][4 * q + s] = dh2[0]; uacc[b][4 * q + s + 1] = dh2[1];
           }
-          st4(gv, gr, ho + (unsigned)(b * 32 + 8 * q) * 4u);
-          st4(dv, dhr, ho + (unsigned)(b * 32 + 8 * q) * 4u);
+          gq[q] = gv; dq[q] = dv;
         }
+        // g and dh to HBM as whole 128-B lines (the operands of the two filter gradients)
+        store_block_lines(scratch, gq, gr, (unsigned)p0, (unsigned)CH, (unsigned)(hp * 64 + b * 32), lane, li, h);
+        store_block_lines(scratch, dq, dhr, (unsigned)p0, (unsigned)CH, (unsigned)(hp * 64 + b * 32), lane, li, h);
+      }
       // dx += W1^T[:, hidden blocks 2 hp, 2 hp + 1] dh   (K-tiles in order, the two input-channel blocks alternate)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
@@ -404,7 +433,7 @@ template <int NW>
 static int mlp_launch(MlpParams& p, bool bwd, hipStream_t st) {
   p.tiles = (p.M + 32 * NW - 1) / (32 * NW);
   const int grid = p.tiles < 256 ? p.tiles : 256;   // persistent: one workgroup per CU (129 KB of LDS), filters deposited once
-  const size_t lds_f = (size_t)(2 * CH * 32 + 8 * CO * 32 + CH + CO) * sizeof(float), lds_b = (size_t)(4 * CH * 32 + CH) * sizeof(float);
+  const size_t lds_f = (size_t)(2 * CH * 32 + 8 * CO * 32 + CH + CO) * sizeof(float), lds_b = (size_t)(4 * CH * 32 + CH + NW * 512) * sizeof(float);
   static PerDeviceOnce attr_once;
   if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
