@@ -250,8 +250,6 @@ def _kernel_name(L, r):
                 f"{(variant >> 24) & 3}, {'true' if (variant >> 26) & 1 else 'false'}>")   # (..., OP: 1 = squared operand (GDN's norm convolution), BF: bf16 MFMA)
     if f == 8:        # the persistent pipelined kernel of the large-map 1x1 layers
         return f"conv_igemm_p1x1_kernel<{(variant >> 24) & 3}>"
-    if f == 9:        # the wave-private kernel of the large-map 1x1 layers whose filter fits in LDS: <KT, NB, OP, NW>
-        return f"conv_w1x1_kernel<{(variant >> 8) & 255}, {variant & 255}, {(variant >> 24) & 3}, {(variant >> 16) & 15}>"
     return f"conv_igemm{ {1: '', 2: '_dma'}[f]}_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}>"
 
 
@@ -416,8 +414,7 @@ def roofline_leg(engine, x, refs):
     t = t_replay if t_replay is not None else t_eager
     # the 1x1 / linear instantiation (..., 1>) moves ~50 FLOP per byte on 128-channel layers — under the f32 ridge once the residual and
     # saved-activation streams are counted — so its roofline is HBM; everything else is MFMA
-    hbm_bound = ((name.startswith("conv_igemm_dma2_kernel") and (", 1, 0, " in name or ", 1, 1, " in name)) or name.startswith("conv_igemm_p1x1_kernel")
-                 or name.startswith("conv_w1x1_kernel")) and nb > 0
+    hbm_bound = ((name.startswith("conv_igemm_dma2_kernel") and (", 1, 0, " in name or ", 1, 1, " in name)) or name.startswith("conv_igemm_p1x1_kernel")) and nb > 0
     achieved = (nb / t / 1e9) if hbm_bound else (f / t / 1e12)
     peak = HBM_PEAK_GBS if hbm_bound else F32_MFMA_PEAK_TFLOPS
     # HBM-side bytes per launch of that kernel from the committed PMC passes (separate `rocprofv3 --pmc FETCH_SIZE` /

@@ -1080,108 +1080,6 @@ void conv_igemm_p1x1_kernel(const ConvParams p, int tiles_m, int tiles_n) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// WAVE-PRIVATE kernel for the large-map 1x1 convolutions / linears whose whole filter fits in LDS (round 4; the structure of
-// csrc/fused_mlp.hip, which is where it was measured first: two chained GEMMs incl. a GELU in 98 us where conv_igemm_p1x1_kernel needs
-// 64 us for one).  Differences to conv_igemm_p1x1_kernel:
-//   * a wave owns 32 pixels and ALL output channels (NB = Cout / 32 accumulator blocks): its operand rows are its own, fetched once,
-//     straight into MFMA-operand registers (16 B per lane and K-step) — no operand tile in LDS, no barrier anywhere in the main loop,
-//     the waves of a workgroup drift apart so that one wave's epilogue traffic runs under another wave's MFMAs;
-//   * the filter ([Cout][Cin] <= 128 KB) is deposited ONCE per persistent workgroup as slot-swizzled [K-tile][row][32] LDS images and
-//     every K-step's NB fragments are conflict-free ds_read_b128 — no re-fetch per pixel tile;
-//   * MFMA roles swapped (A = filter rows, B = pixels): lane (pixel = lane & 31, h = lane >> 5) holds channels 8 (r >> 2) + 4 h + (r & 3)
-//     of a block in register r, i.e. four consecutive channels in four consecutive registers, so the epilogue is epilogue_math4 on
-//     16-B quads with dwordx4 loads / stores (4 store instructions per block and tensor instead of 16);
-//   * consecutive MFMAs alternate between the NB accumulators (no dependent-issue stalls).
-// Same K order per output element (K-tile, 8-group, step -> channel pair {8 t + s, 8 t + 4 + s}; a product commutes) and the same
-// epilogue arithmetic as the tiled kernels -> the same bits (tools/bench_ab.py compares them launch by launch).
-template <int NW>
-__device__ __forceinline__ void fill_filter_image(float* img, const float* src, unsigned src_bytes, int rows, int kcols, int ldw, int wave, int lane) {
-  const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
-  const int per_kt = rows >> 3, n = (kcols >> 5) * per_kt;
-  for (int ii = wave; ii < n; ii += NW) {
-    const int kt = ii / per_kt, r0 = (ii - kt * per_kt) << 3;
-    const int row = r0 + (lane >> 3), chunk = (lane & 7) ^ ((row >> 1) & 7);
-    dma16(sr, img + ((kt * rows + r0) << 5), ((unsigned)row * (unsigned)ldw + (unsigned)(kt * 32 + chunk * 4)) * 4u);
-  }
-}
-template <int KT, int NB, int OP, int NW>
-__global__ __launch_bounds__(64 * NW, 2)
-void conv_w1x1_kernel(const ConvParams p, int tiles) {
-  constexpr int ROWS = NB * 32;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ws = smem;                        // [KT][ROWS][32], slot-swizzled
-  float* bias_s = Ws + KT * ROWS * 32;     // [ROWS]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
-  fill_filter_image<NW>(Ws, p.w, p.w_bytes, ROWS, KT * 32, p.ldw, wave, lane);
-  for (int i = tid; i < ROWS; i += 64 * NW) bias_s[i] = p.bias ? p.bias[i] : 0.f;
-  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
-  const RegEpi re = make_reg_epi(p);
-  const int sw = (li >> 1) & 7;
-  int fo[4];
-#pragma clang loop unroll(full)
-  for (int t8 = 0; t8 < 4; ++t8) fo[t8] = ((2 * t8 + h) ^ sw) << 2;
-  const float* Wl = Ws + (li << 5);
-  auto ld4 = [](__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); };
-  auto st4 = [](f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned off) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0); };
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
-    const int p0 = (t * NW + wave) * 32;
-    if (p0 >= p.M) continue;              // wave-uniform; no barrier below
-    const unsigned pix = (unsigned)(p0 + li);
-    f32x4 xf[KT][4];
-    {
-      const unsigned xo = (pix * (unsigned)p.ldx + 4u * h) * 4u;
-#pragma clang loop unroll(full)
-      for (int kt = 0; kt < KT; ++kt)
-#pragma clang loop unroll(full)
-        for (int t8 = 0; t8 < 4; ++t8) {
-          xf[kt][t8] = ld4(xr, xo + (unsigned)(kt * 32 + 8 * t8) * 4u);
-          if (OP == 1) xf[kt][t8] = xf[kt][t8] * xf[kt][t8];
-        }
-    }
-    f32x16 acc[NB];
-#pragma clang loop unroll(full)
-    for (int nb = 0; nb < NB; ++nb)
-#pragma clang loop unroll(full)
-      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-#pragma clang loop unroll(full)
-    for (int kt = 0; kt < KT; ++kt)
-#pragma clang loop unroll(full)
-      for (int t8 = 0; t8 < 4; ++t8) {
-        f32x4 a[NB];
-#pragma clang loop unroll(full)
-        for (int nb = 0; nb < NB; ++nb) a[nb] = *reinterpret_cast<const f32x4*>(Wl + ((kt * ROWS + nb * 32) << 5) + fo[t8]);
-#pragma clang loop unroll(full)
-        for (int s = 0; s < 4; ++s)
-#pragma clang loop unroll(full)
-          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb][s], xf[kt][t8][s], acc[nb], 0, 0, 0);
-      }
-    // epilogue: 16-B quads (pixel, channels c0 .. c0 + 3), the arithmetic of epilogue_store4
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    const bool has_rg = re.has_rg, has_mul = re.has_mul;
-#pragma clang loop unroll(full)
-    for (int nb = 0; nb < NB; ++nb)
-#pragma clang loop unroll(full)
-      for (int q = 0; q < 4; ++q) {
-        const unsigned c0 = (unsigned)(nb * 32 + 8 * q + 4 * h);
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + c0);
-        f32x4 a4;
-#pragma clang loop unroll(full)
-        for (int s = 0; s < 4; ++s) a4[s] = acc[nb][4 * q + s];
-        const f32x4 rr = p.res ? ld4(re.res_r, (pix * (unsigned)p.ldr + c0) * 4u) : z;
-        const f32x4 rg = has_rg ? ld4(re.rg_r, (pix * (unsigned)p.ldg + c0) * 4u) : z;
-        const f32x4 mv = has_mul ? ld4(re.mul_r, (pix * (unsigned)p.ldm + c0) * 4u) : z;
-        const f32x4 og = p.out_gate ? ld4(re.og_r, (pix * (unsigned)p.ldog + c0) * 4u) : z;
-        const Epi4 o = epilogue_math4(p, bv, a4, rr, rg, mv, og);
-        if (p.y_pre) st4(o.pre, re.pre_r, (pix * (unsigned)p.ldp + c0) * 4u);
-        st4(o.y, re.y_r, (pix * (unsigned)p.ldy + c0) * 4u);
-      }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Small maps (<= 16x16 per image): latency, not MFMA rate, is what matters (a 64->64 3x3 at 8x16x16 is 0.15 GFLOP).
 // One 32 x BN output tile per workgroup of KW = 8 waves; wave w owns K-tiles w, w+8, ... and loads its MFMA fragments
 // STRAIGHT from global memory into registers in operand layout (lane (i,h) needs 4 consecutive k of its own row i:
@@ -1432,36 +1330,6 @@ int launch_p1x1(const ConvParams& p, int classes, hipStream_t st) {
   else hipLaunchKernelGGL((conv_igemm_p1x1_kernel<0>), dim3(grid), dim3(512), lds, st, p, tiles_m, tiles_n);
   CLC_LAUNCH_CHECK();
   return (8 << 20) | ((p.in_op == CLC_IN_SQUARE ? 1 : 0) << 24) | (4 << 16) | (2 << 12) | (128 << 3) | (64 >> 5);   // family 8 = conv_igemm_p1x1_kernel<OP>
-}
-// wave-private 1x1 kernel: eligibility + launch; returns 0 when the layer does not qualify (the caller falls through)
-template <int KT, int NB, int OP, int NW>
-int launch_w1x1_t(const ConvParams& p, hipStream_t st) {
-  const int tiles = (p.M + 32 * NW - 1) / (32 * NW);
-  const int grid = tiles < 256 ? tiles : 256;   // persistent, one workgroup per CU
-  const size_t lds = (size_t)(KT * NB * 32 * 32 + NB * 32) * sizeof(float);
-  static PerDeviceOnce attr_once;
-  if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_w1x1_kernel<KT, NB, OP, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((conv_w1x1_kernel<KT, NB, OP, NW>), dim3(grid), dim3(64 * NW), lds, st, p, tiles);
-  CLC_LAUNCH_CHECK();
-  return (9 << 20) | (OP << 24) | (NW << 16) | (KT << 8) | NB;   // family 9 = conv_w1x1_kernel<KT, NB, OP, NW>
-}
-template <int KT, int NB, int OP>
-int launch_w1x1_n(const ConvParams& p, hipStream_t st) {
-  return p.M >= 65536 ? launch_w1x1_t<KT, NB, OP, 8>(p, st) : launch_w1x1_t<KT, NB, OP, 4>(p, st);
-}
-int launch_w1x1(const ConvParams& p, int classes, hipStream_t st) {
-  if (!clc_tuning[CLC_TUNE_W1X1] || classes != 1 || p.ks != 1 || p.stride != 1 || p.shuffle || p.group_rows || p.xs || p.ksplit > 1) return 0;
-  if (p.M % 32 || p.M < 32768 || p.Cin % 32 || p.Cout % 32 || !(p.in_op == CLC_IN_NONE || p.in_op == CLC_IN_SQUARE)) return 0;
-  if (!reg_epi_ok(p, 32, 32) || (size_t)p.M * (size_t)p.ldx * 4 >= (1ull << 31)) return 0;
-  const int kt = p.Cin / 32, nb = p.Cout / 32, sq = p.in_op == CLC_IN_SQUARE;
-  if (sq) return (kt == 4 && nb == 4) ? launch_w1x1_n<4, 4, 1>(p, st) : 0;
-  if (kt == 2 && nb == 2) return launch_w1x1_n<2, 2, 0>(p, st);
-  if (kt == 2 && nb == 6) return launch_w1x1_n<2, 6, 0>(p, st);
-  if (kt == 6 && nb == 2) return launch_w1x1_n<6, 2, 0>(p, st);
-  if (kt == 4 && nb == 4) return launch_w1x1_n<4, 4, 0>(p, st);
-  if (kt == 2 && nb == 8) return launch_w1x1_n<2, 8, 0>(p, st);
-  if (kt == 8 && nb == 2) return launch_w1x1_n<8, 2, 0>(p, st);
-  return 0;
 }
 template <int BM, int BN, int WM, int WN>
 int launch(const ConvParams& p, int classes, hipStream_t st) {
@@ -1753,11 +1621,12 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   // 8 waves per tile (4 per SIMD at 2 workgroups/CU): measured +3..15 % over 4 waves on every large-map shape
   // (1x1 128->128 @128^2: 63 -> 73 TF); the summation order per output element does not depend on the wave grid
   // (CLC_TUNE_1X1_TILE: HBM-bound 1x1 layers with few K-tiles on the narrower tile — 48 KB of LDS, three workgroups per CU)
-  if (d->ks == 1 && C >= 64 && vec_ok) {   // wave-private kernel (CLC_TUNE_W1X1) where the whole filter fits in LDS ...
-    const int v = launch_w1x1(p, classes, st);
-    if (v) return v;
-  }
-  if (d->ks == 1 && C > 32 && vec_ok) {   // ... else the persistent pipelined kernel (CLC_TUNE_P1X1), where the layer qualifies
+  // (Round 4 built a WAVE-PRIVATE variant of this — conv_w1x1_kernel: a wave owns 32 pixels and all output channels, filter resident in
+  // LDS, operands straight into registers, swapped MFMA roles with 16-B epilogue quads, no barrier — bit-identical, and 1.2-2.1x SLOWER:
+  // 128->128 61 -> 103 us, 64->256 + stored derivative 82 -> 177, 64->192 47 -> 92.  Every access of that layout touches 32 B of a 128-B
+  // line (1.5-2 TB/s where the row pieces of epilogue_regs / LDS-DMA reach 3.3-4.2).  Removed; the structure pays only where two GEMMs
+  // are chained through the registers: csrc/fused_mlp.hip.)
+  if (d->ks == 1 && C > 32 && vec_ok) {   // persistent pipelined kernel (CLC_TUNE_P1X1), where the layer qualifies
     const int v = launch_p1x1(p, classes, st);
     if (v) return v;
   }

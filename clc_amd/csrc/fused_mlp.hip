@@ -91,11 +91,18 @@ __device__ __forceinline__ void store_block_lines(float* scratch, const f32x4 (&
 #pragma unroll
       for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(row + ((((2 * q + h) ^ (li & 7))) << 2)) = v[q];
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the other lanes' quads are in the scratch (and the compiler keeps the order)
+    f32x4 t[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int pl = 8 * k + (lane >> 3), j = lane & 7;
-      const f32x4 t = *reinterpret_cast<const f32x4*>(scratch + (pl << 5) + ((j ^ (pl & 7)) << 2));
-      st4(t, dst, ((pix0 + (unsigned)(16 * rd + pl)) * ld + ch0 + (unsigned)(j * 4)) * 4u);
+      t[k] = *reinterpret_cast<const f32x4*>(scratch + (pl << 5) + ((j ^ (pl & 7)) << 2));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read out before the next round overwrites it
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int pl = 8 * k + (lane >> 3), j = lane & 7;
+      st4(t[k], dst, ((pix0 + (unsigned)(16 * rd + pl)) * ld + ch0 + (unsigned)(j * 4)) * 4u);
     }
   }
 }

@@ -1020,8 +1020,9 @@ def residual_unit(x, units):
 
 FUSED_MLP = int(os.environ.get("CLC_FUSED_MLP", "1"))              # 0: fc1 + GELU and fc2 as two clc_conv2d launches (A/B knob; same bits)
 FUSED_MLP_MIN_PIX = int(os.environ.get("CLC_FUSED_MLP_MIN", "32768"))   # pixels from which the persistent fused kernel pays (one workgroup per CU)
-MLP_SAVE_H = int(os.environ.get("CLC_MLP_SAVE_H", "1"))            # training: 1 = the forward pass stores fc1's pre-activation and the backward kernel reads it;
-                                                                   # 0 = nothing stored, the backward kernel recomputes it from the LayerNorm output (same bits)
+MLP_SAVE_H = int(os.environ.get("CLC_MLP_SAVE_H", "0"))            # training: 0 = nothing stored, the backward kernel recomputes fc1 from the LayerNorm output;
+                                                                   # 1 = the forward pass stores fc1's pre-activation and the backward kernel reads it (same bits;
+                                                                   #     111 vs 133 us per launch at 8x128x128, and the same step time: the 134 MB it writes cost as much)
 
 
 def mlp_fusable(x, w1, w2, pair=None) -> bool:

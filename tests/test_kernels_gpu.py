@@ -915,64 +915,3 @@ def test_fused_mlp_same_bits_as_two_launches(dev, N, H, W, strided, save_h):
     yt = F.conv2d(F.gelu(F.conv2d(xt, fc1.weight.detach()[:, :, None, None], fc1.bias.detach())), fc2.weight.detach()[:, :, None, None], fc2.bias.detach())
     yt.backward(wide[:, 64:] if strided else gy)
     _close(dxf, xt.grad, 1e-4, "fused mlp dx vs torch")
-
-
-W1X1_CASES = [
-    # Cin, Cout, N, H, W, epilogue
-    (64, 64, 2, 128, 128, "res"), (64, 192, 2, 128, 128, "bias"), (192, 64, 8, 64, 64, "plain"), (128, 128, 2, 128, 128, "res"),
-    (64, 256, 8, 64, 64, "gelu_pre"), (256, 64, 2, 128, 128, "res"), (64, 256, 2, 128, 128, "out_gate"), (128, 128, 8, 64, 64, "gdn"),
-    (128, 128, 8, 128, 128, "lrelu_strided"),
-]
-
-
-@pytest.mark.parametrize("Cin,Cout,N,H,W,epi", W1X1_CASES)
-def test_wave_private_1x1_kernel_same_bits_as_tiled(dev, Cin, Cout, N, H, W, epi):
-    """conv_w1x1_kernel (tuning key 20: a wave owns 32 pixels and all output channels, filter resident in LDS, swapped MFMA roles, 16-B
-    epilogue quads) against the kernels it replaces (key 20 off: the persistent / tiled 1x1 kernels) on the same launch: THE SAME BITS
-    for every epilogue form the step uses — bias, residual, GELU with the stored derivative, a consumer's activation gate, GDN's
-    squared operand + x * rsqrt(.) + skip, a strided destination — and against torch fp32."""
-    from clc_amd import lib as _clib
-    from clc_amd import ops
-
-    L = _clib.load()
-    g = torch.Generator().manual_seed(Cin * 1000 + Cout)
-    x = _dev(torch.randn(N, Cin, H, W, generator=g), dev)
-    w = _dev(torch.randn(Cout, Cin, 1, 1, generator=g) * 0.1, dev)
-    b = torch.randn(Cout, generator=g).to(dev)
-    r = _dev(torch.randn(N, Cout, H, W, generator=g), dev)
-    sv = _dev(torch.randn(N, Cout, H, W, generator=g), dev)
-    kw = dict(ks=1)
-    if epi == "res":
-        kw.update(res=r, res_scale=1.0)
-    elif epi == "gelu_pre":
-        kw.update(act=ops.ACT_GELU, pre_deriv=True)
-    elif epi == "out_gate":
-        kw.update(out_gate=(sv, ops.ACT_SAVED_DERIV, True))
-    elif epi == "gdn":
-        kw.update(in_op=ops.IN_SQUARE, norm=ops.NORM_GDN, mul=x, res=r)
-        w = w.abs() * 0.1
-        b = b.abs() + 1.0
-    elif epi == "lrelu_strided":
-        kw.update(act=ops.ACT_LRELU, res=r, res_scale=2.0)
-    outs = {}
-    for key in (0, 1):
-        prev = L.clc_set_tuning(20, key)
-        try:
-            pre = ops.new_act(N, Cout, H, W, x) if epi == "gelu_pre" else None
-            out = ops.new_act(N, 2 * Cout, H, W, x)[:, Cout:] if epi == "lrelu_strided" else None
-            y = ops.conv_raw(x, w, None if epi == "plain" else b, y_pre=pre, out=out, **kw)
-            torch.cuda.synchronize()
-            outs[key] = (y.clone(), pre.clone() if pre is not None else None)
-        finally:
-            L.clc_set_tuning(20, prev)
-    assert torch.equal(outs[0][0], outs[1][0]), f"differs from the tiled kernel: max {(outs[0][0] - outs[1][0]).abs().max().item():.3e}"
-    if epi == "gelu_pre":
-        assert torch.equal(outs[0][1], outs[1][1])
-    with torch.no_grad():
-        if epi == "gdn":
-            want = x * torch.rsqrt(F.conv2d(x * x, w, b)) + r
-        else:
-            v = F.conv2d(x, w, None if epi == "plain" else b)
-            want = {"res": lambda: v + r, "bias": lambda: v, "plain": lambda: v, "gelu_pre": lambda: F.gelu(v), "out_gate": lambda: v * sv,
-                    "lrelu_strided": lambda: F.leaky_relu(v, 0.01) + 2.0 * r}[epi]()
-    _close(outs[1][0], want, 2e-5, f"w1x1 {Cin}->{Cout} {epi} vs torch")
