@@ -1242,12 +1242,12 @@ static int heavy128_split(const ConvParams& p, int classes) {
   while (k > 1 && ksteps / k < 16) --k;
   return k;
 }
-// how many ways clc_conv2d would split the K range of a data-gradient launch on bm x 64 tiles (1: not at all)
-static int conv_ksplit(const ConvParams& p, int classes, int bm = 64) {
+// how many ways clc_conv2d would split the K range of a 64x64-tile data-gradient launch (1: not at all)
+static int conv_ksplit(const ConvParams& p, int classes) {
   { const int k128 = heavy128_split(p, classes); if (k128 > 1) return k128; }
   if (!clc_tuning[CLC_TUNE_DGRAD_SPLITK] || !p.transposed || !p.vec_epi || p.in_op != CLC_IN_NONE || p.xs || p.shuffle) return 1;
-  if (p.M % bm || p.Cout % 64) return 1;
-  const long wgs = (long)(p.M / bm) * (p.Cout / 64) * classes;
+  if (p.M % 64 || p.Cout % 64) return 1;
+  const long wgs = (long)(p.M / 64) * (p.Cout / 64) * classes;
   const int ksteps = (p.transposed && p.stride == 2 ? ((p.ks + 1) / 2) * ((p.ks + 1) / 2) : p.ks * p.ks) * p.kc_tiles;   // (upper bound for stride 2)
   // (measured, r3: 512 -> 128 @ 8x32x32 123 -> 102 us, 512 -> 320 @ 8x16x16 122 -> 81 us; a 36-step layer got slower: long K ranges only)
   if (wgs >= 384 || ksteps < 64) return 1;
@@ -1255,16 +1255,6 @@ static int conv_ksplit(const ConvParams& p, int classes, int bm = 64) {
   if (k > 4) k = 4;
   while (k > 1 && ksteps / k < 24) --k;
   return k;
-}
-// 3x3 layers on <= 32x32 maps with >= 64 output channels: 128 x 64 tiles on 4 waves — a wave owns a 64 x 32 block (two accumulators: 6
-// fragment reads and 6 DMA pieces per 32 MFMAs instead of 8 and 3 per 16, the step that paid on the 256 x 64 / 128 x 32 tiles) — when
-// the grid (with the data gradients' K split) still gives every CU a workgroup.  The K order of an output element does not depend on
-// the tile, so the choice may look at M; forward launches never split K (batch invariance of the summation).
-static int tile128x64_ksplit(const ConvParams& p, int classes) {   // 0: keep the 64 x 64 tile; else the K split (>= 1) to launch with
-  if (!clc_tuning[CLC_TUNE_TILE128X64] || p.ks != 3 || p.M % 128 || p.Cout < 64 || p.xs || p.in_op != CLC_IN_NONE) return 0;
-  const int k = p.transposed ? conv_ksplit(p, classes, 128) : 1;
-  const long wgs = (long)(p.M / 128) * ((p.Cout + 63) / 64) * classes * k;
-  return wgs >= 256 ? k : 0;
 }
 
 template <int BM, int BN, int WM, int WN, bool TR>
@@ -1471,8 +1461,8 @@ extern "C" int clc_filter_transpose_batched(const clc_transpose_entry* table_dev
 }
 
 // turns the K split on for this launch when the caller provided the scratch for it
-static void use_split(ConvParams& p, const clc_conv_desc* d, int classes, int bm = 64) {
-  const int k = conv_ksplit(p, classes, bm);
+static void use_split(ConvParams& p, const clc_conv_desc* d, int classes) {
+  const int k = conv_ksplit(p, classes);
   if (k > 1 && d->workspace && d->workspace_bytes >= (size_t)k * classes * p.M * p.Cout * sizeof(float) && aligned16(d->workspace) &&
       clc_tuning[CLC_TUNE_DMA_LOOP] == 2) {
     p.ksplit = k;
@@ -1559,8 +1549,7 @@ extern "C" size_t clc_conv2d_workspace_bytes(const clc_conv_desc* d) {
   if (!vec_ok || d->Cout < 64) return 0;
   const int img_pix = (d->transposed && d->stride == 2) ? (d->OH / 2) * (d->OW / 2) : d->OH * d->OW;
   if (img_pix > 1024) return 0;   // (only the 64x64-tile family splits; whether THIS launch lands there is decided in clc_conv2d — an unused scratch is harmless)
-  int k = conv_ksplit(p, classes);
-  if (img_pix > 256) { const int k2 = tile128x64_ksplit(p, classes); if (k2 > k) k = k2; }   // (whichever tile clc_conv2d picks: an unused part of the scratch is harmless)
+  const int k = conv_ksplit(p, classes);
   return k > 1 ? (size_t)k * classes * p.M * p.Cout * sizeof(float) : 0;
 }
 
@@ -1624,10 +1613,9 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   p.bf16 = clc_tuning[CLC_TUNE_BF16] != 0 && img_pix > 256;
   if (img_pix <= 1024) {
     if (C >= 64) {
-      if (tile128x64_ksplit(p, classes) > 0) {
-        use_split(p, d, classes, 128);
-        return launch<128, 64, 2, 2>(p, classes, st);
-      }
+      // (128 x 64 tiles on 4 waves — a wave owns two accumulator blocks, the step that paid on the 256 x 64 / 128 x 32 tiles — were built
+      //  for these 32x32-map layers in round 4 and measured in one process, forward / data gradient: 128 -> 512 92.7 / 99.2 us vs 93.6 /
+      //  97.8, 128 -> 128 36.8 / 34.6 vs 36.7 / 34.6, 320 -> 320 172.6 / 169.3 vs 216.0 / 165.7: nothing, or worse.  Removed.)
       use_split(p, d, classes);
       return launch<64, 64, 2, 2>(p, classes, st);
     }
