@@ -248,6 +248,8 @@ def _kernel_name(L, r):
     if f in (4, 5):   # family 5 = the 1x1 instantiation (its own symbol)
         return (f"conv_igemm_dma2_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}, {1 if f == 5 else 3}, "
                 f"{(variant >> 24) & 3}, {'true' if (variant >> 26) & 1 else 'false'}>")   # (..., OP: 1 = squared operand (GDN's norm convolution), BF: bf16 MFMA)
+    if f == 10:       # 16-column MFMAs for the <= 16-channel tail of the synthesis transform
+        return "conv_igemm_n16_kernel<3>"
     if f == 8:        # the persistent pipelined kernel of the large-map 1x1 layers
         return f"conv_igemm_p1x1_kernel<{(variant >> 24) & 3}>"
     return f"conv_igemm{ {1: '', 2: '_dma'}[f]}_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}>"

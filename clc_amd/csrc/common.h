@@ -29,7 +29,8 @@ enum { CLC_TUNE_DMA_LOOP = 0 /* 1: conv_igemm_dma_kernel, 2: conv_igemm_dma2_ker
        CLC_TUNE_HEAVY128 = 17 /* long-K 3x3 layers on <= 16x16 maps (the slice-parameter nets): 128x128 LDS tiles with the K range split to fill the chip */,
        CLC_TUNE_ATTN_SPLIT = 18 /* attention backward on small grids (<= 1024 workgroups): two workgroups per window group, one tile each */,
        CLC_TUNE_MLP_PK = 19 /* fused Swin MLP forward: GELU on the packed-f32 VALU instructions (same bits either way) */,
-       CLC_TUNE_COUNT = 20 };
+       CLC_TUNE_N16 = 20 /* <= 16 output channels on large maps (the 12-channel tail of g_s): 16-column MFMAs (v_mfma_f32_16x16x4_f32); ANOTHER summation order */,
+       CLC_TUNE_COUNT = 21 };
 extern int clc_tuning[CLC_TUNE_COUNT];
 
 #define CLC_CHECK(cond, ...)            \

@@ -937,6 +937,124 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// <= 16 OUTPUT CHANNELS on large maps: the 12-channel tail of the synthesis transform (subpel_conv3x3(N, 3, 2): 128 -> 12 + PixelShuffle,
+// /root/reference/models/CLC_run.py:351).  On the 32-column tiles 20 of 32 MFMA columns were padding (163 us for 9.7 padded GFLOP;
+// 128 x 32 tiles in round 3: 147 -> 115 us).  Here the N = 16 shape of the f32 MFMA: v_mfma_f32_16x16x4_f32 (16 x 16 x 4 in 32 cycles:
+// the same FLOP rate, half the columns) — 12 of 16 columns useful.  256 x 16 tiles on 4 waves; a wave owns 64 rows = four independent
+// 16 x 16 accumulators (the 16x16x4 MFMA needs >= 2: 40-cycle dependent latency), staged by LDS-DMA like conv_igemm_dma2_kernel
+// (same slot swizzle, same row-origin + scalar tap-delta addressing).  Lane (i = lane & 15, g = lane >> 4) reads the 16-B chunk 4 t + g
+// of its row and feeds four MFMAs from it, so MFMA step (t, s) contracts k in {16 t + 4 g + s : g = 0..3} — ANOTHER summation order
+// than the 32-column kernels; the layer takes this kernel by its shape alone (never by the batch), so an image's bits stay
+// batch-independent, and the decoder's x_hat still equals the encoder-side reconstruction.
+template <int KS>
+__global__ __launch_bounds__(256, 2)
+void conv_igemm_n16_kernel(const ConvParams p) {
+  constexpr int BM = 256, NT = 256, A_P = 8;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                  // [2][256][32], slot-swizzled
+  float* Bs = smem + 2 * BM * BK;    // [2][16][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM;
+  const int DH = p.OH, DW = p.OW;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+  unsigned a_base[A_P], a_mask[A_P];
+  int a_c4[A_P];
+#pragma unroll
+  for (int i = 0; i < A_P; ++i) {
+    const int r = (tid + i * NT) >> 3;
+    const RowState rs = make_row<false>(p, m0 + r, DH, DW, 0, 0);
+    a_c4[i] = ((tid & 7) ^ ((r >> 1) & 7)) * 4;
+    unsigned mask = 0;
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+#pragma unroll
+      for (int q = 0; q < KS; ++q) {
+        const int iy = rs.y0 + j, ix = rs.x0 + q;
+        mask |= (rs.ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? (1u << (j * 3 + q)) : 0u;
+      }
+    a_mask[i] = mask;
+    a_base[i] = ((unsigned)(rs.base + rs.y0 * p.W + rs.x0) * (unsigned)p.ldx + (unsigned)a_c4[i]) * 4u;
+  }
+  const int b_r = tid >> 3, b_c4 = ((tid & 7) ^ ((b_r >> 1) & 7)) * 4;     // threads 0..127: the 16 filter rows
+  const bool b_ok = tid < 128 && b_r < p.Cout;
+  const unsigned b_base = ((unsigned)b_r * (unsigned)p.ldw + (unsigned)b_c4) * 4u;
+  const int wave_row = wave * 8;
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int total = KS * KS * p.kc_tiles;
+  int tj = 0, ti = 0, kc = 0;
+  auto advance = [&]() {
+    const int kc1 = kc + 1;
+    const bool w1 = kc1 == p.kc_tiles;
+    kc = w1 ? 0 : kc1;
+    const int ti1 = ti + (w1 ? 1 : 0);
+    const bool w2 = ti1 == KS;
+    ti = w2 ? 0 : ti1;
+    tj += w2 ? 1 : 0;
+  };
+  unsigned s_bit, s_adelta, s_bdelta; int s_cleft; bool s_en;
+  auto set_fetch = [&](bool en) {
+    s_en = en;
+    s_bit = 1u << (tj * 3 + ti);
+    s_cleft = p.Cin - kc * BK;
+    s_adelta = (unsigned)((tj * p.W + ti) * p.ldx + kc * BK) * 4u;
+    s_bdelta = (unsigned)((tj * KS + ti) * p.Cin + kc * BK) * 4u;
+  };
+  auto dma_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) {
+      const bool ok = s_en && (a_mask[i] & s_bit) != 0u && a_c4[i] < s_cleft;
+      dma16(xr, As + (buf * BM + wave_row + i * (NT / 8)) * BK, ok ? a_base[i] + s_adelta : kOOB);
+    }
+    if (wave < 2) dma16(wr, Bs + (buf * 16 + wave_row) * BK, (s_en && b_ok && b_c4 < s_cleft) ? b_base + s_bdelta : kOOB);   // wave-uniform branch
+  };
+  set_fetch(true);
+  dma_tile(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int li = lane & 15, g = lane >> 4, sw = (li >> 1) & 7;
+  int fo[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) fo[t] = ((4 * t + g) ^ sw) * 4;
+  for (int it = 0; it < total; ++it) {
+    const int buf = it & 1;
+    advance();
+    set_fetch(it + 1 < total);
+    dma_tile(buf ^ 1);
+    const float* Ab = As + (buf * BM + wave * 64 + li) * BK;
+    const float* Bb = Bs + (buf * 16 + li) * BK;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x4 a[4];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) a[rb] = *reinterpret_cast<const f32x4*>(Ab + rb * 16 * BK + fo[t]);   // (rows 16 rb + li: the swizzle term (row >> 1) & 7 is li's)
+      const f32x4 b = *reinterpret_cast<const f32x4*>(Bb + fo[t]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][s], b[s], acc[rb], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // epilogue: lane (col = lane & 15, g) holds rows 4 g + r of each 16-row block
+  const int co = li;
+  if (co < p.Cout) {
+    const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wave * 64 + rb * 16 + 4 * g + r;
+        if (m < p.M) epilogue_store(p, acc[rb][r], bv, m, co, DH, DW, 0, 0);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // PERSISTENT kernel for the large-map 1x1 convolutions / linears (KS = 1, stride 1; 128 x 64 tiles, 8 waves as 4 x 2).
 // Why (r3 ablation of conv_igemm_dma2_kernel<128,64,4,2,*,1,0> on 64 -> 192 @ 8x128x128, 70.8 us in all): without its MFMAs 54.8,
 // without its result stores 41.0, without its operand DMA 61.2 — and with NONE of the three still 18.3 us.  A tile of these layers is
@@ -1311,6 +1429,18 @@ int launch_dma2_t(const ConvParams& p, int classes, hipStream_t st) {
   }
   return ((KS == 1 ? 5 : 4) << 20) | (OP << 24) | ((BF ? 1 : 0) << 26) | (WM << 16) | (WN << 12) | (BM << 3) | (BN >> 5);  // family 4 / 5 = conv_igemm_dma2_kernel<BM,BN,WM,WN,TR,3 / 1,OP>
 }
+// <= 16 output channels on large maps (forward, stride 1, one filter set): see conv_igemm_n16_kernel
+int launch_n16(const ConvParams& p, int classes, hipStream_t st) {
+  if (!clc_tuning[CLC_TUNE_N16] || classes != 1 || p.transposed || p.stride != 1 || p.Cout > 16 || p.group_rows || p.xs || p.in_op != CLC_IN_NONE || p.ksplit > 1) return 0;
+  if (p.ks != 3) return 0;
+  dim3 grid((p.M + 255) / 256);
+  const size_t lds = (size_t)2 * (256 + 16) * BK * sizeof(float);
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_n16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((conv_igemm_n16_kernel<3>), grid, dim3(256), lds, st, p);
+  CLC_LAUNCH_CHECK();
+  return (10 << 20) | (4 << 16) | (256 << 3);   // family 10 = conv_igemm_n16_kernel<KS>
+}
 // persistent 1x1 kernel: eligibility + launch; returns 0 when the layer does not qualify (the caller falls through to the tiled kernels)
 int launch_p1x1(const ConvParams& p, int classes, hipStream_t st) {
   if (!clc_tuning[CLC_TUNE_P1X1] || classes != 1 || p.ks != 1 || p.stride != 1 || p.shuffle || p.group_rows || p.xs) return 0;
@@ -1642,6 +1772,10 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   if (clc_tuning[CLC_TUNE_TILE256] && d->ks == 3 && C > 32 && C <= 64 && p.M >= 256 * 512 && (!p.group_rows || p.group_rows % 256 == 0))
     return launch<256, 64, 4, 2>(p, classes, st);
   if (C > 32) return launch<128, 64, 4, 2>(p, classes, st);
+  if (C <= 16 && vec_ok) {   // 16-column MFMAs for the 12-channel tail (a rule on the layer's shape alone: its K order differs from the 32-column kernels')
+    const int v = launch_n16(p, classes, st);
+    if (v) return v;
+  }
   // the 12-channel tail of the synthesis transform (and any <= 32-channel 3x3 layer on >= 65 536 rows): 128 x 32 tiles, a wave owns 64 x 32
   // (two accumulators per B fragment) — 149.5 -> 120.3 us on 128 -> 12 @ 8x128x128, same bits (the same reasoning as the 256 x 64 rule)
   if (clc_tuning[CLC_TUNE_TILE256] && d->ks == 3 && p.M % 128 == 0 && p.M >= 128 * 512) return launch<128, 32, 2, 1>(p, classes, st);

@@ -915,3 +915,35 @@ def test_fused_mlp_same_bits_as_two_launches(dev, N, H, W, strided, save_h):
     yt = F.conv2d(F.gelu(F.conv2d(xt, fc1.weight.detach()[:, :, None, None], fc1.bias.detach())), fc2.weight.detach()[:, :, None, None], fc2.bias.detach())
     yt.backward(wide[:, 64:] if strided else gy)
     _close(dxf, xt.grad, 1e-4, "fused mlp dx vs torch")
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,shuffle", [(2, 128, 64, 64, 12, True), (1, 128, 40, 72, 12, True), (2, 64, 64, 48, 16, False), (3, 256, 48, 48, 12, True)])
+def test_16_column_kernel_for_the_few_channel_tail(dev, N, Cin, H, W, Cout, shuffle):
+    """conv_igemm_n16_kernel (v_mfma_f32_16x16x4_f32, 256 x 16 tiles; tuning key 20): the synthesis transform's subpel tail, 128 -> 12 with the
+    PixelShuffle(2) store (CLC_run.py:351) — vs torch fp32, vs the 32-column kernel it replaces (another summation order: fp32 accuracy,
+    not bits), ragged row counts, and batch-independence of an image's bits (the kernel is chosen by the layer's shape alone)."""
+    from clc_amd import lib as _clib
+    from clc_amd import ops
+
+    L = _clib.load()
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    x = _dev(torch.randn(N, Cin, H, W, generator=g), dev)
+    w = _dev(torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05, dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    outs = {}
+    for key in (0, 1):
+        prev = L.clc_set_tuning(20, key)
+        try:
+            outs[key] = ops.conv_raw(x, ops.to_kernel_weight(w), b, ks=3, shuffle=shuffle).clone()
+            if key == 1:
+                one = ops.conv_raw(x[:1].contiguous(memory_format=CL), ops.to_kernel_weight(w), b, ks=3, shuffle=shuffle).clone()
+        finally:
+            L.clc_set_tuning(20, prev)
+    with torch.no_grad():
+        want = F.conv2d(x, w, b, padding=1)
+        if shuffle:
+            want = F.pixel_shuffle(want, 2)
+    assert outs[1].shape == want.shape
+    _close(outs[1], want, 2e-5, "n16 kernel vs torch")
+    _close(outs[1], outs[0], 4e-6, "n16 kernel vs the 32-column kernel")
+    assert torch.equal(one, outs[1][:1]), "an image's bits depend on the batch"
