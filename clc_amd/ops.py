@@ -705,6 +705,11 @@ def _dw_to_param_layout(dw_flat, w_param):
     if w_param.dim() == 2:
         return dw_flat.view(w_param.shape)
     Co, Ci, kh, kw = w_param.shape
+    if kh == 1 and kw == 1:
+        # [Co][1][1][Ci] IS [Co][Ci][1][1]: hand the gradient out with the PARAMETER's strides (a 1x1 filter is "contiguous" and
+        # "channels_last" at once, with different stride tuples) — stock DistributedDataParallel checks a gradient's strides against
+        # its bucket view's (the gradient layout contract) and falls back to a copy + warning when they differ
+        return dw_flat.as_strided(w_param.shape, w_param.stride()) if w_param.stride(1) == 1 else dw_flat.view(Co, Ci, 1, 1)
     return dw_flat.view(Co, kh, kw, Ci).permute(0, 3, 1, 2)  # logical OIHW, channels_last strides
 
 

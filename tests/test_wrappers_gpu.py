@@ -74,9 +74,17 @@ def test_distributed_data_parallel_single_rank_equals_bare_module(dev):
     created = not dist.is_initialized()
     if created:
         dist.init_process_group("gloo", rank=0, world_size=1)
+    import warnings
+
     try:
         ddp = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], find_unused_parameters=True)
-        l1, g1 = _loss_and_grads(ddp, m, x, refs)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            l1, g1 = _loss_and_grads(ddp, m, x, refs)
+        # DDP's gradient layout contract: every gradient arrives with the strides of its parameter's bucket view (a 1x1 filter's
+        # gradient used to come out with channels_last strides, [Co, 1, Co, Co], next to a bucket view of [Ci, 1, 1, 1])
+        bad = [str(w.message)[:200] for w in caught if "strides do not match" in str(w.message)]
+        assert not bad, bad
     finally:
         if created:
             dist.destroy_process_group()
