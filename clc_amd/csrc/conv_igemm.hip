@@ -775,7 +775,7 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
   // scalar state of the tile being fetched
   unsigned s_bit, s_adelta, s_bdelta; int s_cleft; bool s_en;
   auto set_fetch = [&](bool en) {
-    s_en = en && !(p.ablate & 4);
+    s_en = en;
     s_bit = 1u << (tj * 3 + ti);
     s_cleft = p.Cin - kc * BK;
     s_adelta = (unsigned)(sgn * (tj * p.W + ti) * p.ldx + kc * BK) * 4u;
@@ -821,7 +821,6 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
     for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * BK);
   };
   auto mfma_group = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) {
-    if (p.ablate & 1) { asm volatile("" ::"v"(a[0]), "v"(b[0])); return; }
 #pragma unroll
     for (int ss = 0; ss < 4; ++ss)
 #pragma unroll
@@ -831,7 +830,6 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][ss], b[j][ss], acc[i][j], 0, 0, 0);
   };
   auto mfma_pair_bf16 = [&](const f32x4 (&a0)[TM], const f32x4 (&b0)[TN], const f32x4 (&a1)[TM], const f32x4 (&b1)[TN]) {
-    if (p.ablate & 1) { asm volatile("" ::"v"(a0[0]), "v"(b0[0]), "v"(a1[0]), "v"(b1[0])); return; }
     bf16x8 pa[TM], pb[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) pa[i] = pack_bf16(a0[i], a1[i]);
@@ -863,16 +861,15 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
     const int buf = it & 1;
     advance();
     set_fetch(it + 1 < total);
-    // Where the next tile's DMA pieces are issued (block-uniform): at the top they have the whole iteration to land — what
-    // counts inside the training step, where operands come from HBM / Infinity Cache; between the MFMA groups their address
-    // VALU hides in the MFMA shadow — faster only when the operands are L2-resident (single-layer micro-benchmark).
-    if (p.dma_place) { dma_a(buf ^ 1); dma_b(buf ^ 1); }
+    // The next tile's DMA pieces are issued at the TOP of the iteration: they have the whole iteration to land — what counts inside the
+    // training step, where operands come from HBM / Infinity Cache (between the MFMA groups measured -1.7 % in the step, round 2).
+    // No block-uniform branch in this loop (round 4 removed the ablation / placement switches: every one of them split the K step
+    // into separately scheduled pieces).
+    dma_a(buf ^ 1); dma_b(buf ^ 1);
     read_frag(buf, 1, af[1], bf[1]);
     mfma_group(af[0], bf[0]);
-    if (!p.dma_place) dma_a(buf ^ 1);
     read_frag(buf, 2, af[0], bf[0]);
     mfma_group(af[1], bf[1]);
-    if (!p.dma_place) dma_b(buf ^ 1);
     read_frag(buf, 3, af[1], bf[1]);
     mfma_group(af[0], bf[0]);
     mfma_group(af[1], bf[1]);
@@ -881,7 +878,6 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
     read_frag(buf ^ 1, 0, af[0], bf[0]);                // (after the last tile: a harmless read of the zero-filled buffer)
   }
 
-  if (p.ablate & 2) { if (acc[0][0][0] == 123.456f) p.y[0] = 1.f; return; }
   if (ksp > 1) {   // raw partial tile -> scratch [class][split][M][Cout] (whole tiles: host-checked); conv_splitk_finish_kernel does the rest
     float* dst = p.partial + ((size_t)(cls * ksp + sk) * p.M) * p.Cout;
 #pragma unroll
@@ -1121,7 +1117,7 @@ void conv_igemm_p1x1_kernel(const ConvParams p, int tiles_m, int tiles_n) {
     ++c.n;
   };
   auto dma = [&](int slot, const Cur& c) {
-    const bool en = c.n < total && !(p.ablate & 4);
+    const bool en = c.n < total;
     const int cleft = p.Cin - c.kt * BK;
     const unsigned ao = ((unsigned)(c.mt * BM) * (unsigned)p.ldx + (unsigned)(c.kt * BK)) * 4u;
     const unsigned bo = ((unsigned)(c.nt * BN) * (unsigned)p.ldw + (unsigned)(c.kt * BK)) * 4u;
@@ -1146,7 +1142,6 @@ void conv_igemm_p1x1_kernel(const ConvParams p, int tiles_m, int tiles_n) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   auto mfma4 = [&](const f32x4& a, const f32x4& b) {
-    if (p.ablate & 1) { asm volatile("" ::"v"(a), "v"(b)); return; }
 #pragma unroll
     for (int ss = 0; ss < 4; ++ss) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ss], b[ss], acc, 0, 0, 0);
   };
@@ -1178,8 +1173,7 @@ void conv_igemm_p1x1_kernel(const ConvParams p, int tiles_m, int tiles_n) {
     mfma4(af[1], bf[1]);
     const bool last = cc.kt == p.kc_tiles - 1;        // block-uniform
     if (last) {
-      if (!(p.ablate & 2)) epilogue(cc.mt, cc.nt);
-      else if (acc[0] == 123.456f) p.y[0] = 1.f;
+      epilogue(cc.mt, cc.nt);
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     }
@@ -1187,7 +1181,7 @@ void conv_igemm_p1x1_kernel(const ConvParams p, int tiles_m, int tiles_n) {
     // the epilogues of steps s - 1 and s, which may stay in flight (an epilogue with operand loads has already waited for everything
     // older than them).
     const int e_cur = last ? 1 : 0;
-    wait_vm((p.ablate & 2) ? P : P + S * (e_prev + e_cur));
+    wait_vm(P + S * (e_prev + e_cur));
     __builtin_amdgcn_s_barrier();
     e_prev = e_cur;
     step(cc);

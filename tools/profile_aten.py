@@ -29,13 +29,13 @@ for k, c, sd, td in rows:
         print(f"{k[:50]:50s} {c:6d} {sd:12.0f} {td:12.0f}")
 
 import collections
-for name in ("aten::clone", "aten::add", "aten::add_", "aten::mul", "aten::copy_"):
+for name in ("aten::clone", "aten::add", "aten::add_", "aten::mul", "aten::copy_", "aten::cat", "aten::fill_", "aten::zero_", "aten::zeros_like", "aten::sum"):
     by = collections.Counter(); dev_us = collections.Counter()
     for e in prof.events():
         if e.name == name:
             st = [f for f in e.stack if "clc_amd" in f or "autograd" in f][:2]
-            key = (" <- ".join(x.split("/")[-1] for x in st) or "(autograd engine)") + "  " + str(e.input_shapes)[:60]
+            key = (" <- ".join(x.split("/")[-1] for x in st) or "(autograd engine)") + "  " + str(e.input_shapes)[:90]
             by[key] += 1; dev_us[key] += e.device_time_total
     print("==", name)
-    for k, c in by.most_common(8):
+    for k, c in by.most_common(14):
         print(f"   {c:4d}  {dev_us[k]:8.0f} us  {k}")
