@@ -13,6 +13,8 @@
 // The bias gradient (column sums of dY) rides along in the workgroups of the first column.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int BK = 32;
@@ -159,6 +161,44 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
       dma16(xr, Bs + buf * BK * BN + (i * NT + wave_base) * 4, ok ? ((unsigned)((n * pH + iy) * pW + ix) * (unsigned)pldx + (unsigned)ci) * 4u : kOOB);
     }
   };
+  // LIN (stride 1, 'same' padding, power-of-two maps — every DMA-staged problem of the training step): the source pixel of output pixel
+  // `pix` at this workgroup's tap is pix + (kh - pad) * W + (kw - pad), i.e. the operand address is LINEAR in pix.  A piece's part of it
+  // is computed once; per K-tile it costs one add, and the border test two shifts / masks and two compares — no v_mul_lo_u32 (a
+  // quarter-rate instruction) and no division in the loop.  f32 MFMAs and VALU work do not overlap on gfx950: on the 64 x 64 tile the
+  // general form above spent ~400 VALU cycles per K-tile next to 1 024 MFMA cycles (conv_wgrad_sk_kernel<64, 64, 2, 2, true>: 43 %
+  // MFMA-busy in round 3).
+  int a_rel[A_P], b_rel[B_P], b_row[B_P];
+  bool a_okc[A_P], b_okc[B_P];
+#pragma unroll
+  for (int i = 0; i < A_P; ++i) {
+    const int piece = tid + i * NT, row = piece / AQ, q = piece - row * AQ;
+    a_rel[i] = (row * plddy + co0 + q * 4) * 4;
+    a_okc[i] = co0 + q * 4 < pCout;
+  }
+#pragma unroll
+  for (int i = 0; i < B_P; ++i) {
+    const int piece = tid + i * NT, row = piece / BQ, q = piece - row * BQ;
+    b_row[i] = row;
+    b_rel[i] = ((row + (kh - ppad) * pW + (kw - ppad)) * pldx + ci0 + q * 4) * 4;
+    b_okc[i] = ci0 + q * 4 < pCin;
+  }
+  auto dma_tile_lin = [&](int kt, int buf, bool en) {   // en = false: deposits zeros (no block-uniform branch in the K loop)
+    const int kbase = k_begin + kt * BK;
+    const int kleft = en ? k_end - kbase : 0;                       // rows of this tile that exist (scalar)
+    const int a_org = kbase * plddy * 4, b_org = kbase * pldx * 4;   // scalars
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) {
+      const int row = (tid + i * NT) / AQ;
+      dma16(dr, As + buf * BK * BM + (i * NT + wave_base) * 4, (row < kleft && a_okc[i]) ? (unsigned)(a_org + a_rel[i]) : kOOB);
+    }
+#pragma unroll
+    for (int i = 0; i < B_P; ++i) {
+      const int pix = kbase + b_row[i];
+      const int oy = (pix >> pows) & (pOH - 1), ox = pix & (pOW - 1);
+      const bool ok = b_row[i] < kleft && b_okc[i] && (unsigned)(oy + kh - ppad) < (unsigned)pH && (unsigned)(ox + kw - ppad) < (unsigned)pW;
+      dma16(xr, Bs + buf * BK * BN + (i * NT + wave_base) * 4, ok ? (unsigned)(b_org + b_rel[i]) : kOOB);
+    }
+  };
   auto bias_from_lds = [&](int buf) {   // (the DMA path has no staging registers to sum: the dY tile is read back, 4 floats per piece)
 #pragma unroll
     for (int i = 0; i < A_P; ++i) bias_acc[i] += *reinterpret_cast<const f32x4*>(As + buf * BK * BM + (tid + i * NT) * 4);
@@ -186,59 +226,69 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (ntiles > 0) {
-    if (use_dma) {
-      dma_tile(0, 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      load_tile(0);
-      store_tile(0);
-    }
-    __syncthreads();
-  }
+  const bool lin = use_dma && pows >= 0 && pstride == 1 && pH == pOH && pW == pOW;   // block-uniform: chosen ONCE, outside the K loop
   const int khalf = lane >> 5, li = lane & 31;
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int buf = kt & 1;
-    const bool more = kt + 1 < ntiles;
-    if (more) { if (use_dma) dma_tile(kt + 1, buf ^ 1); else load_tile(kt + 1); }
-    if (use_dma && do_bias) bias_from_lds(buf);
-    const float* Ab = As + (buf * BK + khalf) * BM + wm * (BM / WM) + li;
-    const float* Bb = Bs + (buf * BK + khalf) * BN + wn * (BN / WN) + li;
-    if constexpr (BF) {
-#pragma unroll
-      for (int q = 0; q < BK / 16; ++q) {
-        bf16x8 pa[TM], pb[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) pa[i][e] = (__bf16)Ab[(16 * q + 2 * e) * BM + i * 32];
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) pb[j][e] = (__bf16)Bb[(16 * q + 2 * e) * BN + j * 32];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i], pb[j], acc[i][j], 0, 0, 0);
+  auto kloop = [&](auto LIN) {
+    constexpr bool kLin = decltype(LIN)::value;
+    if (ntiles > 0) {
+      if (kLin) {
+        dma_tile_lin(0, 0, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if (use_dma) {
+        dma_tile(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        load_tile(0);
+        store_tile(0);
       }
-    } else
-#pragma unroll
-    for (int ss = 0; ss < BK / 2; ++ss) {
-      float af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = Ab[(2 * ss) * BM + i * 32];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = Bb[(2 * ss) * BN + j * 32];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      __syncthreads();
     }
-    if (use_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's pieces have landed
-    else if (more) store_tile(buf ^ 1);
-    __syncthreads();
-  }
+    for (int kt = 0; kt < ntiles; ++kt) {
+      const int buf = kt & 1;
+      const bool more = kt + 1 < ntiles;
+      if (kLin) dma_tile_lin(kt + 1, buf ^ 1, more);
+      else if (more) { if (use_dma) dma_tile(kt + 1, buf ^ 1); else load_tile(kt + 1); }
+      if (use_dma && do_bias) bias_from_lds(buf);
+      const float* Ab = As + (buf * BK + khalf) * BM + wm * (BM / WM) + li;
+      const float* Bb = Bs + (buf * BK + khalf) * BN + wn * (BN / WN) + li;
+      if constexpr (BF) {
+#pragma unroll
+        for (int q = 0; q < BK / 16; ++q) {
+          bf16x8 pa[TM], pb[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pa[i][e] = (__bf16)Ab[(16 * q + 2 * e) * BM + i * 32];
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pb[j][e] = (__bf16)Bb[(16 * q + 2 * e) * BN + j * 32];
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i], pb[j], acc[i][j], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int ss = 0; ss < BK / 2; ++ss) {
+          float af[TM], bf[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[i] = Ab[(2 * ss) * BM + i * 32];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bf[j] = Bb[(2 * ss) * BN + j * 32];
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      if (use_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's pieces have landed
+      else if (more) store_tile(buf ^ 1);
+      __syncthreads();
+    }
+  };
+  if (lin) kloop(std::true_type{}); else kloop(std::false_type{});
 
   // result: [Cout][T][Cin] (slab / gradient) or the compact [BM][BN] image of a stream-K partial
   const int T = p.ks * p.ks;
@@ -343,25 +393,39 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int 
   // piece p lands at float offset 4 p of its tile image, where 64 consecutive lanes x 16 B of one DMA instruction go (the last
   // window instruction is partly masked) — which frees the 44 staging registers for a one-step-ahead fragment prefetch below.
   const int wave_base = (tid >> 6) * 64;
-  auto dma_tile = [&](int t, int buf) {
+  // f32 MFMAs and VALU instructions do not overlap on gfx950, so the per-piece address arithmetic of the staging (9 pieces with three
+  // v_mul_lo_u32 and a division each: ~700 VALU cycles per K-tile next to 9 216 MFMA cycles) came straight out of the MFMA rate.  A
+  // piece's position inside the tile never changes: its element offset relative to the tile origin and its border flags are computed
+  // ONCE; per K-tile the origin and the tile's border mask are scalars, and a piece costs an add, an and, a compare and a select.
+  // (Tiles are aligned blocks of power-of-two maps: a window pixel leaves the image only on the side where its tile touches the border.)
+  int a_rel[2], x_rel[X_P], x_flag[X_P];   // x_flag: bit 0-3 = the piece is the window's top / bottom / left / right halo, bit 4 = never fetched
+  bool a_okc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int piece = tid + i * 256, row = piece >> 4, q = piece & 15;
+    a_rel[i] = ((row >> LTW) * pOW + (row & (TW - 1))) * plddy + co0 + q * 4;
+    a_okc[i] = co0 + q * 4 < pCout;
+  }
+#pragma unroll
+  for (int i = 0; i < X_P; ++i) {
+    const int piece = tid + i * 256, xp = piece >> 4, q = piece & 15;
+    const int wy = xp / XW, wx = xp - wy * XW, ci = ci0 + q * 4;
+    x_rel[i] = ((wy - 1) * pW + (wx - 1)) * pldx + ci;
+    x_flag[i] = (wy == 0 ? 1 : 0) | (wy == XH - 1 ? 2 : 0) | (wx == 0 ? 4 : 0) | (wx == XW - 1 ? 8 : 0) | ((piece < XP * 16 && ci < pCin) ? 0 : 16);
+  }
+  auto dma_tile = [&](int t, int buf, bool en) {   // en = false: deposits zeros (the K loop stays free of a block-uniform branch)
     const int bc = t & ((1 << lcols) - 1), t2 = t >> lcols;
     const int br = t2 & ((1 << lrows) - 1), n = t2 >> lrows;
     const int oy0 = br * TH, ox0 = bc * TW;
+    const int a_org = ((n * pOH + oy0) * pOW + ox0) * plddy, x_org = ((n * pH + oy0) * pW + ox0) * pldx;   // scalars
+    const int tmask = (en ? 0 : 31) | (oy0 == 0 ? 1 : 0) | (oy0 + TH == pH ? 2 : 0) | (ox0 == 0 ? 4 : 0) | (ox0 + TW == pW ? 8 : 0) | 16;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int piece = tid + i * 256, row = piece >> 4, q = piece & 15;
-      const int pix = (n * pOH + oy0 + (row >> LTW)) * pOW + ox0 + (row & (TW - 1));
-      const int co = co0 + q * 4;
-      dma16(dr, As + buf * 32 * 64 + (i * 256 + wave_base) * 4, co < pCout ? ((unsigned)pix * (unsigned)plddy + (unsigned)co) * 4u : kOOB);
-    }
+    for (int i = 0; i < 2; ++i)
+      dma16(dr, As + buf * 32 * 64 + (i * 256 + wave_base) * 4, (en && a_okc[i]) ? (unsigned)(a_org + a_rel[i]) * 4u : kOOB);
 #pragma unroll
     for (int i = 0; i < X_P; ++i) {
-      const int piece = tid + i * 256, xp = piece >> 4, q = piece & 15;
-      const int wy = xp / XW, wx = xp - wy * XW;
-      const int iy = oy0 + wy - 1, ix = ox0 + wx - 1, ci = ci0 + q * 4;
-      const bool ok = ci < pCin && (unsigned)iy < (unsigned)pH && (unsigned)ix < (unsigned)pW;
-      if (piece < XP * 16)
-        dma16(xr, Xs + buf * XP * 64 + (i * 256 + wave_base) * 4, ok ? ((unsigned)((n * pH + iy) * pW + ix) * (unsigned)pldx + (unsigned)ci) * 4u : kOOB);
+      if ((i + 1) * 256 <= XP * 16 || tid + i * 256 < XP * 16)   // (only the last instruction is partly masked: compile-time for the others)
+        dma16(xr, Xs + buf * XP * 64 + (i * 256 + wave_base) * 4, (x_flag[i] & tmask) == 0 ? (unsigned)(x_org + x_rel[i]) * 4u : kOOB);
     }
   };
   auto store_tile = [&](int buf) {
@@ -387,7 +451,7 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int 
 
   if (ntiles > 0) {
     if (DMA) {
-      dma_tile(t_begin, 0);
+      dma_tile(t_begin, 0, true);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       load_tile(t_begin);
@@ -399,7 +463,8 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int 
   for (int kt = 0; kt < ntiles; ++kt) {
     const int buf = kt & 1;
     const bool more = kt + 1 < ntiles;
-    if (more) { if (DMA) dma_tile(t_begin + kt + 1, buf ^ 1); else load_tile(t_begin + kt + 1); }
+    if (DMA) dma_tile(t_begin + kt + 1, buf ^ 1, more);
+    else if (more) load_tile(t_begin + kt + 1);
     const float* Ab = As + buf * 32 * 64 + wm * 32 + li;
     const float* Xb = Xs + buf * XP * 64 + wn * 32 + li;
     if (DMA && BF) {   // reduced-precision mode: 16 k per v_mfma_f32_32x32x16_bf16, lane half h supplies k = 16 q + 2 j + h as element j
