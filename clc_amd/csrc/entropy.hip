@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void gauss_lik_bwd_kernel(const float* __restr
                                                           const float* __restrict__ mu, int ldmu, const float* __restrict__ scale, int ldsc,
                                                           const float* __restrict__ noise, int ldn, float* __restrict__ dy, int lddy,
                                                           float* __restrict__ dmu, int lddmu, float* __restrict__ dscale, int lddsc, long rows,
-                                                          int C, int mode) {
+                                                          int C, int mode, const float* __restrict__ dy_add, int ldadd) {
   const long total = rows * C;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long r = i / C;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void gauss_lik_bwd_kernel(const float* __restr
       const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
       gy = g * dl_dv * sgn;
     }
-    if (dy) dy[r * lddy + c] = gy;
+    if (dy) dy[r * lddy + c] = dy_add ? gy + dy_add[r * ldadd + c] : gy;   // (+ the straight-through gradient of y_hat = round(y - mu) + mu)
     if (dmu) dmu[r * lddmu + c] = -gy;
   }
 }
@@ -338,11 +338,11 @@ extern "C" int clc_gauss_lik_fwd(const float* y, int ldy, const float* mu, int l
 
 extern "C" int clc_gauss_lik_bwd(const float* dlik, int lddl, const float* y, int ldy, const float* mu, int ldmu, const float* scale,
                                  int ldsc, const float* noise, int ldn, float* dy, int lddy, float* dmu, int lddmu, float* dscale,
-                                 int lddsc, long rows, int C, int mode, clc_stream_t stream) {
+                                 int lddsc, long rows, int C, int mode, const float* dy_add, int ldadd, clc_stream_t stream) {
   CLC_CHECK(dlik && y && mu && scale && dscale && rows > 0 && C > 0, "clc_gauss_lik_bwd: bad args");
   CLC_CHECK(mode == 1 || noise, "clc_gauss_lik_bwd: training mode needs noise");
   hipLaunchKernelGGL(gauss_lik_bwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, ST, dlik, lddl, y, ldy, mu, ldmu, scale, ldsc, noise, ldn, dy,
-                     lddy, dmu, lddmu, dscale, lddsc, rows, C, mode);
+                     lddy, dmu, lddmu, dscale, lddsc, rows, C, mode, dy_add, ldadd);
   CLC_LAUNCH_CHECK();
   return 0;
 }

@@ -128,7 +128,7 @@ SIGNATURES = {
     "clc_winattn_bwd": (_i, [fp, _i, fp, _i, fp, fp, _i, fp, fp, _i, fp, _i, _i, _i, _i, _i, _i, _i, _i, fp, _sz, fp]),
     "clc_gauss_lik_partials": (_i, [_l, _i]),
     "clc_gauss_lik_fwd": (_i, [fp, _i, fp, _i, fp, _i, fp, _i, fp, _i, fp, _i, _l, _i, _i, fp, _i, fp]),
-    "clc_gauss_lik_bwd": (_i, [fp, _i, fp, _i, fp, _i, fp, _i, fp, _i, fp, _i, fp, _i, fp, _i, _l, _i, _i, fp]),
+    "clc_gauss_lik_bwd": (_i, [fp, _i, fp, _i, fp, _i, fp, _i, fp, _i, fp, _i, fp, _i, fp, _i, _l, _i, _i, fp, _i, fp]),
     "clc_eb_lik_fwd": (_i, [fp, _i, fp, _i, fp, _pp, _pp, _pp, fp, _i, fp, _i, _l, _i, _i, fp]),
     "clc_eb_lik_bwd": (_i, [fp, _i, fp, _i, fp, _i, fp, _pp, _pp, _pp, _pp, _pp, _pp, fp, _i, _l, _i, _i, fp]),
     "clc_eb_aux": (_i, [fp, _pp, _pp, _pp, fp, fp, fp, _i, fp]),

@@ -1210,6 +1210,13 @@ class _SplitBatchFn(Function):
     def backward(ctx, ga, gb):
         shape, dtype, device = ctx.meta
         h = shape[0] // 2
+        if ga is not None and gb is not None:
+            # the two halves of ONE buffer, written in place by their producer (_GaussLikFn.backward): that buffer IS the concatenation
+            base = ga._base
+            if (base is not None and base is gb._base and tuple(base.shape) == tuple(shape) and base.is_contiguous(memory_format=CL)
+                    and ga.data_ptr() == base.data_ptr() and gb.data_ptr() == base.data_ptr() + h * base.stride(0) * base.element_size()
+                    and ga.stride() == base.stride() and gb.stride() == base.stride()):
+                return base
         if ga is None:
             ga = torch.zeros((h,) + tuple(shape[1:]), dtype=dtype, device=device).contiguous(memory_format=CL)
         if gb is None:
@@ -1741,14 +1748,20 @@ class _GaussLikFn(Function):
         if ctx.training:
             noise, npn, *_d, ldn = nhwc(noise)
         dy = new_act(N, Cc, H, W, y) if ctx.training else None
-        dmu = new_act(N, Cc, H, W, y) if ctx.training else None
-        dsc = new_act(N, Cc, H, W, y)
+        # d(mu) and d(scale) as the two batch halves of ONE buffer: the paired slice nets produce [mu; scale] as one stacked tensor, and
+        # _SplitBatchFn.backward hands such a pair back as it is instead of concatenating it
+        both = new_act(2 * N, Cc, H, W, y)
+        dmu = both[:N] if ctx.training else None
+        dsc = both[N:]
+        add_p, ldadd = None, 0
+        if ctx.training and dyhat is not None:   # the straight-through gradient of y_hat rides in the same pass (was an elementwise add)
+            dyhat, add_p, *_e, ldadd = nhwc(dyhat)
         _lib.check(_L().clc_gauss_lik_bwd(dlp, lddl, yp, ldy, mp, ldmu, sp, ldsc, npn, ldn,
                                           dy.data_ptr() if dy is not None else None, Cc, dmu.data_ptr() if dmu is not None else None, Cc,
-                                          dsc.data_ptr(), Cc, rows, Cc, 0 if ctx.training else 1, _stream()), "clc_gauss_lik_bwd")
+                                          dsc.data_ptr(), Cc, rows, Cc, 0 if ctx.training else 1, add_p, ldadd, _stream()), "clc_gauss_lik_bwd")
         # y_hat = round(y - mu) + mu with the straight-through estimator: d y_hat/dy = 1, d y_hat/dmu = 0
-        if dyhat is not None:
-            dy = dyhat if dy is None else dy + dyhat
+        if dy is None:
+            dy = dyhat
         return dy, dsc, dmu, None, None
 
 

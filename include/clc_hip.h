@@ -291,10 +291,12 @@ int clc_winattn_bwd_pair(const float* dout, int lddo, const float* qkv, int ldq,
 int clc_gauss_lik_fwd(const float* y, int ldy, const float* mu, int ldmu, const float* scale, int ldsc,
                       const float* noise, int ldn, float* lik, int ldl, float* y_hat, int ldh, long rows, int C,
                       int mode, float* bits_partial, int n_partials, clc_stream_t stream);
-/* grads wrt y, mu, scale given dlik (gradient wrt lik) — includes both LowerBound rules */
+/* grads wrt y, mu, scale given dlik (gradient wrt lik) — includes both LowerBound rules.  dy_add (optional, leading dimension ldadd):
+ * added to dy in the same pass — the straight-through gradient arriving through y_hat = ste_round(y - mu) + mu (CLC_run.py:571). */
 int clc_gauss_lik_bwd(const float* dlik, int lddl, const float* y, int ldy, const float* mu, int ldmu,
                       const float* scale, int ldsc, const float* noise, int ldn, float* dy, int lddy, float* dmu,
-                      int lddmu, float* dscale, int lddsc, long rows, int C, int mode, clc_stream_t stream);
+                      int lddmu, float* dscale, int lddsc, long rows, int C, int mode, const float* dy_add, int ldadd,
+                      clc_stream_t stream);
 
 /* number of workgroup partials clc_gauss_lik_fwd writes for (rows, C) */
 int clc_gauss_lik_partials(long rows, int C);
