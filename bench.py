@@ -244,7 +244,8 @@ def _kernel_name(L, r):
     f, bm, bn = (variant >> 20) & 15, (variant >> 3) & 0x1FF, (variant & 7) << 5
     if f == 3:   # <BN, TR, KW, PF>: 4-wave tiles keep one K-tile in flight, 8-wave ones CLC_TUNE_SPLITK_PF (key 6)
         kw = (variant >> 16) & 15
-        return f"conv_igemm_splitk_kernel<{bn}, {tr}, {kw}, {1 if kw == 4 or splitk_pf == 1 else 3}>"
+        ops_arith = "true" if ("+actbwd" in shape) else "false"   # (<..., OPS>: the instantiation with operand arithmetic; GDN's squared-input launches on small maps also take it)
+        return f"conv_igemm_splitk_kernel<{bn}, {tr}, {kw}, {1 if kw == 4 or splitk_pf == 1 else 3}, {ops_arith}>"
     if f in (4, 5):   # family 5 = the 1x1 instantiation (its own symbol)
         return (f"conv_igemm_dma2_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}, {1 if f == 5 else 3}, "
                 f"{(variant >> 24) & 3}, {'true' if (variant >> 26) & 1 else 'false'}>")   # (..., OP: 1 = squared operand (GDN's norm convolution), BF: bf16 MFMA)

@@ -1202,7 +1202,10 @@ void conv_igemm_p1x1_kernel(const ConvParams p, int tiles_m, int tiles_n) {
 // rows = 1024 tiles) would need 4 rounds of 512-thread workgroups instead of one round of 256-thread ones.
 // PF = K-tiles a wave keeps in flight.  KW = 8: PF = 3 needs ~200-256 VGPRs (one 8-wave workgroup per CU); PF = 1 fits 128 (two per
 // CU: the other workgroup's loads cover this one's latency instead of its own prefetch) — CLC_TUNE_SPLITK_PF picks.
-template <int BN, bool TR, int KW, int PF>
+// OPS: the launch has operand arithmetic (GDN's squared input, or a fused activation derivative on the gathered operand).  The plain
+// instantiation carries none of that code: with the block-uniform `if (fuse_act)` + the activation switch inlined around every one of
+// its MFMA groups, the K loop of this (latency-bound, 960-launches-per-step) kernel had compiled to ~180 branch instructions for 32 MFMAs.
+template <int BN, bool TR, int KW, int PF, bool OPS>
 __global__ __launch_bounds__(64 * KW, KW == 8 ? (PF >= 2 ? 1 : 4) : 4)
 void conv_igemm_splitk_kernel(const ConvParams p) {
   constexpr int BM = 32, TN = BN / 32;
@@ -1231,10 +1234,10 @@ void conv_igemm_splitk_kernel(const ConvParams p) {
     b_ok[j] = co < p.Cout;
     b_row_off[j] = (unsigned)co * (unsigned)p.ldw;
   }
-  const bool sq = p.in_op == CLC_IN_SQUARE;
+  const bool sq = OPS && p.in_op == CLC_IN_SQUARE;
   const int total = tg.nkh * tg.nkw * p.kc_tiles;
 
-  const bool fuse_act = p.xs != nullptr;
+  const bool fuse_act = OPS && p.xs != nullptr;
   const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fuse_act ? p.xs : p.x), 0, fuse_act ? p.xs_bytes : p.x_bytes, 0x00020000);
   f32x4 af[PF][4], sf[PF][4], bf[PF][TN][4];
   auto load_tile = [&](int slot, int it) {   // it = global K-tile index -> (tap, kc); fragment t8 covers k = 8*t8 + 4h .. +3
@@ -1248,7 +1251,7 @@ void conv_igemm_splitk_kernel(const ConvParams p) {
       const int c = kc * BK + t8 * 8 + 4 * h;
       const bool c_ok = c < p.Cin;
       af[slot][t8] = buf_load4(xr, pix_off(pix, p.ldx, c, c_ok));
-      if (fuse_act) sf[slot][t8] = buf_load4(sr, pix_off(pix, p.ldxs, c, c_ok));
+      if (OPS && fuse_act) sf[slot][t8] = buf_load4(sr, pix_off(pix, p.ldxs, c, c_ok));
 #pragma unroll
       for (int j = 0; j < TN; ++j) bf[slot][j][t8] = buf_load4(wr, (b_ok[j] && c_ok) ? (b_row_off[j] + tap_off + (unsigned)c) * 4u : kOOB);
     }
@@ -1271,8 +1274,11 @@ void conv_igemm_splitk_kernel(const ConvParams p) {
       if (it < total) {      // wave-uniform
 #pragma unroll
         for (int t8 = 0; t8 < 4; ++t8) {
-          f32x4 a = sq ? af[s][t8] * af[s][t8] : af[s][t8];
-          if (fuse_act) a = a * act_deriv4(sf[s][t8], p.xs_act, p.xs_pre);
+          f32x4 a = af[s][t8];
+          if constexpr (OPS) {
+            if (sq) a = a * a;
+            if (fuse_act) a = a * act_deriv4(sf[s][t8], p.xs_act, p.xs_pre);
+          }
 #pragma unroll
           for (int ss = 0; ss < 4; ++ss)
 #pragma unroll
@@ -1472,27 +1478,31 @@ int launch(const ConvParams& p, int classes, hipStream_t st) {
   return p.transposed ? launch_t<BM, BN, WM, WN, true>(p, classes, st) : launch_t<BM, BN, WM, WN, false>(p, classes, st);
 }
 
-template <int BN, bool TR, int KW, int PF>
+template <int BN, bool TR, int KW, int PF, bool OPS>
 int launch_splitk_t(const ConvParams& p, int classes, hipStream_t st) {
   dim3 grid((p.M + 31) / 32, (p.Cout + BN - 1) / BN, classes);
   const size_t lds = (size_t)KW * (BN / 32) * 16 * 64 * sizeof(float);
   static PerDeviceOnce attr_once;
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_splitk_kernel<BN, TR, KW, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_splitk_kernel<BN, TR, KW, PF, OPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  hipLaunchKernelGGL((conv_igemm_splitk_kernel<BN, TR, KW, PF>), grid, dim3(64 * KW), lds, st, p);
+  hipLaunchKernelGGL((conv_igemm_splitk_kernel<BN, TR, KW, PF, OPS>), grid, dim3(64 * KW), lds, st, p);
   CLC_LAUNCH_CHECK();
   return (3 << 20) | (KW << 16) | (32 << 3) | (BN >> 5);  // family 3 = conv_igemm_splitk_kernel<BN,TR,KW>
+}
+template <int BN, bool TR, int KW, int PF>
+int launch_splitk_o(const ConvParams& p, int classes, hipStream_t st) {
+  return (p.xs != nullptr || p.in_op == CLC_IN_SQUARE) ? launch_splitk_t<BN, TR, KW, PF, true>(p, classes, st) : launch_splitk_t<BN, TR, KW, PF, false>(p, classes, st);
 }
 template <int BN>
 int launch_splitk(const ConvParams& p, int classes, hipStream_t st) {
   // the K-split factor is a function of the layer shape alone (never of the batch), like the family itself
   static const int kw4 = getenv("CLC_SPLITK_KW4") ? atoi(getenv("CLC_SPLITK_KW4")) : 1;   // 0: always 8 waves (A/B knob)
   if (kw4 && p.ks * p.ks * p.kc_tiles <= 4)
-    return p.transposed ? launch_splitk_t<BN, true, 4, 1>(p, classes, st) : launch_splitk_t<BN, false, 4, 1>(p, classes, st);
+    return p.transposed ? launch_splitk_o<BN, true, 4, 1>(p, classes, st) : launch_splitk_o<BN, false, 4, 1>(p, classes, st);
   if (clc_tuning[CLC_TUNE_SPLITK_PF] == 1)
-    return p.transposed ? launch_splitk_t<BN, true, 8, 1>(p, classes, st) : launch_splitk_t<BN, false, 8, 1>(p, classes, st);
-  return p.transposed ? launch_splitk_t<BN, true, 8, 3>(p, classes, st) : launch_splitk_t<BN, false, 8, 3>(p, classes, st);
+    return p.transposed ? launch_splitk_o<BN, true, 8, 1>(p, classes, st) : launch_splitk_o<BN, false, 8, 1>(p, classes, st);
+  return p.transposed ? launch_splitk_o<BN, true, 8, 3>(p, classes, st) : launch_splitk_o<BN, false, 8, 3>(p, classes, st);
 }
 
 // small-Cin (image, Cin<=4, unaligned) direct convolution: one thread per (pixel, 4 output channels)
