@@ -1368,7 +1368,9 @@ static int conv_ksplit(const ConvParams& p, int classes) {
   const long wgs = (long)(p.M / 64) * (p.Cout / 64) * classes;
   const int ksteps = (p.transposed && p.stride == 2 ? ((p.ks + 1) / 2) * ((p.ks + 1) / 2) : p.ks * p.ks) * p.kc_tiles;   // (upper bound for stride 2)
   // (measured, r3: 512 -> 128 @ 8x32x32 123 -> 102 us, 512 -> 320 @ 8x16x16 122 -> 81 us; a 36-step layer got slower: long K ranges only)
-  if (wgs >= 384 || ksteps < 64) return 1;
+  // (r4: the 63-step data gradients of the un-paired lrp nets — 224 -> 448..704 on 2 048 rows, 288-352 tiles — 704 -> 224: 78.6 -> 65.1 us)
+  const int min_steps = clc_tuning[CLC_TUNE_DGRAD_SPLITK] > 1 ? clc_tuning[CLC_TUNE_DGRAD_SPLITK] : 56;   // (key 11 > 1: the K-step threshold itself, for A/B)
+  if (wgs >= 384 || ksteps < min_steps) return 1;
   int k = (int)((640 + wgs - 1) / wgs);
   if (k > 4) k = 4;
   while (k > 1 && ksteps / k < 24) --k;
