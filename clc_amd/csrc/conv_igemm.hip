@@ -1770,6 +1770,8 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
     if (v) return v;
   }
   if (clc_tuning[CLC_TUNE_1X1_TILE] && d->ks == 1 && p.kc_tiles <= clc_tuning[CLC_TUNE_1X1_TILE] && C > 32) return launch<128, 64, 4, 2>(p, classes, st);
+  // (256 x 128 tiles — 64 x 64 per wave, one workgroup per CU — were measured again in round 4 on the branch-free K loop: 128 -> 128 @ 8x128x128
+  //  306.0 / 299.3 us (forward / data gradient) vs 310.1 / 308.1, 128 -> 512 @ 8x64x64 296.3 / 302.9 vs 300.7 / 303.2; step 27.57 vs 27.74 ms.)
   if (C % 128 == 0 || C >= 384) return launch<128, 128, 4, 2>(p, classes, st);
   // 64-channel 3x3 layers (the ResidualBlocks of the ConvTransBlocks) with enough rows for 512 tiles of 256: each wave then owns a
   // 64 x 32 block (two accumulators, 12 fragment reads and 6 DMA pieces per 32 MFMAs instead of 8 and 3 per 16): 98.1 -> 91.0 us on

@@ -245,7 +245,7 @@ class GaussianConditional(EntropyModel):
         self._cdf_length = (pmf_length + 2).to(dev)
         self._host_tables = None
 
-    def likelihood_and_ste(self, y, scales, means, training=None, noise=None):
+    def likelihood_and_ste(self, y, scales, means, training=None, noise=None, lik_out=None):
         """(likelihood, ste_round(y - means) + means) in one kernel (CLC_run.py:569-571).  noise: pre-drawn U(-1/2, 1/2) of y's
         shape (the model draws all slices' noise in one launch); drawn here when None."""
         training = self.training if training is None else training
@@ -253,7 +253,7 @@ class GaussianConditional(EntropyModel):
             noise = torch.empty_like(y, memory_format=ops.CL).uniform_(-0.5, 0.5)
         if not training:
             noise = None
-        return ops.gaussian_likelihood(y, scales, means, noise, training)
+        return ops.gaussian_likelihood(y, scales, means, noise, training, lik_out)
 
     def forward(self, inputs, scales, means=None, training=None):
         training = self.training if training is None else training

@@ -389,11 +389,13 @@ class SwinBlock(nn.Module):
         self.block_2 = Block(input_dim, output_dim, head_dim, window_size, drop_path, type="SW")
         self.window_size = window_size
 
-    def forward(self, x, pair=None):
+    def forward(self, x, pair=None, out=None):
+        """out (paired form only): destination of the second block's result (a batch half of a wider buffer)."""
         if x.size(-1) <= self.window_size or x.size(-2) <= self.window_size:
             raise ValueError("SwinBlock: feature map must be larger than the window (input must be >= 256x256)")
         if pair is not None:
-            return self.block_2(self.block_1(x, pair=pair.block_1), pair=pair.block_2)
+            return self.block_2(self.block_1(x, pair=pair.block_1), pair=pair.block_2, out=out)
+        assert out is None
         return self.block_2(self.block_1(x))
 
 
@@ -414,8 +416,14 @@ class SWAtten(AttentionBlock):
         every convolution / linear of the two modules runs as ONE launch over both halves.
         in_fold / in_slot: GradFold / gradient slot of the first convolution (ops.SliceSupport)."""
         if pair is not None:
+            quad = ops.QUAD_UNITS and x.shape[0] % 2 == 0 and (x.shape[0] // 2) * x.shape[2] * x.shape[3] % 128 == 0
+            u_buf = None
+            if quad and self.in_conv is not None:
+                # the stacked input of the quad chain, [x ; Swin(x)], is WRITTEN in place by its two producers (this convolution and the
+                # Swin block's last linear) instead of concatenated afterwards
+                u_buf = ops.new_act(2 * x.shape[0], self.in_conv.out_channels, x.shape[2], x.shape[3], x)
             if self.in_conv is not None:
-                x = self.in_conv(x, pair=pair.in_conv, fold_in=in_fold, grad_slot=in_slot)
+                x = self.in_conv(x, pair=pair.in_conv, fold_in=in_fold, grad_slot=in_slot, out=u_buf[: x.shape[0]] if u_buf is not None else None)
             else:
                 assert in_fold is None and in_slot is None
             def branch_a():
@@ -424,16 +432,22 @@ class SWAtten(AttentionBlock):
                     a = m(a, pair=q)
                 return a
 
-            if ops.QUAD_UNITS and x.shape[0] % 2 == 0 and (x.shape[0] // 2) * x.shape[2] * x.shape[3] % 128 == 0:
+            if quad:
                 # conv_a's three ResidualUnits (on x) and conv_b's (on the Swin output) are same-shaped layers on different data: stacked
                 # along the batch they run as ONE chain of 9 launches with four filter sets (this net's a, the pair's a, this net's b,
                 # the pair's b on the quarters) instead of two chains of 9 — these 16x16-map layers are latency-bound
-                u = torch.cat((x, self.non_local_block(x, pair=pair.non_local_block)), dim=0)
+                if u_buf is not None:
+                    u = ops.cat_batch(x, self.non_local_block(x, pair=pair.non_local_block, out=u_buf[x.shape[0]:]), u_buf)
+                else:
+                    u = torch.cat((x, self.non_local_block(x, pair=pair.non_local_block)), dim=0)
                 for k in range(3):
                     u = self.conv_a[k](u, pair=(pair.conv_a[k], self.conv_b[k], pair.conv_b[k]))
                 a, b = ops.split_batch(u)
-                b = self.conv_b[3](b, pair=pair.conv_b[3])
-                out = ops.gate(a, b, x)
+                # ... and the gradients of the two halves are written into the halves of one buffer by their producers (the gate's d(a),
+                # conv_b[3]'s data gradient), which split_batch's backward hands on as it is
+                bs = ops.BatchSlots() if u.requires_grad else None
+                b = self.conv_b[3](b, pair=pair.conv_b[3], grad_slot=(bs, 0, 1) if bs is not None else None)
+                out = ops.gate(a, b, x, a_slot=(bs, 0) if bs is not None else None)
                 return self.out_conv(out, pair=pair.out_conv) if self.out_conv is not None else out
             fork_a = ops.BRANCH_STREAMS and ops.PROFILE is None and "swatten_a" in ops.BRANCH_SLOTS
             if fork_a:   # conv_a(x) is independent of the Swin -> conv_b branch: run it on a forked stream

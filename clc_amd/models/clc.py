@@ -255,7 +255,7 @@ class _SliceCodec(CompressionModel):
         z = self._fuse_z(self.h_a(y))
         z_likelihoods, z_hat = self.entropy_bottleneck.likelihood_and_ste(z)
         S = y.shape[1] // self.num_slices
-        sup = y_buf = None
+        sup = y_buf = lik_buf = None
         rows = z_hat.shape[0] * z_hat.shape[2] * z_hat.shape[3]
         if (ops.SUPPORT_BUFFER and ops.PAIR_SLICES and ops.PAIR_HYPER and rows % 128 == 0 and z_hat.shape[0] % 2 == 0
                 and (y.shape[0] * y.shape[2] * y.shape[3]) % 128 == 0
@@ -267,6 +267,7 @@ class _SliceCodec(CompressionModel):
                 sup = ops.SliceSupport(both, self.max_support_slices, S)
                 latent_means, latent_scales = both[:y.shape[0]], both[y.shape[0]:]   # (shapes only: the nets read them through `sup`)
                 y_buf = ops.new_act(y.shape[0], y.shape[1], y.shape[2], y.shape[3], y)   # y_hat: every slice's refined result, written in place
+                lik_buf = ops.new_act(y.shape[0], y.shape[1], y.shape[2], y.shape[3], y)  # ... and every slice's likelihoods
             else:
                 latent_means, latent_scales = ops.split_batch(both)
         else:
@@ -280,7 +281,8 @@ class _SliceCodec(CompressionModel):
             mus.append(mu)
             scales.append(scale)
             lik, y_hat_slice = self.gaussian_conditional.likelihood_and_ste(
-                y_slice, scale, mu, noise=noise_all[:, i * S:(i + 1) * S] if noise_all is not None else None)
+                y_slice, scale, mu, noise=noise_all[:, i * S:(i + 1) * S] if noise_all is not None else None,
+                lik_out=lik_buf[:, i * S:(i + 1) * S] if lik_buf is not None else None)
             y_lik.append(lik)
             y_hat_slices.append(self._refine(i, mean_support, y_hat_slice, ref_features, out=y_buf[:, i * S:(i + 1) * S] if y_buf is not None else None))
             if sup is not None and i < sup.n:
@@ -291,7 +293,8 @@ class _SliceCodec(CompressionModel):
         x_hat = self.g_s(ops.flush_point(y_hat))
         if prof:
             ops.set_owner("other")
-        out = {"x_hat": x_hat, "likelihoods": {"y": torch.cat(y_lik, dim=1), "z": z_likelihoods}}
+        y_likelihoods = ops.gather_channels(lik_buf, y_lik) if lik_buf is not None else torch.cat(y_lik, dim=1)
+        out = {"x_hat": x_hat, "likelihoods": {"y": y_likelihoods, "z": z_likelihoods}}
         if not getattr(self, "_lean_outputs", False):   # (clc_amd.train.TrainEngine: the criterion never reads these two concatenations)
             out["para"] = {"means": torch.cat(mus, dim=1), "scales": torch.cat(scales, dim=1), "y": y}
         return out

@@ -347,6 +347,23 @@ class GradSlots:
         return self.buf[:, off:off + n]
 
 
+class BatchSlots:
+    """GradSlots for the BATCH halves of a stacked tensor: the two consumers of split_batch(u) write their gradients straight into the
+    halves of one buffer (a convolution through `grad_slot=(slots, 0, half)`, the gate through `slot=`), and _SplitBatchFn.backward
+    hands that buffer on as it is — no concatenation."""
+
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+    def view(self, like, total_c, half, n):
+        N = like.shape[0]
+        if self.buf is None:
+            self.buf = new_act(2 * N, like.shape[1], like.shape[2], like.shape[3], like)
+        return self.buf[half * N:(half + 1) * N]
+
+
 # When set to a list, EVERY launch through the C ABI is bracketed by HIP events on the launch stream and recorded as a ProfRec
 # (bench.py's roofline leg, tools/profile_shapes.py): convolutions / filter gradients with their tile-variant id, algorithmic FLOPs
 # and bytes (recorded at their call sites), everything else (LayerNorm, attention, elementwise, optimizer ...) through the
@@ -1147,6 +1164,25 @@ class _CatHalvesFn(Function):
         return g[:, : ctx.ca], g[:, ctx.ca:], None
 
 
+class _CatBatchFn(Function):
+    """cat((a, b), dim=0) where a and b were WRITTEN as the two batch halves of `buf` by their producers (out=): no copy forward;
+    backward hands each producer its half of the gradient as a view."""
+
+    @staticmethod
+    def forward(ctx, a, b, buf):
+        ctx.h = a.shape[0]
+        assert a.data_ptr() == buf.data_ptr() and b.data_ptr() == buf.data_ptr() + a.numel() * a.element_size() and a.shape[0] + b.shape[0] == buf.shape[0]
+        return buf.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[: ctx.h], g[ctx.h:], None
+
+
+def cat_batch(a, b, buf):
+    return _CatBatchFn.apply(a, b, buf)
+
+
 def cat_halves(a, b, buf):
     return _CatHalvesFn.apply(a, b, buf)
 
@@ -1691,11 +1727,12 @@ class _GateFn(Function):
     """a * sigmoid(b) + idn."""
 
     @staticmethod
-    def forward(ctx, a, b, idn):
+    def forward(ctx, a, b, idn, a_slot=None):
         _own(ctx)
         a, b, idn = dense(a), dense(b), dense(idn)
         out = new_act(*a.shape, a)
         _lib.check(_L().clc_gate_fwd(a.data_ptr(), b.data_ptr(), idn.data_ptr(), out.data_ptr(), a.numel(), _stream()), "clc_gate_fwd")
+        ctx.a_slot = a_slot   # (BatchSlots, half): where d(a) is to be written (a is one batch half of a stacked tensor)
         ctx.save_for_backward(a, b)
         return out
 
@@ -1704,13 +1741,14 @@ class _GateFn(Function):
         _reown(ctx)
         a, b = ctx.saved_tensors
         g = dense(g)
-        da, db = new_act(*a.shape, a), new_act(*a.shape, a)
+        da = ctx.a_slot[0].view(a, 0, ctx.a_slot[1], 0) if ctx.a_slot is not None else new_act(*a.shape, a)
+        db = new_act(*a.shape, a)
         _lib.check(_L().clc_gate_bwd(g.data_ptr(), a.data_ptr(), b.data_ptr(), da.data_ptr(), db.data_ptr(), a.numel(), _stream()), "clc_gate_bwd")
-        return da, db, g
+        return da, db, g, None
 
 
-def gate(a, b, idn):
-    return _GateFn.apply(a, b, idn)
+def gate(a, b, idn, a_slot=None):
+    return _GateFn.apply(a, b, idn, a_slot)
 
 
 # --------------------------------------------------------------------------------------- entropy
@@ -1720,21 +1758,27 @@ class _GaussLikFn(Function):
     """GaussianConditional.forward likelihood (training: additive noise; eval: dequantised)."""
 
     @staticmethod
-    def forward(ctx, y, scale, mu, noise, training):
+    def forward(ctx, y, scale, mu, noise, training, lik_out=None):
         y, yp, N, H, W, Cc, ldy = nhwc(y)
         scale, sp, *_a, ldsc = nhwc(scale)
         mu, mp, *_b, ldmu = nhwc(mu)
         rows = N * H * W
-        lik = new_act(N, Cc, H, W, y)
+        ldl = Cc
+        if lik_out is not None:   # a channel range of a wider buffer (the model gathers the slices' likelihoods without a concatenation)
+            lo, _lp, *_q, ldl = nhwc(lik_out)
+            assert lo is lik_out and tuple(lik_out.shape) == (N, Cc, H, W)
+            lik = lik_out
+        else:
+            lik = new_act(N, Cc, H, W, y)
         y_hat = new_act(N, Cc, H, W, y)
         npn, ldn = (None, 0)
         if training:
             noise, npn, *_c, ldn = nhwc(noise)
-        _lib.check(_L().clc_gauss_lik_fwd(yp, ldy, mp, ldmu, sp, ldsc, npn, ldn, lik.data_ptr(), Cc, y_hat.data_ptr(), Cc, rows, Cc,
+        _lib.check(_L().clc_gauss_lik_fwd(yp, ldy, mp, ldmu, sp, ldsc, npn, ldn, lik.data_ptr(), ldl, y_hat.data_ptr(), Cc, rows, Cc,
                                           0 if training else 1, None, 0, _stream()), "clc_gauss_lik_fwd")
         ctx.training = training
         ctx.save_for_backward(y, scale, mu, noise if training else None)
-        return lik, y_hat
+        return (lik.detach() if lik_out is not None else lik), y_hat
 
     @staticmethod
     def backward(ctx, dlik, dyhat):
@@ -1762,12 +1806,13 @@ class _GaussLikFn(Function):
         # y_hat = round(y - mu) + mu with the straight-through estimator: d y_hat/dy = 1, d y_hat/dmu = 0
         if dy is None:
             dy = dyhat
-        return dy, dsc, dmu, None, None
+        return dy, dsc, dmu, None, None, None
 
 
-def gaussian_likelihood(y, scale, mu, noise, training):
-    """-> (likelihood, y_hat) with y_hat = ste_round(y - mu) + mu  (CLC_run.py:569-571)."""
-    return _GaussLikFn.apply(y, scale, mu, noise, bool(training))
+def gaussian_likelihood(y, scale, mu, noise, training, lik_out=None):
+    """-> (likelihood, y_hat) with y_hat = ste_round(y - mu) + mu  (CLC_run.py:569-571).  lik_out: optional destination (a pixel-major
+    view, e.g. a channel range of the buffer that collects all slices' likelihoods)."""
+    return _GaussLikFn.apply(y, scale, mu, noise, bool(training), lik_out)
 
 
 def _eb_ptrs(mats, biases, factors):
