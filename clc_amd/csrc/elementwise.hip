@@ -360,6 +360,19 @@ __global__ void axpby_kernel(const float* __restrict__ a, float alpha, const flo
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
 }
+// dst[r][c] = ((src0 + src1) + src2) + ... — up to 12 pixel-major sources with their own leading dimensions (gradient views into wider
+// buffers), fixed order: the gradient of a tensor with several consumers in ONE launch instead of autograd's chain of pairwise adds.
+struct SumN { const float* src[12]; int ld[12]; int n; };
+__global__ void sum_n_kernel(const SumN s, float* __restrict__ dst, int ldd, long rows, int C4) {
+  const long total = rows * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C4;
+    const int c = (int)(i - r * C4) * 4;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(s.src[0] + r * s.ld[0] + c);
+    for (int k = 1; k < s.n; ++k) acc = acc + *reinterpret_cast<const f32x4*>(s.src[k] + r * s.ld[k] + c);
+    *reinterpret_cast<f32x4*>(dst + r * ldd + c) = acc;
+  }
+}
 __global__ void copy2d_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, long rows, int C) {
   const long total = rows * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -697,6 +710,16 @@ extern "C" int clc_gate_fwd(const float* a, const float* b, const float* idn, fl
 extern "C" int clc_gate_bwd(const float* dout, const float* a, const float* b, float* da, float* db, long n, clc_stream_t stream) {
   CLC_CHECK(dout && a && b && da && db && n > 0, "clc_gate_bwd: bad args");
   hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, ST, dout, a, b, da, db, n);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int clc_sum_n(const float* const* srcs, const int* lds, int n, float* dst, int ldd, long rows, int C, clc_stream_t stream) {
+  CLC_CHECK(srcs && lds && dst && n >= 1 && n <= 12 && rows > 0 && C > 0 && C % 4 == 0 && ldd % 4 == 0 && aligned16(dst), "clc_sum_n: bad args (1..12 sources, C %% 4 == 0)");
+  SumN s;
+  s.n = n;
+  for (int k = 0; k < 12; ++k) { s.src[k] = k < n ? srcs[k] : nullptr; s.ld[k] = k < n ? lds[k] : 0; }
+  for (int k = 0; k < n; ++k) CLC_CHECK(srcs[k] && aligned16(srcs[k]) && lds[k] % 4 == 0 && lds[k] >= C, "clc_sum_n: source %d unaligned", k);
+  hipLaunchKernelGGL(sum_n_kernel, dim3(grid_for(rows * (C / 4), 1024)), dim3(256), 0, ST, s, dst, ldd, rows, C / 4);
   CLC_LAUNCH_CHECK();
   return 0;
 }

@@ -436,10 +436,13 @@ class SWAtten(AttentionBlock):
                 # conv_a's three ResidualUnits (on x) and conv_b's (on the Swin output) are same-shaped layers on different data: stacked
                 # along the batch they run as ONE chain of 9 launches with four filter sets (this net's a, the pair's a, this net's b,
                 # the pair's b on the quarters) instead of two chains of 9 — these 16x16-map layers are latency-bound
+                # x has three consumers (the quad chain, the Swin block, the gate's identity term): one alias each, their gradients summed
+                # in one launch (ops.fanout) instead of two pairwise adds
+                x_u, x_sw, x = ops.fanout(x, 3)
                 if u_buf is not None:
-                    u = ops.cat_batch(x, self.non_local_block(x, pair=pair.non_local_block, out=u_buf[x.shape[0]:]), u_buf)
+                    u = ops.cat_batch(x_u, self.non_local_block(x_sw, pair=pair.non_local_block, out=u_buf[x.shape[0]:]), u_buf)
                 else:
-                    u = torch.cat((x, self.non_local_block(x, pair=pair.non_local_block)), dim=0)
+                    u = torch.cat((x_u, self.non_local_block(x_sw, pair=pair.non_local_block)), dim=0)
                 for k in range(3):
                     u = self.conv_a[k](u, pair=(pair.conv_a[k], self.conv_b[k], pair.conv_b[k]))
                 a, b = ops.split_batch(u)

@@ -116,6 +116,7 @@ SIGNATURES = {
     "clc_gate_fwd": (_i, [fp, fp, fp, fp, _l, fp]),
     "clc_gate_bwd": (_i, [fp, fp, fp, fp, fp, _l, fp]),
     "clc_axpby": (_i, [fp, _f, fp, _f, fp, _l, fp]),
+    "clc_sum_n": (_i, [_pp, C.POINTER(C.c_int), _i, fp, _i, _l, _i, fp]),
     "clc_copy2d": (_i, [fp, _i, fp, _i, _l, _i, fp]),
     "clc_stem_pack": (_i, [fp, fp, fp, fp, _i, _i, fp]),
     "clc_stem_unpack_add": (_i, [fp, fp, fp, fp, _i, _i, fp]),

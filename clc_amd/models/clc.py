@@ -273,18 +273,29 @@ class _SliceCodec(CompressionModel):
         else:
             latent_means, latent_scales = self._hyper_synthesis(z_hat)
         y_hat_slices, y_lik, mus, scales = [], [], [], []
-        ref_pair = torch.cat((ref_features, ref_features), dim=0) if (ref_features is not None and ops.PAIR_SLICES) else None
+        # the reference features feed every slice's cc pair and lrp net: one alias per consumer, the gradients summed in one launch each
+        # (ops.fanout) instead of a chain of pairwise adds
+        NS = self.num_slices
+        ref_lrp = ref_cc = None
+        if ref_features is not None:
+            fan = ops.fanout(ref_features, NS + 2)
+            ref_lrp = fan[:NS]
+            if ops.PAIR_SLICES:
+                ref_cc = ops.fanout(torch.cat((fan[NS], fan[NS + 1]), dim=0), NS)
+        ref_pair = None
         # the additive-noise proxy of training (one uniform draw per latent element): all slices' noise in ONE launch
         noise_all = torch.empty_like(y, memory_format=CL).uniform_(-0.5, 0.5) if self.gaussian_conditional.training else None
         for i, y_slice in enumerate(ops.split_channels(y, [S] * self.num_slices)):
-            mean_support, mu, scale = self._slice_params(i, latent_means, latent_scales, y_hat_slices, ref_features, y_shape, ref_pair, sup)
+            mean_support, mu, scale = self._slice_params(i, latent_means, latent_scales, y_hat_slices, ref_features, y_shape,
+                                                         ref_cc[i] if ref_cc is not None else ref_pair, sup)
             mus.append(mu)
             scales.append(scale)
             lik, y_hat_slice = self.gaussian_conditional.likelihood_and_ste(
                 y_slice, scale, mu, noise=noise_all[:, i * S:(i + 1) * S] if noise_all is not None else None,
                 lik_out=lik_buf[:, i * S:(i + 1) * S] if lik_buf is not None else None)
             y_lik.append(lik)
-            y_hat_slices.append(self._refine(i, mean_support, y_hat_slice, ref_features, out=y_buf[:, i * S:(i + 1) * S] if y_buf is not None else None))
+            y_hat_slices.append(self._refine(i, mean_support, y_hat_slice, ref_lrp[i] if ref_lrp is not None else None,
+                                             out=y_buf[:, i * S:(i + 1) * S] if y_buf is not None else None))
             if sup is not None and i < sup.n:
                 sup.add(i, y_hat_slices[-1])
         y_hat = ops.gather_channels(y_buf, y_hat_slices) if y_buf is not None else torch.cat(y_hat_slices, dim=1)

@@ -1164,6 +1164,49 @@ class _CatHalvesFn(Function):
         return g[:, : ctx.ca], g[:, ctx.ca:], None
 
 
+class _FanOutFn(Function):
+    """x -> n aliases of x, one per consumer; the backward sums the consumers' gradients in ONE launch (clc_sum_n, fixed order) instead of
+    autograd's chain of pairwise adds (n - 1 launches).  For tensors with many consumers in the slice loop: the reference features
+    (every slice's cc and lrp nets), the attention blocks' input."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        _own(ctx)
+        ctx.meta = tuple(x.shape)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        _reown(ctx)
+        gs = [g for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        N, Cc, H, W = ctx.meta
+        views = [nhwc(g) for g in gs]
+        if Cc % 4 or len(gs) > 12 or any(v[1] % 16 or v[6] % 4 for v in views):
+            out = gs[0]
+            for g in gs[1:]:
+                out = out + g
+            return out, None
+        out = new_act(N, Cc, H, W, gs[0])
+        ptrs = _lib.ptr_array([v[1] for v in views])
+        lds = (C.c_int * len(views))(*[v[6] for v in views])
+        _lib.check(_L().clc_sum_n(ptrs, lds, len(views), out.data_ptr(), Cc, N * H * W, Cc, _stream()), "clc_sum_n")
+        return out, None
+
+
+FANOUT = int(os.environ.get("CLC_FANOUT", "1"))   # 0: leave multi-consumer gradients to autograd's pairwise accumulation (A/B knob)
+
+
+def fanout(x, n):
+    """n aliases of x for n consumers (see _FanOutFn); a tensor that needs no gradient is handed out as it is"""
+    if n <= 1 or not FANOUT or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * max(n, 1)
+    return _FanOutFn.apply(x, n)
+
+
 class _CatBatchFn(Function):
     """cat((a, b), dim=0) where a and b were WRITTEN as the two batch halves of `buf` by their producers (out=): no copy forward;
     backward hands each producer its half of the gradient as a view."""

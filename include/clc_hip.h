@@ -243,6 +243,9 @@ int clc_gate_fwd(const float* a, const float* b, const float* idn, float* out, l
 int clc_gate_bwd(const float* dout, const float* a, const float* b, float* da, float* db, long n, clc_stream_t stream);
 
 /* generic fused adds: out = alpha*a + beta*b */
+/* dst = ((src0 + src1) + src2) + ...: up to 12 pixel-major [rows][C] sources (HOST arrays of device pointers / leading dimensions), fixed
+ * order — the gradient of a tensor with several consumers in one launch (ops.fanout) instead of autograd's chain of pairwise adds. */
+int clc_sum_n(const float* const* srcs, const int* lds, int n, float* dst, int lddst, long rows, int C, clc_stream_t stream);
 int clc_axpby(const float* a, float alpha, const float* b, float beta, float* out, long n, clc_stream_t stream);
 /* RGB-head filters (3x3 / stride 2 [co][3][3][cin] and its 1x1 skip [co][cin], 9 cin <= 32) as the 32-column matrices of the patch-row
  * formulation (clc_im2col_small): w1[o][k] = w3[o][k] (k < 9 cin), ws[o][4 cin + c] = w1x1[o][c], zero elsewhere; and the reverse, ADDING the
