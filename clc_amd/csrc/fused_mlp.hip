@@ -43,6 +43,8 @@ struct MlpParams {
   const float* x; const float* w1; const float* b1; const float* w2; const float* b2; const float* res; float* y;
   const float* dy; const float* w2t; float* dx; float* dh; float* g;
   float* hsave;                 // [M][256] fc1 pre-activation: written by the forward pass (optional), read instead of recomputed backward
+  const float* ln_gamma; const float* ln_beta;   // LayerNorm in front of fc1 (LN instantiations): x is the block's raw input and the residual
+  float* ln_out; float* ln_ws;                   // backward: LN(x) [M][64] for fc1's filter gradient; partial rows [grid][2][64] (dgamma, dbeta)
   int ldx, ldr, ldy, lddy, lddx;
   int M, tiles;
   unsigned x_bytes, res_bytes, y_bytes, dy_bytes, dx_bytes, hid_bytes;
@@ -107,6 +109,98 @@ __device__ __forceinline__ void store_block_lines(float* scratch, const f32x4 (&
   }
 }
 
+
+
+// Measured and NOT built in: starting the second wave of every SIMD a few microseconds late (s_sleep), so that a SIMD's two waves are out of step
+// and one computes while the other is in its VALU / LDS / memory phase.  Under an eager kernel trace (every launch starts on an idle chip, all
+// waves together) that took the LayerNorm backward launch at 8 x 128 x 128 from 164.5 to 145.8 us; replayed inside a hipGraph, back to back with
+// its neighbours — how the step runs — offsets of 0 / 1.7 / 3.4 / 6.8 us all gave the same time (397 us per forward + backward of the block,
+// tools/bench_mlp_ln.py) and the same step (27.26-27.30 ms): the previous launch's tail already spreads the workgroups' start times.  The same
+// goes for the eager-trace ablations of the LayerNorm epilogue (column sums 11 us, x re-read 20 us per launch): 3-5 us in the graph.
+
+// ---------------------------------------------------------------------------------------------------------------- LayerNorm in front (LN)
+// `x + mlp(ln2(x))` from the block's RAW input: a lane (pixel li, half h) holds the 16-B chunks c = 8 kt + 2 t8 + h of its pixel's 64 channels
+// (the B-operand layout above), i.e. the whole row of nn.LayerNorm(64) sits in two lanes.  The row sums follow layernorm_fwd_vec_kernel<16>'s
+// xor-butterfly over its 16 chunk lanes (partners c ^ 8, c ^ 4, c ^ 2, c ^ 1 = kt, t8 bit 1, t8 bit 0 — all inside the lane — then h: one
+// cross-lane add), and the same expressions are used, so LN(x), the row statistics and the LayerNorm gradient carry THE SAME BITS as the
+// separate launches (elementwise.hip) — which batch sizes below the fusion threshold still use.
+__device__ __forceinline__ float ln_row_sum(const float (&p)[2][4]) {
+  float q[4];
+#pragma unroll
+  for (int t8 = 0; t8 < 4; ++t8) q[t8] = p[0][t8] + p[1][t8];
+  float s = (q[0] + q[2]) + (q[1] + q[3]);
+  s += __shfl_xor(s, 32, 64);
+  return s;
+}
+// in place: xf <- x - mean; returns the row's mean and reciprocal standard deviation
+__device__ __forceinline__ void ln_center(f32x4 (&xf)[2][4], float& mu, float& rs) {
+  float pp[2][4];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int t8 = 0; t8 < 4; ++t8) pp[kt][t8] = (xf[kt][t8][0] + xf[kt][t8][1]) + (xf[kt][t8][2] + xf[kt][t8][3]);
+  mu = ln_row_sum(pp) / 64.f;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int t8 = 0; t8 < 4; ++t8) {
+      const f32x4 d = xf[kt][t8] - mu;
+      xf[kt][t8] = d;
+      pp[kt][t8] = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+  rs = rsqrtf(ln_row_sum(pp) / 64.f + 1e-5f);
+}
+// in place: xf <- LN(xf); returns the row's mean and reciprocal standard deviation
+__device__ __forceinline__ void ln_apply(f32x4 (&xf)[2][4], const float* lns, int h, float& mu, float& rs) {
+  float pp[2][4];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int t8 = 0; t8 < 4; ++t8) pp[kt][t8] = (xf[kt][t8][0] + xf[kt][t8][1]) + (xf[kt][t8][2] + xf[kt][t8][3]);
+  mu = ln_row_sum(pp) / 64.f;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int t8 = 0; t8 < 4; ++t8) {
+      const f32x4 d = xf[kt][t8] - mu;
+      xf[kt][t8] = d;
+      pp[kt][t8] = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+  rs = rsqrtf(ln_row_sum(pp) / 64.f + 1e-5f);
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int t8 = 0; t8 < 4; ++t8) {
+      const int c0 = kt * 32 + 8 * t8 + 4 * h;
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(lns + c0), bt = *reinterpret_cast<const f32x4*>(lns + 64 + c0);
+      xf[kt][t8] = xf[kt][t8] * rs * gm + bt;
+    }
+}
+// Column sums over a tile's 32 pixels of one 32-channel block held in the accumulator layout, added to *acc of lane (channel cc = lane & 31 of
+// the block, pixel parity hh = lane >> 5): through the wave's 2 KB scratch, 16 pixels at a time, in a fixed order.  (A DPP butterfly per
+// register — quad permutes, row mirrors, one swizzle: 320 VALU instructions per tile, no LDS round trip — measured SLOWER: 166 vs 156 us per
+// launch at 8 x 128 x 128; f32 MFMAs do not hide VALU work and the waves of a launch run in step.)
+__device__ __forceinline__ void colsum_block(float* scratch, const f32x4 (&v)[4], float* acc, int lane, int li, int h) {
+  const int cc = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) {
+    if ((li >> 4) == rd) {
+      float* row = scratch + ((li & 15) << 5);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(row + ((((2 * q + h) ^ (li & 7))) << 2)) = v[q];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int pl = 2 * k + hh;
+      t += scratch[(pl << 5) + ((((cc >> 2) ^ (pl & 7))) << 2) + (cc & 3)];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    *acc += t;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- forward
 // Measured on the way (8 x 128 x 128, one launch, graph-replayed; tools/bench_mlp.py with CLC_TUNING=12:x):
 //   * f32 MFMAs and VALU instructions do NOT overlap on this hardware (the f32 matrix rate IS the vector rate): the GELU's ~19 VALU
@@ -117,21 +211,26 @@ __device__ __forceinline__ void store_block_lines(float* scratch, const f32x4 (&
 //     independent rate), so two hidden blocks are computed side by side and every MFMA alternates between two accumulators;
 //   * LDS fragment reads cost nothing measurable (ablated: 105 vs 111 us).
 // SAVE: store fc1's pre-activation (training, save mode).  PK: GELU on the packed-f32 instructions (gelu_parts2; same bits).
-template <int NW, int ABL = 0, bool SAVE = false, bool PK = true>   // ABL: timing diagnostics of CLC_TUNE_ABLATE (results WRONG): 1 = no GELU arithmetic, 2 = no fc1 MFMAs, 4 = no LDS fragment reads
+// LN: LayerNorm in front, computed in registers from the raw input, which is also the residual (p.res is not read).
+template <int NW, int ABL = 0, bool SAVE = false, bool PK = true, bool LN = false>   // ABL: timing diagnostics of CLC_TUNE_ABLATE (results WRONG): 1 = no GELU arithmetic, 2 = no fc1 MFMAs, 4 = no LDS fragment reads
 __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_kernel(const MlpParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W1s = smem;                    // [2][256][32]  fc1: rows = hidden, K = input channels
   float* W2s = W1s + 2 * CH * 32;       // [8][64][32]   fc2: rows = output channels, K = hidden
   float* b1s = W2s + 8 * CO * 32;       // [256]
   float* b2s = b1s + CH;                // [64]
+  float* lns = b2s + CO;                // [2][64]  LayerNorm gamma, beta (LN)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+  float* scratch = lns + 2 * CI + wave * 512;   // 2 KB per wave (LN, training): store_block_lines
   fill_image<NW>(W1s, p.w1, CH, CI, wave, lane);
   fill_image<NW>(W2s, p.w2, CO, CH, wave, lane);
   for (int i = tid; i < CH; i += 64 * NW) b1s[i] = p.b1 ? p.b1[i] : 0.f;
   for (int i = tid; i < CO; i += 64 * NW) b2s[i] = p.b2 ? p.b2[i] : 0.f;
+  if (LN) for (int i = tid; i < 2 * CI; i += 64 * NW) lns[i] = i < CI ? p.ln_gamma[i] : p.ln_beta[i - CI];
 
   const __amdgpu_buffer_rsrc_t xr = srd(p.x, p.x_bytes), rr = srd(p.res ? p.res : p.x, p.res ? p.res_bytes : p.x_bytes), yr = srd(p.y, p.y_bytes);
   const __amdgpu_buffer_rsrc_t hr = srd(SAVE ? p.hsave : p.y, SAVE ? p.hid_bytes : p.y_bytes);
+  const __amdgpu_buffer_rsrc_t lnr = srd(LN && p.ln_out ? p.ln_out : p.y, LN && p.ln_out ? (unsigned)p.M * CI * 4u : p.y_bytes);
   const int sw = (li >> 1) & 7;
   int fo[4];
 #pragma unroll
@@ -161,6 +260,19 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_kernel(const MlpParams p) 
       for (int t8 = 0; t8 < 4; ++t8) xf[kt][t8] = xn[kt][t8];
     load_x(t + gridDim.x, xn);          // the next tile's pixels: in flight under this tile's 512 MFMAs
     if (p0 >= p.M) continue;            // wave-uniform; there is no barrier below
+    f32x4 xraw[2][4];
+    if (LN) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int t8 = 0; t8 < 4; ++t8) xraw[kt][t8] = xf[kt][t8];
+      float mu, rs;
+      ln_apply(xf, lns, h, mu, rs);
+      if (p.ln_out) {   // training: LN(x) [M][64] dense for the backward launch (fc1's operand again there, and the x operand of its filter gradient)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) store_block_lines(scratch, xf[kt], lnr, (unsigned)p0, (unsigned)CI, (unsigned)(kt * 32), lane, li, h);
+      }
+    }
     f32x16 yacc[2];
 #pragma unroll
     for (int ob = 0; ob < 2; ++ob)
@@ -233,7 +345,12 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_kernel(const MlpParams p) 
     }
     // epilogue: y = (acc + b2) + 1 * res, 16 B per lane
     f32x4 rv[2][4];
-    if (p.res) {
+    if (LN) {   // (the accumulator layout of output block ob, quad q IS the operand layout of K-tile ob, group q: the residual is in registers)
+#pragma unroll
+      for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rv[ob][q] = xraw[ob][q];
+    } else if (p.res) {
 #pragma unroll
       for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
@@ -248,7 +365,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_kernel(const MlpParams p) 
         f32x4 v;
 #pragma unroll
         for (int s = 0; s < 4; ++s) v[s] = yacc[ob][4 * q + s] + bq[s];
-        if (p.res) {
+        if (LN || p.res) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) v[s] += 1.0f * rv[ob][q][s];
         }
@@ -261,7 +378,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_kernel(const MlpParams p) 
 // LOADH: the forward pass saved the fc1 pre-activation (clc_mlp_desc.h): it is read back (134 MB per 8 x 128 x 128 block, on a kernel that is
 // MFMA / VALU-bound either way) instead of recomputed (256 of a tile's 768 MFMAs).
 // Two hidden blocks side by side, as forward: consecutive MFMAs never share an accumulator.
-template <int NW, bool LOADH>
+// LN: x is the block's raw input and ln_out the LN(x) the forward launch stored (fc1's operand here); dx is the gradient of the whole
+// `x + mlp(LN(x))` — layernorm_bwd_vec_kernel<16>'s expressions on the accumulator registers (row statistics again from x), dy added as
+// the residual's gradient — and the per-workgroup column sums for dgamma / dbeta go to ln_ws.
+template <int NW, bool LOADH, bool LN = false, int ABL = 0>   // ABL (timing diagnostics, results WRONG): 1 = no dgamma / dbeta column sums, 4 = x not read again
 __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const MlpParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W1s = smem;                    // [2][256][32]  fc1 filter: rows = hidden, K = input channels (also read column-wise for dx)
@@ -269,9 +389,11 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const MlpParams p) 
   float* b1s = Wts + 2 * CH * 32;       // [256]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
   float* scratch = b1s + CH + wave * 512;   // 2 KB per wave: store_block_lines
+  float* lns = b1s + CH + NW * 512;         // [2][64]  LayerNorm gamma, beta (LN)
   fill_image<NW>(W1s, p.w1, CH, CI, wave, lane);
   fill_image<NW>(Wts, p.w2t, CH, CO, wave, lane);
   for (int i = tid; i < CH; i += 64 * NW) b1s[i] = p.b1 ? p.b1[i] : 0.f;
+  if (LN) for (int i = tid; i < 2 * CI; i += 64 * NW) lns[i] = i < CI ? p.ln_gamma[i] : p.ln_beta[i - CI];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -291,6 +413,14 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const MlpParams p) 
 #pragma unroll
     for (int s = 0; s < 4; ++s)
       co_[q][s] = ((8 * q + 4 * h + s) << 5) + ((((li >> 2) ^ ((4 * q + 2 * h + (s >> 1)) & 7))) << 2) + (li & 3);
+  const __amdgpu_buffer_rsrc_t lnr = srd(LN ? p.ln_out : p.x, p.x_bytes);   // fc1's operand
+  // LN: lane-private LDS slots (the kernel has no register to spare): [0..1] this lane's share of dgamma (channel ib * 32 + (lane & 31), pixel
+  // parity lane >> 5), [2..3] of dbeta
+  float* wacc = lns + 2 * CI + wave * 256 + lane;
+  if (LN) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wacc[k * 64] = 0.f;
+  }
 
   for (int t = blockIdx.x; t < p.tiles; t += gridDim.x) {
     const int p0 = (t * NW + wave) * 32;
@@ -303,7 +433,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const MlpParams p) 
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int t8 = 0; t8 < 4; ++t8) {
-          if (!LOADH) xf[kt][t8] = ld4(xr, xo + (unsigned)(kt * 32 + 8 * t8) * 4u);
+          if (!LOADH) xf[kt][t8] = ld4(lnr, xo + (unsigned)(kt * 32 + 8 * t8) * 4u);
           df[kt][t8] = ld4(dyr, yo + (unsigned)(kt * 32 + 8 * t8) * 4u);
         }
     }
@@ -313,8 +443,8 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const MlpParams p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) dxacc[ib][r] = 0.f;
 
-#pragma unroll 1
-    for (int hp = 0; hp < 4; ++hp) {
+    f32x4 xh[2][4];   // LN: the raw x again, for the LayerNorm gradient
+    auto hp_iter = [&](const int hp, auto&& before_dx) __attribute__((always_inline)) {
       f32x16 hacc[2], uacc[2];
       const unsigned ho = (pix * (unsigned)CH + (unsigned)(hp * 64 + 4 * h)) * 4u;
       f32x4 hv[2][4];
@@ -377,6 +507,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const MlpParams p) 
         store_block_lines(scratch, gq, gr, (unsigned)p0, (unsigned)CH, (unsigned)(hp * 64 + b * 32), lane, li, h);
         store_block_lines(scratch, dq, dhr, (unsigned)p0, (unsigned)CH, (unsigned)(hp * 64 + b * 32), lane, li, h);
       }
+      before_dx();
       // dx += W1^T[:, hidden blocks 2 hp, 2 hp + 1] dh   (K-tiles in order, the two input-channel blocks alternate)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
@@ -388,6 +519,63 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const MlpParams p) 
 #pragma unroll
             for (int ib = 0; ib < 2; ++ib) dxacc[ib] = MFMA(colb[((ib * CH) << 5) + co_[q][s]], uacc[b][4 * q + s], dxacc[ib]);
       }
+    };
+    if constexpr (LN) {
+      // the last round is peeled: the x loads for the LayerNorm gradient go out behind its dh / g stores and land under its 128 dx MFMAs
+      // (issued after the loop they waited for the whole store queue to drain: 20 us of a 163-us launch at 8 x 128 x 128)
+#pragma unroll 1
+      for (int hp = 0; hp < 3; ++hp) hp_iter(hp, [] {});
+      hp_iter(3, [&] {
+        const unsigned xo = (pix * (unsigned)p.ldx + 4u * h) * 4u;
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xh[ib][q] = (ABL & 4) ? xf[ib][q] : ld4(xr, xo + (unsigned)(ib * 32 + 8 * q) * 4u);
+      });
+    } else {
+#pragma unroll 1
+      for (int hp = 0; hp < 4; ++hp) hp_iter(hp, [] {});
+    }
+    if (LN) {
+      // d = gradient of LN's output; x again (from the caches) for xhat = (x - mean) * rstd
+      f32x4 dv[2][4];
+      float p1[2][4], p2[2][4];
+      float mu, rs;
+      ln_center(xh, mu, rs);
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(lns + ib * 32 + 8 * q + 4 * h);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) dv[ib][q][s] = dxacc[ib][4 * q + s] + 0.f;
+          xh[ib][q] = xh[ib][q] * rs;   // (x - mean) * rstd
+          const f32x4 g = dv[ib][q] * gm;
+          p1[ib][q] = (g[0] + g[1]) + (g[2] + g[3]);
+          p2[ib][q] = (g[0] * xh[ib][q][0] + g[1] * xh[ib][q][1]) + (g[2] * xh[ib][q][2] + g[3] * xh[ib][q][3]);
+        }
+      const float s1 = ln_row_sum(p1) / 64.f, s2 = ln_row_sum(p2) / 64.f;
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(lns + ib * 32 + 8 * q + 4 * h);
+          const f32x4 g = dv[ib][q] * gm;
+          f32x4 o = rs * (g - s1 - xh[ib][q] * s2);
+          o += df[ib][q];   // the residual branch's gradient
+          st4(o, dxr, (pix * (unsigned)p.lddx + (unsigned)(ib * 32 + 8 * q + 4 * h)) * 4u);
+        }
+      if (ABL & 1) continue;
+      int ln_ = lane;
+      asm volatile("" : "+v"(ln_));   // (addresses derived from here are recomputed per tile: hoisted out of the tile loop they spill)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib) {
+        colsum_block(scratch, dv[ib], wacc + (2 + ib) * 64, ln_, ln_ & 31, ln_ >> 5);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xh[ib][q] = dv[ib][q] * xh[ib][q];
+        colsum_block(scratch, xh[ib], wacc + ib * 64, ln_, ln_ & 31, ln_ >> 5);
+      }
+      continue;
     }
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib)
@@ -398,6 +586,19 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const MlpParams p) 
         for (int s = 0; s < 4; ++s) v[s] = dxacc[ib][4 * q + s] + 0.f;
         st4(v, dxr, (pix * (unsigned)p.lddx + (unsigned)(ib * 32 + 8 * q + 4 * h)) * 4u);
       }
+  }
+  if (LN) {   // the workgroup's row of partial sums, in a fixed order (every wave leaves the tile loop after the same number of rounds)
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, c = tid & 63;
+      const float* slot = lns + 2 * CI + (2 * which + (c >> 5)) * 64 + (c & 31);   // wave 0, parity 0
+      float tsum = 0.f;
+      for (int w = 0; w < NW; ++w) {
+        tsum += slot[w * 256];
+        tsum += slot[w * 256 + 32];
+      }
+      p.ln_ws[((size_t)blockIdx.x * 2 + which) * 64 + c] = tsum;
+    }
   }
 }
 
@@ -416,12 +617,21 @@ static int mlp_fill(const clc_mlp_desc* d, MlpParams& p, bool bwd, const char* w
   p.res = nullptr; p.y = nullptr; p.dy = nullptr; p.w2t = nullptr; p.dx = nullptr; p.dh = nullptr; p.g = nullptr; p.hsave = d->h;
   CLC_CHECK(!d->h || aligned16(d->h), "%s: h unaligned", who);
   p.hid_bytes = (unsigned)bytes(d->M, CH, CH);
+  p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.ln_out = nullptr; p.ln_ws = nullptr;
+  CLC_CHECK((d->ln_gamma == nullptr) == (d->ln_beta == nullptr), "%s: ln_gamma / ln_beta must both be given or both NULL", who);
+  if (d->ln_gamma) {
+    CLC_CHECK(aligned16(d->ln_gamma) && aligned16(d->ln_beta), "%s: ln_gamma / ln_beta unaligned", who);
+    CLC_CHECK(d->h == nullptr, "%s: the LayerNorm form recomputes the hidden tensor (h must be NULL)", who);
+  }
   p.ldr = p.ldy = p.lddy = p.lddx = 0; p.res_bytes = p.y_bytes = p.dy_bytes = p.dx_bytes = 0;
   if (!bwd) {
     CLC_CHECK(d->y && ok(d->y, d->ldy, CO) && ok(d->res, d->ldr, CO), "%s: y / res missing or unaligned", who);
     CLC_CHECK(bytes(d->M, d->ldy, CO) < (1ull << 31) && (!d->res || bytes(d->M, d->ldr, CO) < (1ull << 31)), "%s: tensor larger than 2 GiB", who);
     p.y = d->y; p.ldy = d->ldy; p.y_bytes = (unsigned)bytes(d->M, d->ldy, CO);
     p.res = d->res; p.ldr = d->ldr; p.res_bytes = d->res ? (unsigned)bytes(d->M, d->ldr, CO) : 0;
+    CLC_CHECK(!d->ln_gamma || !d->res, "%s: with ln_gamma the residual is x itself (res must be NULL)", who);
+    CLC_CHECK(!d->ln_out || (d->ln_gamma && aligned16(d->ln_out)), "%s: ln_out needs ln_gamma and 16-B alignment", who);
+    p.ln_out = d->ln_out;
   } else {
     CLC_CHECK(d->dy && d->w2t && d->dx && d->dh && d->g, "%s: dy / w2t / dx / dh / g missing", who);
     CLC_CHECK(ok(d->dy, d->lddy, CO) && ok(d->dx, d->lddx, CI) && aligned16(d->w2t) && aligned16(d->dh) && aligned16(d->g), "%s: gradient operands unaligned", who);
@@ -429,6 +639,11 @@ static int mlp_fill(const clc_mlp_desc* d, MlpParams& p, bool bwd, const char* w
     p.dy = d->dy; p.lddy = d->lddy; p.dy_bytes = (unsigned)bytes(d->M, d->lddy, CO);
     p.w2t = d->w2t; p.dx = d->dx; p.lddx = d->lddx; p.dx_bytes = (unsigned)bytes(d->M, d->lddx, CI);
     p.dh = d->dh; p.g = d->g;
+    if (d->ln_gamma) {
+      CLC_CHECK(d->ln_out && d->ln_ws && aligned16(d->ln_out) && aligned16(d->ln_ws), "%s: ln_out / ln_ws missing or unaligned", who);
+      CLC_CHECK(d->ldx == CI, "%s: the LayerNorm form reads a dense x (ln_out has its size)", who);
+      p.ln_out = d->ln_out; p.ln_ws = d->ln_ws;
+    }
   }
   return 0;
 }
@@ -436,23 +651,40 @@ static int mlp_fill(const clc_mlp_desc* d, MlpParams& p, bool bwd, const char* w
 // waves per workgroup: 32 pixels per wave; enough workgroups to give every CU one
 static int mlp_waves(long M) { return M >= 65536 ? 8 : (M >= 32768 ? 4 : 2); }
 
+static int mlp_grid(long M, int nw) {
+  const long tiles = (M + 32 * nw - 1) / (32 * nw);
+  return (int)(tiles < 256 ? tiles : 256);   // persistent: one workgroup per CU (129 KB of LDS), filters deposited once
+}
+
 template <int NW>
 static int mlp_launch(MlpParams& p, bool bwd, hipStream_t st) {
   p.tiles = (p.M + 32 * NW - 1) / (32 * NW);
-  const int grid = p.tiles < 256 ? p.tiles : 256;   // persistent: one workgroup per CU (129 KB of LDS), filters deposited once
-  const size_t lds_f = (size_t)(2 * CH * 32 + 8 * CO * 32 + CH + CO) * sizeof(float), lds_b = (size_t)(4 * CH * 32 + CH + NW * 512) * sizeof(float);
+  const int grid = mlp_grid(p.M, NW);
+  const size_t lds_f = (size_t)(2 * CH * 32 + 8 * CO * 32 + CH + CO + 2 * CI + NW * 512) * sizeof(float), lds_b = (size_t)(4 * CH * 32 + CH + NW * 512 + 2 * CI + NW * 256) * sizeof(float);
+  const int abl = clc_tuning[CLC_TUNE_ABLATE];
   static PerDeviceOnce attr_once;
   if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<NW, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
     auto optin = [&](auto kern) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f); };
     optin(&mlp_fwd_kernel<NW, 0, true, true>); optin(&mlp_fwd_kernel<NW, 0, false, true>);
     optin(&mlp_fwd_kernel<NW, 0, true, false>); optin(&mlp_fwd_kernel<NW, 0, false, false>);
+    optin(&mlp_fwd_kernel<NW, 0, false, true, true>);
     if (NW == 8) { optin(&mlp_fwd_kernel<8, 1>); optin(&mlp_fwd_kernel<8, 2>); optin(&mlp_fwd_kernel<8, 4>); optin(&mlp_fwd_kernel<8, 5>); }
   }
-  const int abl = clc_tuning[CLC_TUNE_ABLATE];
   auto fwd = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_f, st, p); };
-  if (bwd && p.hsave) hipLaunchKernelGGL((mlp_bwd_kernel<NW, true>), dim3(grid), dim3(64 * NW), lds_b, st, p);
+  if (bwd && p.ln_gamma && NW == 8 && abl) {   // timing diagnostics (wrong results)
+    auto go = [&](auto kern) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_b, st, p);
+    };
+    if (abl == 1) go(&mlp_bwd_kernel<8, false, true, 1>);
+    else if (abl == 4) go(&mlp_bwd_kernel<8, false, true, 4>);
+    else go(&mlp_bwd_kernel<8, false, true, 5>);
+  } else if (bwd && p.ln_gamma) hipLaunchKernelGGL((mlp_bwd_kernel<NW, false, true>), dim3(grid), dim3(64 * NW), lds_b, st, p);
+  else if (!bwd && p.ln_gamma) fwd(&mlp_fwd_kernel<NW, 0, false, true, true>);
+  else if (bwd && p.hsave) hipLaunchKernelGGL((mlp_bwd_kernel<NW, true>), dim3(grid), dim3(64 * NW), lds_b, st, p);
   else if (bwd) hipLaunchKernelGGL((mlp_bwd_kernel<NW, false>), dim3(grid), dim3(64 * NW), lds_b, st, p);
   else if (NW == 8 && abl) {   // timing diagnostics (wrong results): see the template argument
     if (abl == 1) fwd(&mlp_fwd_kernel<8, 1>);
@@ -479,5 +711,6 @@ static int mlp_dispatch(const clc_mlp_desc* d, bool bwd, clc_stream_t stream, co
   }
 }
 
+extern "C" int clc_mlp_blocks(long M) { return M > 0 ? mlp_grid(M, mlp_waves(M)) : 0; }
 extern "C" int clc_mlp_fwd(const clc_mlp_desc* d, clc_stream_t stream) { return mlp_dispatch(d, false, stream, "clc_mlp_fwd"); }
 extern "C" int clc_mlp_bwd(const clc_mlp_desc* d, clc_stream_t stream) { return mlp_dispatch(d, true, stream, "clc_mlp_bwd"); }

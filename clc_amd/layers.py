@@ -338,6 +338,9 @@ class Block(nn.Module):
             # x + f(LN(x)) twice: the residual gradients are added inside the LayerNorm backward passes
             f1 = ops.GradFold() if x.requires_grad else None
             x = self.msa(self.ln1(x, fold_in=f1, grad_slot=grad_slot), res=x, fold_out=f1)
+            if ops.mlp_ln_fusable(x, self.mlp[0].weight, self.mlp[2].weight):
+                # ... and ln2 with them: LN in registers forward, its whole backward pass in the data-gradient launch's epilogue
+                return ops.mlp_ln(x, self.ln2.weight, self.ln2.bias, self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias, out=out)
             f2 = ops.GradFold() if x.requires_grad else None
             if ops.mlp_fusable(x, self.mlp[0].weight, self.mlp[2].weight):
                 # large maps: fc1 + GELU + fc2 + residual in ONE launch, the 256-channel hidden tensor never leaves the registers; the

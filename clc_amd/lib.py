@@ -56,7 +56,8 @@ class RUDesc(C.Structure):
 class MlpDesc(C.Structure):
     _fields_ = [("x", fp), ("ldx", C.c_int), ("w1", fp), ("b1", fp), ("w2", fp), ("b2", fp), ("res", fp), ("ldr", C.c_int),
                 ("y", fp), ("ldy", C.c_int), ("M", C.c_long), ("Cin", C.c_int), ("Chid", C.c_int), ("Cout", C.c_int),
-                ("dy", fp), ("lddy", C.c_int), ("w2t", fp), ("dx", fp), ("lddx", C.c_int), ("dh", fp), ("g", fp), ("h", fp)]
+                ("dy", fp), ("lddy", C.c_int), ("w2t", fp), ("dx", fp), ("lddx", C.c_int), ("dh", fp), ("g", fp), ("h", fp),
+                ("ln_gamma", fp), ("ln_beta", fp), ("ln_out", fp), ("ln_ws", fp)]
 
 
 class GDNEntry(C.Structure):
@@ -159,6 +160,7 @@ SIGNATURES = {
     "clc_residual_unit_dgrad": (_i, [C.POINTER(RUDesc), fp]),
     "clc_mlp_fwd": (_i, [C.POINTER(MlpDesc), fp]),
     "clc_mlp_bwd": (_i, [C.POINTER(MlpDesc), fp]),
+    "clc_mlp_blocks": (_i, [_l]),
     "clc_maxpool2d": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, fp]),
     "clc_adaptive_pool2d": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, _i, fp]),
     "clc_optim_chunk_elems": (_i, []),

@@ -1042,6 +1042,7 @@ def residual_unit(x, units):
 
 FUSED_MLP = int(os.environ.get("CLC_FUSED_MLP", "1"))              # 0: fc1 + GELU and fc2 as two clc_conv2d launches (A/B knob; same bits)
 FUSED_MLP_MIN_PIX = int(os.environ.get("CLC_FUSED_MLP_MIN", "32768"))   # pixels from which the persistent fused kernel pays (one workgroup per CU)
+FUSED_MLP_LN = int(os.environ.get("CLC_FUSED_MLP_LN", "1"))        # 1: the LayerNorm in front (Block.ln2) inside the fused kernels too (same bits; not with MLP_SAVE_H)
 MLP_SAVE_H = int(os.environ.get("CLC_MLP_SAVE_H", "0"))            # training: 0 = nothing stored, the backward kernel recomputes fc1 from the LayerNorm output;
                                                                    # 1 = the forward pass stores fc1's pre-activation and the backward kernel reads it (same bits;
                                                                    #     111 vs 133 us per launch at 8x128x128, and the same step time: the 134 MB it writes cost as much)
@@ -1056,8 +1057,16 @@ def mlp_fusable(x, w1, w2, pair=None) -> bool:
     return M >= FUSED_MLP_MIN_PIX and M % 32 == 0 and M < (1 << 24)
 
 
-def mlp_fwd_raw(x, w1, b1, w2, b2, res=None, out=None, h_out=None):
-    """One clc_mlp_fwd launch: out = res + fc2(gelu(fc1(x))); h_out ([N,256,H,W], optional) receives fc1's pre-activation."""
+def mlp_ln_fusable(x, w1, w2, pair=None) -> bool:
+    """mlp_fusable and the LayerNorm in front can ride along: the kernels then read the block's raw (dense) input."""
+    if not (FUSED_MLP_LN and not MLP_SAVE_H and mlp_fusable(x, w1, w2, pair)):
+        return False
+    return nhwc(x)[6] == x.shape[1]
+
+
+def mlp_fwd_raw(x, w1, b1, w2, b2, res=None, out=None, h_out=None, ln=None):
+    """One clc_mlp_fwd launch: out = res + fc2(gelu(fc1(x))); h_out ([N,256,H,W], optional) receives fc1's pre-activation.
+    ln = (gamma, beta): out = x + fc2(gelu(fc1(LN(x)))) from the raw x (res and h_out must be None)."""
     _require_gpu(x, "mlp")
     x, xp, N, H, W, Cin, ldx = nhwc(x)
     if out is None:
@@ -1077,14 +1086,22 @@ def mlp_fwd_raw(x, w1, b1, w2, b2, res=None, out=None, h_out=None):
     if h_out is not None:
         assert h_out.is_contiguous(memory_format=CL)
         d.h = h_out.data_ptr()
+    if ln is not None:
+        assert res is None and h_out is None
+        d.ln_gamma, d.ln_beta = ln[0].data_ptr(), ln[1].data_ptr()
+        if len(ln) > 2 and ln[2] is not None:   # training: LN(x) kept for the backward launch
+            assert ln[2].is_contiguous(memory_format=CL)
+            d.ln_out = ln[2].data_ptr()
     _prof_hint(2.0 * N * H * W * 2 * Cin * w1.shape[0], f"mlp fwd {Cin}->{w1.shape[0]}->{w2.shape[0]} {N}x{H}x{W}")
     _lib.check(_L().clc_mlp_fwd(C.byref(d), _stream()), "clc_mlp_fwd")
     return out
 
 
-def mlp_bwd_raw(x, dy, w1, b1, w2t, h_saved=None):
+def mlp_bwd_raw(x, dy, w1, b1, w2t, h_saved=None, ln=None):
     """One clc_mlp_bwd launch -> (dx, dh, g): the block's input gradient, and the two [N,256,H,W] tensors its filter gradients contract
-    (dh = d(fc1 pre-activation), g = gelu(fc1(x)) — fc1(x) read from h_saved, or recomputed from x when that is None)."""
+    (dh = d(fc1 pre-activation), g = gelu(fc1(x)) — fc1(x) read from h_saved, or recomputed from x when that is None).
+    ln = (gamma, beta, LN(x) as the forward launch stored it): x is the raw input of `x + mlp(LN(x))`; -> (dx of the whole expression, dh, g,
+    partial rows [nb][2][C] of dgamma / dbeta, nb)."""
     x, xp, N, H, W, Cin, ldx = nhwc(x)
     dy, dp, *_r, lddy = nhwc(dy)
     Ch = w1.shape[0]
@@ -1096,9 +1113,16 @@ def mlp_bwd_raw(x, dy, w1, b1, w2t, h_saved=None):
     d.dy, d.lddy, d.w2t, d.dx, d.lddx, d.dh, d.g = dp, lddy, w2t.data_ptr(), dx.data_ptr(), Cin, dh.data_ptr(), g.data_ptr()
     if h_saved is not None:
         d.h = h_saved.data_ptr()
+    if ln is not None:
+        assert h_saved is None and ldx == Cin and ln[2].is_contiguous(memory_format=CL)
+        nb = _L().clc_mlp_blocks(N * H * W)
+        ws = torch.empty(nb * 2 * Cin, device=x.device, dtype=torch.float32)
+        d.ln_gamma, d.ln_beta, d.ln_out, d.ln_ws = ln[0].data_ptr(), ln[1].data_ptr(), ln[2].data_ptr(), ws.data_ptr()
     # algorithmic work = the two data gradients (the recomputed fc1 is this path's overhead, not counted)
     _prof_hint(2.0 * N * H * W * 2 * Cin * Ch, f"mlp dgrad {Cin}->{Ch}->{dy.shape[1]} {N}x{H}x{W}")
     _lib.check(_L().clc_mlp_bwd(C.byref(d), _stream()), "clc_mlp_bwd")
+    if ln is not None:
+        return dx, dh, g, ws, nb
     return dx, dh, g
 
 
@@ -1108,14 +1132,19 @@ class _MlpFn(Function):
     on `fold_out` (the LayerNorm in front adds it in its backward kernel), as _ConvFn does for fc2."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, res, fold_out, out_buf):
+    def forward(ctx, x, w1, b1, w2, b2, res, fold_out, out_buf, ln_g=None, ln_b=None):
         _own(ctx)
-        hs = new_act(x.shape[0], w1.shape[0], x.shape[2], x.shape[3], x) if (MLP_SAVE_H and _recording(ctx)) else None
-        y = mlp_fwd_raw(x, w1, b1, w2, b2, res, out_buf, hs)
+        ln = (ln_g, ln_b) if ln_g is not None else None
+        hs = new_act(x.shape[0], w1.shape[0], x.shape[2], x.shape[3], x) if (MLP_SAVE_H and _recording(ctx) and ln is None) else None
+        if ln is not None and _recording(ctx):
+            hs = new_act(x.shape[0], x.shape[1], x.shape[2], x.shape[3], x)   # LN(x), stored by the forward launch
+            ln = (ln_g, ln_b, hs)
+        y = mlp_fwd_raw(x, w1, b1, w2, b2, res, out_buf, None if ln is not None else hs, ln)
         if out_buf is not None:
             y = out_buf.detach()
         ctx.fold_out, ctx.has_res = fold_out, res is not None
         ctx.has_b = (b1 is not None, b2 is not None)
+        ctx.ln = ln[:2] if ln is not None else None
         ctx.save_for_backward(x, w1, b1, w2, b2, hs)
         return y
 
@@ -1124,23 +1153,47 @@ class _MlpFn(Function):
         _reown(ctx)
         x, w1, b1, w2, b2, hs = ctx.saved_tensors
         need = ctx.needs_input_grad
-        dres = None
+        dres = dlg = dlb = None
         if ctx.has_res and need[5]:
             if not (ctx.fold_out is not None and ctx.fold_out.park(dy, 1.0)):
                 dres = dy
-        dx, dh, g = mlp_bwd_raw(x, dy, w1, b1, _wt_of(w2), hs)
+        xw = x   # the x operand of fc1's filter gradient
+        if ctx.ln is None:
+            dx, dh, g = mlp_bwd_raw(x, dy, w1, b1, _wt_of(w2), hs)
+        else:
+            # the LayerNorm's backward pass (residual gradient folded in) happens inside the launch; its parameter gradients as _LayerNormFn's
+            xw = hs
+            dx, dh, g, ws, nb = mlp_bwd_raw(x, dy, w1, b1, _wt_of(w2), None, ctx.ln + (hs,))
+            Cc = x.shape[1]
+            gd, bd = _direct_grad(ctx.ln[0]), _direct_grad(ctx.ln[1])
+            direct = gd is not None and bd is not None
+            if direct and DEFER_REDUCTIONS:
+                defer_reduce(ws, nb, 2 * Cc, gd, bd, Cc)
+            else:
+                tot = ws.view(nb, 2, Cc).sum(0)
+                if direct:
+                    gd.add_(tot[0])
+                    bd.add_(tot[1])
+                else:
+                    dlg, dlb = tot[0], tot[1]
         dw1 = db1 = dw2 = db2 = None
         if need[1] or (ctx.has_b[0] and need[2]):
-            dw1, db1 = _ConvFn._wgrad(x, dh, w1, b1, ctx.has_b[0], need[1], ctx.has_b[0] and need[2], 1, 1, 0, {})
+            dw1, db1 = _ConvFn._wgrad(xw, dh, w1, b1, ctx.has_b[0], need[1], ctx.has_b[0] and need[2], 1, 1, 0, {})
         if need[3] or (ctx.has_b[1] and need[4]):
             dw2, db2 = _ConvFn._wgrad(g, dy, w2, b2, ctx.has_b[1], need[3], ctx.has_b[1] and need[4], 1, 1, 0, {})
-        return (dx if need[0] else None), dw1, db1, dw2, db2, dres, None, None
+        return (dx if need[0] else None), dw1, db1, dw2, db2, dres, None, None, dlg, dlb
 
 
 def mlp(x, w1, b1, w2, b2, *, res=None, fold_out=None, out=None):
-    """x + fc2(gelu(fc1(LN(x)))) of a Swin block, fused (see mlp_fusable)."""
+    """res + fc2(gelu(fc1(x))) of a Swin block (x = the LayerNorm's output), fused (see mlp_fusable)."""
     _note_grad_mode()
     return _MlpFn.apply(x, w1, b1, w2, b2, res, fold_out, out)
+
+
+def mlp_ln(x, ln_g, ln_b, w1, b1, w2, b2, *, out=None):
+    """x + fc2(gelu(fc1(LN(x)))) of a Swin block from its raw input, LayerNorm included (see mlp_ln_fusable)."""
+    _note_grad_mode()
+    return _MlpFn.apply(x, w1, b1, w2, b2, None, None, out, ln_g, ln_b)
 
 
 def linear(x, w, b=None, *, act=ACT_NONE, res=None, w2=None, b2=None, fold_in=None, fold_out=None, out=None, gate_in=None, gate_out=None):

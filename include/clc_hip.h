@@ -472,9 +472,18 @@ typedef struct {
   /* optional, both directions: h [M][256] dense = the fc1 PRE-activation (W1 x + b1).  clc_mlp_fwd writes it when non-NULL (training,
    * "save" mode); clc_mlp_bwd then reads it instead of recomputing it (256 of a tile's 768 MFMAs for 134 MB of traffic per 8x128x128). */
   float* h;
+  /* optional, both directions: the LayerNorm in front (Block.ln2, CLC_run.py:183,192).  ln_gamma / ln_beta [64] non-NULL: x is the block's RAW
+   * input and the kernels compute  y = x + mlp(LN(x))  (res must be NULL — the residual is x; h must be NULL).  clc_mlp_fwd also writes LN(x)
+   * to ln_out [M][64] dense when that is non-NULL (training).  clc_mlp_bwd reads it back (fc1's operand again; it is also the x operand of
+   * fc1's filter gradient), needs a dense x, returns in dx the gradient of the whole expression (clc_layernorm_bwd's result with dy folded in
+   * as dx_add) and leaves clc_mlp_blocks(M) partial rows [2][64] (dgamma, dbeta) in ln_ws for clc_partial_reduce_batched.  LN(x), y and dx
+   * carry the bits of clc_layernorm_fwd / clc_layernorm_bwd around the plain form. */
+  const float* ln_gamma; const float* ln_beta;
+  float* ln_out; float* ln_ws;
 } clc_mlp_desc;
 int clc_mlp_fwd(const clc_mlp_desc* d, clc_stream_t stream);
 int clc_mlp_bwd(const clc_mlp_desc* d, clc_stream_t stream);
+int clc_mlp_blocks(long M);   /* workgroups (= partial rows in ln_ws) of a clc_mlp_bwd launch over M pixels */
 
 /* ---- reference-retrieval feature extractor: the pooling layers of torchvision's ResNet50 as the reference uses it ----
  * clc_maxpool2d        nn.MaxPool2d(ks, stride, pad) of resnet50.maxpool (/root/reference/dataloader_ref_cluster.py:41-44, dataloader_CLC.py:275),

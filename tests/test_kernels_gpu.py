@@ -917,6 +917,63 @@ def test_fused_mlp_same_bits_as_two_launches(dev, N, H, W, strided, save_h):
     _close(dxf, xt.grad, 1e-4, "fused mlp dx vs torch")
 
 
+@pytest.mark.parametrize("N,H,W,strided", [(8, 64, 64, False), (2, 128, 128, True), (8, 128, 128, False), (1, 64, 96, True), (3, 40, 56, False)])
+def test_fused_mlp_with_layernorm_same_bits_as_separate_launches(dev, N, H, W, strided):
+    """The LayerNorm form of clc_mlp_fwd / clc_mlp_bwd (`x + mlp(ln2(x))` from the block's raw input, /root/reference/models/CLC_run.py:183,192):
+    LN in registers forward, its backward pass (+ the residual's gradient) in the data-gradient launch — against clc_layernorm_fwd / _bwd around
+    the plain fused form: THE SAME BITS for y, dx and the four filter / bias gradients (the row sums follow the LayerNorm kernel's butterfly);
+    dgamma / dbeta sum the same products over the pixels in another order -> fp32 accuracy.  And plain torch fp32."""
+    from clc_amd import layers, ops
+
+    torch.manual_seed(11)
+    fc1, fc2, ln = layers.Linear(64, 256).to(dev), layers.Linear(256, 64).to(dev), layers.LayerNorm(64).to(dev)
+    with torch.no_grad():
+        fc1.bias.normal_(0, 0.3)
+        fc2.bias.normal_(0, 0.3)
+        ln.weight.normal_(1.0, 0.2)
+        ln.bias.normal_(0, 0.2)
+    prms = list(fc1.parameters()) + list(fc2.parameters()) + list(ln.parameters())
+    x0 = (torch.randn(N, 64, H, W, device=dev) * 1.5 + 0.3).contiguous(memory_format=CL)
+    gy = torch.randn(N, 64, H, W, device=dev).contiguous(memory_format=CL)
+    wide = torch.randn(N, 128, H, W, device=dev).contiguous(memory_format=CL)
+    old_min = ops.FUSED_MLP_MIN_PIX
+    ops.FUSED_MLP_MIN_PIX = 1024
+    try:
+        assert ops.mlp_ln_fusable(x0, fc1.weight, fc2.weight)
+        res = {}
+        for mode in ("ln_fused", "separate"):
+            for prm in prms:
+                prm.grad = None
+            x = x0.clone().requires_grad_(True)
+            out = ops.new_act(N, 128, H, W, x0)[:, 64:] if strided else None
+            if mode == "ln_fused":
+                y = ops.mlp_ln(x, ln.weight, ln.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, out=out)
+            else:
+                f2 = ops.GradFold()
+                y = ops.mlp(ln(x, fold_in=f2), fc1.weight, fc1.bias, fc2.weight, fc2.bias, res=x, fold_out=f2, out=out)
+            y.backward(wide[:, 64:] if strided else gy)
+            torch.cuda.synchronize()
+            res[mode] = (y.detach().clone(), x.grad.clone(), [prm.grad.clone() for prm in prms])
+    finally:
+        ops.FUSED_MLP_MIN_PIX = old_min
+    (yf, dxf, pf), (yc, dxc, pc) = res["ln_fused"], res["separate"]
+    assert torch.equal(yf, yc), f"forward differs from LayerNorm + fused MLP: max {(yf - yc).abs().max().item():.3e}"
+    assert torch.equal(dxf, dxc), f"dx differs: max {(dxf - dxc).abs().max().item():.3e}"
+    for a, b, name in zip(pf[:4], pc[:4], ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")):
+        assert torch.equal(a, b), f"{name} gradient differs: max {(a - b).abs().max().item():.3e}"
+    _close(pf[4], pc[4], 2e-5, "ln.weight gradient vs the LayerNorm kernel")
+    _close(pf[5], pc[5], 2e-5, "ln.bias gradient vs the LayerNorm kernel")
+    xt = x0.clone().requires_grad_(True)
+    lw, lb = ln.weight.detach().clone().requires_grad_(True), ln.bias.detach().clone().requires_grad_(True)
+    t = F.layer_norm(xt.permute(0, 2, 3, 1), (64,), lw, lb, 1e-5).permute(0, 3, 1, 2)
+    yt = xt + F.conv2d(F.gelu(F.conv2d(t, fc1.weight.detach()[:, :, None, None], fc1.bias.detach())), fc2.weight.detach()[:, :, None, None], fc2.bias.detach())
+    yt.backward(wide[:, 64:] if strided else gy)
+    _close(yf, yt.detach(), 2e-5, "ln-fused mlp forward vs torch")
+    _close(dxf, xt.grad, 1e-4, "ln-fused mlp dx vs torch")
+    _close(pf[4], lw.grad, 1e-4, "ln.weight gradient vs torch")
+    _close(pf[5], lb.grad, 1e-4, "ln.bias gradient vs torch")
+
+
 @pytest.mark.parametrize("N,Cin,H,W,Cout,shuffle", [(2, 128, 64, 64, 12, True), (1, 128, 40, 72, 12, True), (2, 64, 64, 48, 16, False), (3, 256, 48, 48, 12, True)])
 def test_16_column_kernel_for_the_few_channel_tail(dev, N, Cin, H, W, Cout, shuffle):
     """conv_igemm_n16_kernel (v_mfma_f32_16x16x4_f32, 256 x 16 tiles; tuning key 20): the synthesis transform's subpel tail, 128 -> 12 with the
