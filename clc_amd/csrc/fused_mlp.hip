@@ -201,6 +201,66 @@ __device__ __forceinline__ void colsum_block(float* scratch, const f32x4 (&v)[4]
   }
 }
 
+
+// The LayerNorm gradient as the epilogue of a data-gradient launch: dxacc = the gradient of LN's output in the accumulator layout, xh = the raw
+// x of the tile's pixels in the same layout (destroyed), add = the residual branch's gradient.  layernorm_bwd_vec_kernel<16>'s expressions and
+// row-sum order (-> its bits); the tile's dgamma / dbeta column sums are added to the lane-private slots `wacc`.
+template <bool NO_COLSUM>
+__device__ __forceinline__ void ln_bwd_epilogue(const f32x16 (&dxacc)[2], f32x4 (&xh)[2][4], const f32x4 (&add)[2][4], const float* lns, float* scratch,
+                                                float* wacc, __amdgpu_buffer_rsrc_t dxr, unsigned pix, unsigned lddx, int lane, int h) {
+  f32x4 dv[2][4];
+  float p1[2][4], p2[2][4];
+  float mu, rs;
+  ln_center(xh, mu, rs);
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(lns + ib * 32 + 8 * q + 4 * h);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) dv[ib][q][s] = dxacc[ib][4 * q + s] + 0.f;
+      xh[ib][q] = xh[ib][q] * rs;   // (x - mean) * rstd
+      const f32x4 g = dv[ib][q] * gm;
+      p1[ib][q] = (g[0] + g[1]) + (g[2] + g[3]);
+      p2[ib][q] = (g[0] * xh[ib][q][0] + g[1] * xh[ib][q][1]) + (g[2] * xh[ib][q][2] + g[3] * xh[ib][q][3]);
+    }
+  const float s1 = ln_row_sum(p1) / 64.f, s2 = ln_row_sum(p2) / 64.f;
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(lns + ib * 32 + 8 * q + 4 * h);
+      const f32x4 g = dv[ib][q] * gm;
+      f32x4 o = rs * (g - s1 - xh[ib][q] * s2);
+      o += add[ib][q];   // the residual branch's gradient
+      st4(o, dxr, (pix * lddx + (unsigned)(ib * 32 + 8 * q + 4 * h)) * 4u);
+    }
+  if (NO_COLSUM) return;
+  int ln_ = lane;
+  asm volatile("" : "+v"(ln_));   // (addresses derived from here are recomputed per tile: hoisted out of the tile loop they spill)
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib) {
+    colsum_block(scratch, dv[ib], wacc + (2 + ib) * 64, ln_, ln_ & 31, ln_ >> 5);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xh[ib][q] = dv[ib][q] * xh[ib][q];
+    colsum_block(scratch, xh[ib], wacc + ib * 64, ln_, ln_ & 31, ln_ >> 5);
+  }
+}
+// the workgroup's row [2][64] of dgamma / dbeta partial sums from its waves' slots, in a fixed order (call after a barrier)
+template <int NW>
+__device__ __forceinline__ void ln_ws_row(const float* slots, float* ln_ws, int tid) {
+  if (tid < 128) {
+    const int which = tid >> 6, c = tid & 63;
+    const float* slot = slots + (2 * which + (c >> 5)) * 64 + (c & 31);   // wave 0, parity 0
+    float tsum = 0.f;
+    for (int w = 0; w < NW; ++w) {
+      tsum += slot[w * 256];
+      tsum += slot[w * 256 + 32];
+    }
+    ln_ws[((size_t)blockIdx.x * 2 + which) * 64 + c] = tsum;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- forward
 // Measured on the way (8 x 128 x 128, one launch, graph-replayed; tools/bench_mlp.py with CLC_TUNING=12:x):
 //   * f32 MFMAs and VALU instructions do NOT overlap on this hardware (the f32 matrix rate IS the vector rate): the GELU's ~19 VALU
@@ -537,44 +597,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const MlpParams p) 
       for (int hp = 0; hp < 4; ++hp) hp_iter(hp, [] {});
     }
     if (LN) {
-      // d = gradient of LN's output; x again (from the caches) for xhat = (x - mean) * rstd
-      f32x4 dv[2][4];
-      float p1[2][4], p2[2][4];
-      float mu, rs;
-      ln_center(xh, mu, rs);
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 gm = *reinterpret_cast<const f32x4*>(lns + ib * 32 + 8 * q + 4 * h);
-#pragma unroll
-          for (int s = 0; s < 4; ++s) dv[ib][q][s] = dxacc[ib][4 * q + s] + 0.f;
-          xh[ib][q] = xh[ib][q] * rs;   // (x - mean) * rstd
-          const f32x4 g = dv[ib][q] * gm;
-          p1[ib][q] = (g[0] + g[1]) + (g[2] + g[3]);
-          p2[ib][q] = (g[0] * xh[ib][q][0] + g[1] * xh[ib][q][1]) + (g[2] * xh[ib][q][2] + g[3] * xh[ib][q][3]);
-        }
-      const float s1 = ln_row_sum(p1) / 64.f, s2 = ln_row_sum(p2) / 64.f;
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 gm = *reinterpret_cast<const f32x4*>(lns + ib * 32 + 8 * q + 4 * h);
-          const f32x4 g = dv[ib][q] * gm;
-          f32x4 o = rs * (g - s1 - xh[ib][q] * s2);
-          o += df[ib][q];   // the residual branch's gradient
-          st4(o, dxr, (pix * (unsigned)p.lddx + (unsigned)(ib * 32 + 8 * q + 4 * h)) * 4u);
-        }
-      if (ABL & 1) continue;
-      int ln_ = lane;
-      asm volatile("" : "+v"(ln_));   // (addresses derived from here are recomputed per tile: hoisted out of the tile loop they spill)
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib) {
-        colsum_block(scratch, dv[ib], wacc + (2 + ib) * 64, ln_, ln_ & 31, ln_ >> 5);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xh[ib][q] = dv[ib][q] * xh[ib][q];
-        colsum_block(scratch, xh[ib], wacc + ib * 64, ln_, ln_ & 31, ln_ >> 5);
-      }
+      ln_bwd_epilogue<(ABL & 1) != 0>(dxacc, xh, df, lns, scratch, wacc, dxr, pix, (unsigned)p.lddx, lane, h);
       continue;
     }
 #pragma unroll
@@ -589,17 +612,182 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const MlpParams p) 
   }
   if (LN) {   // the workgroup's row of partial sums, in a fixed order (every wave leaves the tile loop after the same number of rounds)
     __syncthreads();
-    if (tid < 128) {
-      const int which = tid >> 6, c = tid & 63;
-      const float* slot = lns + 2 * CI + (2 * which + (c >> 5)) * 64 + (c & 31);   // wave 0, parity 0
-      float tsum = 0.f;
-      for (int w = 0; w < NW; ++w) {
-        tsum += slot[w * 256];
-        tsum += slot[w * 256 + 32];
+    ln_ws_row<NW>(lns + 2 * CI, p.ln_ws, tid);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------- LayerNorm + Linear
+// ln1 and the attention's embedding (`self.embedding_layer(ln1(x))`: nn.LayerNorm(64) + nn.Linear(64, 192), /root/reference/models/CLC_run.py:120,
+// 141, 180, 191) as ONE launch, and the Linear's data gradient + the LayerNorm's backward pass (+ the block's residual gradient) as one more —
+// the same building blocks as above: a wave owns 32 pixels, the filter is a resident LDS image, LN in registers in the operand layout, the
+// LayerNorm gradient as the epilogue on the dx accumulators, whole-line stores.  Same K order and expressions as the LayerNorm kernel followed
+// by the tiled 1x1 kernels -> the same bits for qkv and dx.
+struct LnLinParams {
+  const float* x; const float* w; const float* b; const float* ln_gamma; const float* ln_beta;
+  float* y; float* ln_out;
+  const float* dy; const float* wt; float* dx; const float* dadd; float* ln_ws;
+  int ldx, lddx, ldadd;
+  int M, tiles;
+  unsigned x_bytes, y_bytes, dx_bytes, add_bytes;
+};
+
+template <int NW, int CO_>   // CO_ output channels (a multiple of 64)
+__global__ __launch_bounds__(64 * NW, 2) void lnlin_fwd_kernel(const LnLinParams p) {
+  constexpr int NB = CO_ / 32;
+  static_assert(NB % 2 == 0, "output blocks are computed in pairs");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;                       // [2][CO_][32]  rows = output channels, K = input channels
+  float* bs = Ws + 2 * CO_ * 32;          // [CO_]
+  float* lns = bs + CO_;                  // [2][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+  float* scratch = lns + 2 * CI + wave * 512;
+  fill_image<NW>(Ws, p.w, CO_, CI, wave, lane);
+  for (int i = tid; i < CO_; i += 64 * NW) bs[i] = p.b ? p.b[i] : 0.f;
+  for (int i = tid; i < 2 * CI; i += 64 * NW) lns[i] = i < CI ? p.ln_gamma[i] : p.ln_beta[i - CI];
+  const __amdgpu_buffer_rsrc_t xr = srd(p.x, p.x_bytes), yr = srd(p.y, p.y_bytes);
+  const __amdgpu_buffer_rsrc_t lnr = srd(p.ln_out ? p.ln_out : p.y, p.ln_out ? (unsigned)p.M * CI * 4u : p.y_bytes);
+  const int sw = (li >> 1) & 7;
+  int fo[4];
+#pragma unroll
+  for (int t8 = 0; t8 < 4; ++t8) fo[t8] = ((2 * t8 + h) ^ sw) << 2;
+  const float* Wl = Ws + (li << 5);
+  auto load_x = [&](int t, f32x4 (&xf)[2][4]) {   // a tile past the end reads zeros through the SRD's range check
+    const int p0 = (t * NW + wave) * 32;
+    const unsigned xo = ((unsigned)(p0 + li) * (unsigned)p.ldx + 4u * h) * 4u;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int t8 = 0; t8 < 4; ++t8) xf[kt][t8] = ld4(xr, p0 < p.M ? xo + (unsigned)(kt * 32 + 8 * t8) * 4u : kOOB);
+  };
+  f32x4 xf[2][4], xn[2][4];
+  load_x(blockIdx.x, xn);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = blockIdx.x; t < p.tiles; t += gridDim.x) {
+    const int p0 = (t * NW + wave) * 32;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int t8 = 0; t8 < 4; ++t8) xf[kt][t8] = xn[kt][t8];
+    load_x(t + gridDim.x, xn);
+    if (p0 >= p.M) continue;            // wave-uniform; no barrier below
+    float mu, rs;
+    ln_apply(xf, lns, h, mu, rs);
+    if (p.ln_out) {   // training: the x operand of the Linear's filter gradient
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) store_block_lines(scratch, xf[kt], lnr, (unsigned)p0, (unsigned)CI, (unsigned)(kt * 32), lane, li, h);
+    }
+#pragma unroll 1
+    for (int op = 0; op < NB / 2; ++op) {
+      f32x16 acc[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+      const float* wb = Wl + ((op * 64) << 5);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {       // K-steps (kt, t8) in the tiled kernels' order
+        f32x4 a[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) a[b] = *reinterpret_cast<const f32x4*>(wb + (((j >> 2) * CO_ + b * 32) << 5) + fo[j & 3]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[b] = MFMA(a[b][s], xf[j >> 2][j & 3][s], acc[b]);
       }
-      p.ln_ws[((size_t)blockIdx.x * 2 + which) * 64 + c] = tsum;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        f32x4 vq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 bq = *reinterpret_cast<const f32x4*>(bs + (2 * op + b) * 32 + 8 * q + 4 * h);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) vq[q][s] = acc[b][4 * q + s] + bq[s];
+        }
+        store_block_lines(scratch, vq, yr, (unsigned)p0, (unsigned)CO_, (unsigned)((2 * op + b) * 32), lane, li, h);
+      }
     }
   }
+}
+
+template <int NW, int CO_>
+__global__ __launch_bounds__(64 * NW, 2) void lnlin_bwd_kernel(const LnLinParams p) {
+  constexpr int NB = CO_ / 32;
+  static_assert(NB % 2 == 0, "K-tiles are consumed in pairs");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wts = smem;                      // [NB][64][32]  the transposed filter: rows = input channels, K = output channels
+  float* lns = Wts + NB * CI * 32;        // [2][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+  float* scratch = lns + 2 * CI + wave * 512;
+  float* wacc = lns + 2 * CI + NW * 512 + wave * 256 + lane;   // lane-private dgamma / dbeta slots (ln_bwd_epilogue)
+  fill_image<NW>(Wts, p.wt, CI, CO_, wave, lane);
+  for (int i = tid; i < 2 * CI; i += 64 * NW) lns[i] = i < CI ? p.ln_gamma[i] : p.ln_beta[i - CI];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) wacc[k * 64] = 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t xr = srd(p.x, p.x_bytes), dyr = srd(p.dy, p.y_bytes), dxr = srd(p.dx, p.dx_bytes);
+  const __amdgpu_buffer_rsrc_t ar = srd(p.dadd ? p.dadd : p.x, p.dadd ? p.add_bytes : p.x_bytes);
+  const int sw = (li >> 1) & 7;
+  int fo[4];
+#pragma unroll
+  for (int t8 = 0; t8 < 4; ++t8) fo[t8] = ((2 * t8 + h) ^ sw) << 2;
+  const float* Wtl = Wts + (li << 5);
+
+  for (int t = blockIdx.x; t < p.tiles; t += gridDim.x) {
+    const int p0 = (t * NW + wave) * 32;
+    if (p0 >= p.M) continue;            // wave-uniform; no barrier below
+    const unsigned pix = (unsigned)(p0 + li);
+    f32x4 dq[2][4], dqn[2][4], xh[2][4], da[2][4];
+    auto load_dq = [&](int kp, f32x4 (&dst)[2][4]) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int t8 = 0; t8 < 4; ++t8) dst[b][t8] = ld4(dyr, (pix * (unsigned)CO_ + (unsigned)((2 * kp + b) * 32 + 8 * t8 + 4 * h)) * 4u);
+    };
+    load_dq(0, dq);
+    {
+      const unsigned xo = (pix * (unsigned)p.ldx + 4u * h) * 4u, ao = (pix * (unsigned)p.ldadd + 4u * h) * 4u;
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          xh[ib][q] = ld4(xr, xo + (unsigned)(ib * 32 + 8 * q) * 4u);
+          if (p.dadd) da[ib][q] = ld4(ar, ao + (unsigned)(ib * 32 + 8 * q) * 4u);
+          else da[ib][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    f32x16 dxacc[2];
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dxacc[ib][r] = 0.f;
+#pragma unroll
+    for (int kp = 0; kp < NB / 2; ++kp) {   // dx = W^T dy: K-tiles in order, the two input-channel blocks alternate
+      if (kp + 1 < NB / 2) load_dq(kp + 1, dqn);
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int t8 = 0; t8 < 4; ++t8) {
+          f32x4 a[2];
+#pragma unroll
+          for (int ib = 0; ib < 2; ++ib) a[ib] = *reinterpret_cast<const f32x4*>(Wtl + (((2 * kp + b) * CI + ib * 32) << 5) + fo[t8]);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) dxacc[ib] = MFMA(a[ib][s], dq[b][t8][s], dxacc[ib]);
+        }
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int t8 = 0; t8 < 4; ++t8) dq[b][t8] = dqn[b][t8];
+    }
+    ln_bwd_epilogue<false>(dxacc, xh, da, lns, scratch, wacc, dxr, pix, (unsigned)p.lddx, lane, h);
+  }
+  __syncthreads();   // (every wave leaves the tile loop after the same number of rounds)
+  ln_ws_row<NW>(lns + 2 * CI + NW * 512, p.ln_ws, tid);
 }
 
 }  // namespace
@@ -714,3 +902,53 @@ static int mlp_dispatch(const clc_mlp_desc* d, bool bwd, clc_stream_t stream, co
 extern "C" int clc_mlp_blocks(long M) { return M > 0 ? mlp_grid(M, mlp_waves(M)) : 0; }
 extern "C" int clc_mlp_fwd(const clc_mlp_desc* d, clc_stream_t stream) { return mlp_dispatch(d, false, stream, "clc_mlp_fwd"); }
 extern "C" int clc_mlp_bwd(const clc_mlp_desc* d, clc_stream_t stream) { return mlp_dispatch(d, true, stream, "clc_mlp_bwd"); }
+
+// ---- LayerNorm + Linear(64 -> 192)
+static int lnlin_dispatch(const clc_lnlin_desc* d, bool bwd, clc_stream_t stream, const char* who) {
+  CLC_CHECK(d && d->x && d->ln_gamma && d->ln_beta, "%s: null pointer", who);
+  CLC_CHECK(d->Cin == CI && d->Cout == 192, "%s: built for LayerNorm(64) + Linear(64 -> 192) (got %d -> %d)", who, d->Cin, d->Cout);
+  CLC_CHECK(d->M > 0 && d->M % 32 == 0 && d->M < (1L << 24), "%s: the pixel count must be a positive multiple of 32 (got %ld)", who, d->M);
+  auto ok = [](const void* ptr, int ld, int c) { return ptr == nullptr || (aligned16(ptr) && ld % 4 == 0 && ld >= c); };
+  auto bytes = [](long M, int ld, int c) { return ((size_t)(M - 1) * ld + c) * 4; };
+  CLC_CHECK(ok(d->x, d->ldx, CI) && aligned16(d->ln_gamma) && aligned16(d->ln_beta), "%s: operands must be 16-B aligned with leading dimensions that are multiples of 4", who);
+  CLC_CHECK(bytes(d->M, d->ldx, CI) < (1ull << 31) && bytes(d->M, 192, 192) < (1ull << 31), "%s: tensor larger than 2 GiB", who);
+  LnLinParams p;
+  p.x = d->x; p.ldx = d->ldx; p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.M = (int)d->M;
+  p.x_bytes = (unsigned)bytes(d->M, d->ldx, CI); p.y_bytes = (unsigned)bytes(d->M, 192, 192);
+  p.w = nullptr; p.b = nullptr; p.y = nullptr; p.ln_out = nullptr; p.dy = nullptr; p.wt = nullptr; p.dx = nullptr; p.dadd = nullptr; p.ln_ws = nullptr;
+  p.lddx = p.ldadd = 0; p.dx_bytes = p.add_bytes = 0;
+  if (!bwd) {
+    CLC_CHECK(d->w && d->y && aligned16(d->w) && aligned16(d->y) && (!d->ln_out || aligned16(d->ln_out)), "%s: w / y missing or unaligned", who);
+    p.w = d->w; p.b = d->b; p.y = d->y; p.ln_out = d->ln_out;
+  } else {
+    CLC_CHECK(d->dy && d->wt && d->dx && d->ln_ws && aligned16(d->dy) && aligned16(d->wt) && aligned16(d->ln_ws), "%s: dy / wt / dx / ln_ws missing or unaligned", who);
+    CLC_CHECK(ok(d->dx, d->lddx, CI) && ok(d->dadd, d->ldadd, CI), "%s: dx / dadd unaligned", who);
+    CLC_CHECK(bytes(d->M, d->lddx, CI) < (1ull << 31) && (!d->dadd || bytes(d->M, d->ldadd, CI) < (1ull << 31)), "%s: tensor larger than 2 GiB", who);
+    p.dy = d->dy; p.wt = d->wt; p.dx = d->dx; p.lddx = d->lddx; p.dx_bytes = (unsigned)bytes(d->M, d->lddx, CI);
+    p.dadd = d->dadd; p.ldadd = d->ldadd; p.add_bytes = d->dadd ? (unsigned)bytes(d->M, d->ldadd, CI) : 0;
+    p.ln_ws = d->ln_ws;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  auto go = [&](auto nw_tag) {
+    constexpr int NW = decltype(nw_tag)::value;
+    p.tiles = (p.M + 32 * NW - 1) / (32 * NW);
+    const int grid = mlp_grid(p.M, NW);
+    const size_t lds_f = (size_t)(2 * 192 * 32 + 192 + 2 * CI + NW * 512) * sizeof(float), lds_b = (size_t)(6 * CI * 32 + 2 * CI + NW * 512 + NW * 256) * sizeof(float);
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lnlin_fwd_kernel<NW, 192>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lnlin_bwd_kernel<NW, 192>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+    }
+    if (bwd) hipLaunchKernelGGL((lnlin_bwd_kernel<NW, 192>), dim3(grid), dim3(64 * NW), lds_b, st, p);
+    else hipLaunchKernelGGL((lnlin_fwd_kernel<NW, 192>), dim3(grid), dim3(64 * NW), lds_f, st, p);
+  };
+  switch (mlp_waves(d->M)) {
+    case 8: go(std::integral_constant<int, 8>{}); break;
+    case 4: go(std::integral_constant<int, 4>{}); break;
+    default: go(std::integral_constant<int, 2>{}); break;
+  }
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int clc_lnlin_fwd(const clc_lnlin_desc* d, clc_stream_t stream) { return lnlin_dispatch(d, false, stream, "clc_lnlin_fwd"); }
+extern "C" int clc_lnlin_bwd(const clc_lnlin_desc* d, clc_stream_t stream) { return lnlin_dispatch(d, true, stream, "clc_lnlin_bwd"); }

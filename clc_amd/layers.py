@@ -302,11 +302,14 @@ class WMSA(nn.Module):
             torch.nn.init.trunc_normal_(torch.zeros(self.n_heads, 2 * window_size - 1, 2 * window_size - 1), std=0.02))
         self.linear = Linear(input_dim, output_dim)
 
+    def attend(self, qkv, res=None, fold_out=None):
+        """everything after the embedding (the caller computed qkv, e.g. fused with the LayerNorm in front)"""
+        a = ops.window_attention(qkv, self.relative_position_params, self.n_heads, self.window_size, self.type != "W")
+        return self.linear(a, res=res, fold_out=fold_out)
+
     def forward(self, x, res=None, pair=None, fold_out=None):
         if pair is None:
-            qkv = self.embedding_layer(x)
-            a = ops.window_attention(qkv, self.relative_position_params, self.n_heads, self.window_size, self.type != "W")
-            return self.linear(a, res=res, fold_out=fold_out)
+            return self.attend(self.embedding_layer(x), res=res, fold_out=fold_out)
         qkv = self.embedding_layer(x, pair=pair.embedding_layer)
         a = ops.window_attention(qkv, self.relative_position_params, self.n_heads, self.window_size, self.type != "W",
                                  relbias2=pair.relative_position_params)   # one launch, per-half relative-position tables
@@ -337,7 +340,14 @@ class Block(nn.Module):
         if pair is None:
             # x + f(LN(x)) twice: the residual gradients are added inside the LayerNorm backward passes
             f1 = ops.GradFold() if x.requires_grad else None
-            x = self.msa(self.ln1(x, fold_in=f1, grad_slot=grad_slot), res=x, fold_out=f1)
+            emb = self.msa.embedding_layer
+            if ops.lnlin_fusable(x, emb.weight):
+                # large maps: ln1 + the qkv embedding in ONE launch; backward: the embedding's data gradient + ln1's backward pass + the
+                # residual gradient in one more (csrc/fused_mlp.hip) — same bits as the separate launches
+                qkv = ops.ln_linear(x, self.ln1.weight, self.ln1.bias, emb.weight, emb.bias, fold_in=f1, grad_slot=grad_slot)
+                x = self.msa.attend(qkv, res=x, fold_out=f1)
+            else:
+                x = self.msa(self.ln1(x, fold_in=f1, grad_slot=grad_slot), res=x, fold_out=f1)
             if ops.mlp_ln_fusable(x, self.mlp[0].weight, self.mlp[2].weight):
                 # ... and ln2 with them: LN in registers forward, its whole backward pass in the data-gradient launch's epilogue
                 return ops.mlp_ln(x, self.ln2.weight, self.ln2.bias, self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias, out=out)

@@ -60,6 +60,12 @@ class MlpDesc(C.Structure):
                 ("ln_gamma", fp), ("ln_beta", fp), ("ln_out", fp), ("ln_ws", fp)]
 
 
+class LnLinDesc(C.Structure):
+    _fields_ = [("x", fp), ("ldx", C.c_int), ("ln_gamma", fp), ("ln_beta", fp), ("w", fp), ("b", fp), ("y", fp), ("ln_out", fp),
+                ("M", C.c_long), ("Cin", C.c_int), ("Cout", C.c_int), ("dy", fp), ("wt", fp), ("dx", fp), ("lddx", C.c_int),
+                ("dadd", fp), ("ldadd", C.c_int), ("ln_ws", fp)]
+
+
 class GDNEntry(C.Structure):
     _fields_ = [("gamma", fp), ("beta", fp), ("gamma_eff", fp), ("gamma_eff_t", fp), ("beta_eff", fp), ("C", C.c_int), ("first_block", C.c_int),
                 ("gamma_bound", C.c_float), ("beta_bound", C.c_float), ("pedestal", C.c_float)]
@@ -161,6 +167,8 @@ SIGNATURES = {
     "clc_mlp_fwd": (_i, [C.POINTER(MlpDesc), fp]),
     "clc_mlp_bwd": (_i, [C.POINTER(MlpDesc), fp]),
     "clc_mlp_blocks": (_i, [_l]),
+    "clc_lnlin_fwd": (_i, [C.POINTER(LnLinDesc), fp]),
+    "clc_lnlin_bwd": (_i, [C.POINTER(LnLinDesc), fp]),
     "clc_maxpool2d": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, fp]),
     "clc_adaptive_pool2d": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, _i, fp]),
     "clc_optim_chunk_elems": (_i, []),

@@ -1196,6 +1196,94 @@ def mlp_ln(x, ln_g, ln_b, w1, b1, w2, b2, *, out=None):
     return _MlpFn.apply(x, w1, b1, w2, b2, None, None, out, ln_g, ln_b)
 
 
+# ------------------------------------------------------------------ LayerNorm + Linear: ln1 and the attention's embedding (csrc/fused_mlp.hip)
+
+FUSED_LNLIN = int(os.environ.get("CLC_FUSED_LNLIN", "1"))   # 0: clc_layernorm_fwd + a 1x1 clc_conv2d launch (A/B knob; same bits)
+
+
+def lnlin_fusable(x, w, pair=None) -> bool:
+    """nn.LayerNorm(64) + nn.Linear(64 -> 192) on a map with enough pixels for the persistent kernels (as mlp_fusable)."""
+    if not FUSED_LNLIN or pair is not None or x.dim() != 4 or x.shape[1] != 64 or tuple(w.shape) != (192, 64):
+        return False
+    M = x.shape[0] * x.shape[2] * x.shape[3]
+    return M >= FUSED_MLP_MIN_PIX and M % 32 == 0 and M < (1 << 24)
+
+
+class _LnLinearFn(Function):
+    """w . LN(x) + b in ONE launch; backward: the Linear's data gradient, the LayerNorm's backward pass and the block's residual gradient
+    (fold_in) in one more, written into `grad_slot` like _LayerNormFn; the filter gradient stays a grouped, deferred problem on the LN(x)
+    the forward launch stored."""
+
+    @staticmethod
+    def forward(ctx, x, ln_g, ln_b, w, b, fold_in, grad_slot):
+        _own(ctx)
+        _require_gpu(x, "ln_linear")
+        x, xp, N, H, W, Cc, ldx = nhwc(x)
+        y = new_act(N, w.shape[0], H, W, x)
+        ln_out = new_act(N, Cc, H, W, x) if _recording(ctx) else None
+        d = _lib.LnLinDesc()
+        d.x, d.ldx, d.ln_gamma, d.ln_beta, d.w = xp, ldx, ln_g.data_ptr(), ln_b.data_ptr(), w.data_ptr()
+        d.b = b.data_ptr() if b is not None else None
+        d.y, d.ln_out = y.data_ptr(), (ln_out.data_ptr() if ln_out is not None else None)
+        d.M, d.Cin, d.Cout = N * H * W, Cc, w.shape[0]
+        _prof_hint(2.0 * N * H * W * Cc * w.shape[0], f"ln+linear fwd {Cc}->{w.shape[0]} {N}x{H}x{W}")
+        _lib.check(_L().clc_lnlin_fwd(C.byref(d), _stream()), "clc_lnlin_fwd")
+        ctx.fold_in, ctx.grad_slot, ctx.has_b = fold_in, grad_slot, b is not None
+        ctx.save_for_backward(x, ln_g, ln_b, w, b, ln_out)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        _reown(ctx)
+        x, ln_g, ln_b, w, b, ln_out = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        x, xp, N, H, W, Cc, ldx = nhwc(x)
+        dy, dyp, *_r, lddy = nhwc(dy)
+        if lddy != dy.shape[1]:
+            dy = dy.contiguous(memory_format=CL)
+            dyp = dy.data_ptr()
+        gs = ctx.grad_slot
+        dx = gs[0].view(x, gs[1], gs[2], Cc) if gs is not None else new_act(N, Cc, H, W, x)
+        extra, extra_scale, gate = ctx.fold_in.take() if ctx.fold_in is not None else (None, 1.0, None)
+        assert gate is None, "gated residual gradients are folded by conv data-gradient kernels only"
+        ep, lde = None, 0
+        if extra is not None:
+            if extra_scale != 1.0:
+                extra = extra * extra_scale
+            extra, ep, *_q, lde = nhwc(extra)
+        M = N * H * W
+        nb = _L().clc_mlp_blocks(M)
+        ws = torch.empty(nb * 2 * Cc, device=x.device, dtype=torch.float32)
+        d = _lib.LnLinDesc()
+        d.x, d.ldx, d.ln_gamma, d.ln_beta = xp, ldx, ln_g.data_ptr(), ln_b.data_ptr()
+        d.M, d.Cin, d.Cout = M, Cc, w.shape[0]
+        d.dy, d.wt, d.dx, d.lddx, d.dadd, d.ldadd, d.ln_ws = dyp, _wt_of(w).data_ptr(), dx.data_ptr(), nhwc(dx)[6], ep, lde, ws.data_ptr()
+        _prof_hint(2.0 * M * Cc * w.shape[0], f"ln+linear dgrad {w.shape[0]}->{Cc} {N}x{H}x{W}")
+        _lib.check(_L().clc_lnlin_bwd(C.byref(d), _stream()), "clc_lnlin_bwd")
+        dlg = dlb = None
+        gd, bd = _direct_grad(ln_g), _direct_grad(ln_b)
+        direct = gd is not None and bd is not None
+        if direct and DEFER_REDUCTIONS:
+            defer_reduce(ws, nb, 2 * Cc, gd, bd, Cc)
+        else:
+            tot = ws.view(nb, 2, Cc).sum(0)
+            if direct:
+                gd.add_(tot[0])
+                bd.add_(tot[1])
+            else:
+                dlg, dlb = tot[0], tot[1]
+        dw = db = None
+        if need[3] or (ctx.has_b and need[4]):
+            dw, db = _ConvFn._wgrad(ln_out, dy, w, b, ctx.has_b, need[3], ctx.has_b and need[4], 1, 1, 0, {})
+        return (dx if need[0] else None), dlg, dlb, dw, db, None, None
+
+
+def ln_linear(x, ln_g, ln_b, w, b, *, fold_in=None, grad_slot=None):
+    """linear(LN(x)) of a Swin block's attention branch from the block's raw input (see lnlin_fusable)."""
+    _note_grad_mode()
+    return _LnLinearFn.apply(x, ln_g, ln_b, w, b, fold_in, grad_slot)
+
+
 def linear(x, w, b=None, *, act=ACT_NONE, res=None, w2=None, b2=None, fold_in=None, fold_out=None, out=None, gate_in=None, gate_out=None):
     """nn.Linear on channels (tokens are pixels): x [N,Cin,H,W] pixel-major, w [Cout,Cin]."""
     _note_grad_mode()

@@ -483,7 +483,30 @@ typedef struct {
 } clc_mlp_desc;
 int clc_mlp_fwd(const clc_mlp_desc* d, clc_stream_t stream);
 int clc_mlp_bwd(const clc_mlp_desc* d, clc_stream_t stream);
-int clc_mlp_blocks(long M);   /* workgroups (= partial rows in ln_ws) of a clc_mlp_bwd launch over M pixels */
+int clc_mlp_blocks(long M);   /* workgroups (= partial rows in ln_ws) of a clc_mlp_bwd / clc_lnlin_bwd launch over M pixels */
+
+/* ---- LayerNorm + Linear: ln1 and the window attention's embedding, round 4 ----
+ * `self.embedding_layer(self.ln1(x))` of Block / WMSA (/root/reference/models/CLC_run.py:120, 141, 180, 191; nn.LayerNorm(64), nn.Linear(64, 192)):
+ *   clc_lnlin_fwd   y [M][192] dense = W . LN(x) + b, x [M][64] (ldx: may be a channel range of a wider buffer); writes LN(x) to ln_out [M][64]
+ *                   dense when non-NULL (training: the x operand of the Linear's filter gradient, which stays clc_conv2d_wgrad*).
+ *   clc_lnlin_bwd   dx [M][64] (lddx) = LayerNorm gradient of (W^T dy) + dadd (the block's residual gradient, ldadd; optional), from dy [M][192]
+ *                   dense, wt = clc_filter_transpose(w) ([64][192]) and the raw x; clc_mlp_blocks(M) partial rows [2][64] (dgamma, dbeta) in ln_ws
+ *                   for clc_partial_reduce_batched.
+ * y and dx carry the bits of clc_layernorm_fwd + clc_conv2d (1x1) / clc_conv2d (transposed) + clc_layernorm_bwd.  M a multiple of 32. */
+typedef struct {
+  const float* x; int ldx;
+  const float* ln_gamma; const float* ln_beta;
+  const float* w; const float* b;
+  float* y; float* ln_out;
+  long M; int Cin, Cout;                /* 64, 192 */
+  /* clc_lnlin_bwd only */
+  const float* dy; const float* wt;
+  float* dx; int lddx;
+  const float* dadd; int ldadd;
+  float* ln_ws;
+} clc_lnlin_desc;
+int clc_lnlin_fwd(const clc_lnlin_desc* d, clc_stream_t stream);
+int clc_lnlin_bwd(const clc_lnlin_desc* d, clc_stream_t stream);
 
 /* ---- reference-retrieval feature extractor: the pooling layers of torchvision's ResNet50 as the reference uses it ----
  * clc_maxpool2d        nn.MaxPool2d(ks, stride, pad) of resnet50.maxpool (/root/reference/dataloader_ref_cluster.py:41-44, dataloader_CLC.py:275),

@@ -974,6 +974,54 @@ def test_fused_mlp_with_layernorm_same_bits_as_separate_launches(dev, N, H, W, s
     _close(pf[5], lb.grad, 1e-4, "ln.bias gradient vs torch")
 
 
+@pytest.mark.parametrize("N,H,W,typ,strided", [(8, 64, 64, "W", True), (2, 128, 128, "SW", True), (8, 128, 128, "W", False), (1, 64, 96, "SW", False)])
+def test_swin_block_fused_launches_same_bits_as_separate(dev, N, H, W, typ, strided):
+    """A whole Swin Block (/root/reference/models/CLC_run.py:172-193) on a large map with its fused launches — ln1 + qkv embedding
+    (clc_lnlin_fwd / _bwd: LayerNorm, Linear(64 -> 192); backward: the embedding's data gradient, ln1's backward pass and the residual
+    gradient) and ln2 + MLP (clc_mlp_*) — against the same Block on separate LayerNorm / 1x1 launches: THE SAME BITS for the output, the input
+    gradient and every filter / bias / relative-position gradient; the LayerNorm parameter gradients (another summation order over the pixels)
+    to fp32 accuracy.  Input and output as channel ranges of wider buffers (ConvTransBlock's layout)."""
+    from clc_amd import layers, ops
+
+    torch.manual_seed(5)
+    blk = layers.Block(64, 64, 8, 8, 0.0, typ).to(dev)
+    with torch.no_grad():
+        for prm in blk.parameters():
+            if prm.dim() == 1:
+                prm.add_(torch.randn_like(prm) * 0.2)
+    wide_x = (torch.randn(N, 128, H, W, device=dev) * 1.3).contiguous(memory_format=CL)
+    x0 = wide_x[:, 64:] if strided else wide_x[:, :64].contiguous(memory_format=CL)
+    gy = torch.randn(N, 64, H, W, device=dev).contiguous(memory_format=CL)
+    names = [n for n, _ in blk.named_parameters()]
+    old = (ops.FUSED_MLP_MIN_PIX, ops.FUSED_LNLIN, ops.FUSED_MLP_LN, ops.FUSED_MLP)
+    ops.FUSED_MLP_MIN_PIX = 1024
+    res = {}
+    try:
+        for mode in ("fused", "separate"):
+            ops.FUSED_LNLIN = ops.FUSED_MLP_LN = ops.FUSED_MLP = 1 if mode == "fused" else 0
+            if mode == "fused":
+                assert ops.lnlin_fusable(x0, blk.msa.embedding_layer.weight)
+            for prm in blk.parameters():
+                prm.grad = None
+            x = x0.detach().clone().requires_grad_(True) if not strided else wide_x.detach().clone().requires_grad_(True)
+            xin = x[:, 64:] if strided else x
+            out = ops.new_act(N, 128, H, W, x0)[:, 64:] if strided else None
+            y = blk(xin, out=out)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            res[mode] = (y.detach().clone(), x.grad.clone(), [prm.grad.clone() for prm in blk.parameters()])
+    finally:
+        ops.FUSED_MLP_MIN_PIX, ops.FUSED_LNLIN, ops.FUSED_MLP_LN, ops.FUSED_MLP = old
+    (yf, dxf, pf), (yc, dxc, pc) = res["fused"], res["separate"]
+    assert torch.equal(yf, yc), f"block output differs: max {(yf - yc).abs().max().item():.3e}"
+    assert torch.equal(dxf, dxc), f"input gradient differs: max {(dxf - dxc).abs().max().item():.3e}"
+    for a, b, name in zip(pf, pc, names):
+        if name.startswith("ln"):
+            _close(a, b, 2e-5, f"{name} gradient vs the LayerNorm kernel")
+        else:
+            assert torch.equal(a, b), f"{name} gradient differs: max {(a - b).abs().max().item():.3e}"
+
+
 @pytest.mark.parametrize("N,Cin,H,W,Cout,shuffle", [(2, 128, 64, 64, 12, True), (1, 128, 40, 72, 12, True), (2, 64, 64, 48, 16, False), (3, 256, 48, 48, 12, True)])
 def test_16_column_kernel_for_the_few_channel_tail(dev, N, Cin, H, W, Cout, shuffle):
     """conv_igemm_n16_kernel (v_mfma_f32_16x16x4_f32, 256 x 16 tiles; tuning key 20): the synthesis transform's subpel tail, 128 -> 12 with the
