@@ -1765,6 +1765,13 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   // 128->128 61 -> 103 us, 64->256 + stored derivative 82 -> 177, 64->192 47 -> 92.  Every access of that layout touches 32 B of a 128-B
   // line (1.5-2 TB/s where the row pieces of epilogue_regs / LDS-DMA reach 3.3-4.2).  Removed; the structure pays only where two GEMMs
   // are chained through the registers: csrc/fused_mlp.hip.)
+  // (... and with whole-line stores it does pay on the plain layers too: lin_kernel, fused_mlp.hip — the 128 -> 128 / 64 -> 64 layers with a
+  //  bias / residual epilogue, forward and data gradient alike: a 1x1 data gradient is the same launch on the transposed filter)
+  if (clc_tuning[CLC_TUNE_LIN] && d->ks == 1 && d->stride == 1 && classes == 1 && vec_ok && !p.shuffle && !p.group_rows && !p.xs && p.in_op == CLC_IN_NONE &&
+      p.act == CLC_ACT_NONE && p.norm == CLC_NORM_NONE && !p.y_pre && !p.res_gate && !p.out_gate && p.ldw == p.Cin && p.vec_epi && !p.bf16) {
+    const int v = clc_lin_launch(p.x, p.ldx, p.w, p.bias, p.res, p.ldr, p.res_scale, p.y, p.ldy, p.M, p.Cin, p.Cout, st);
+    if (v) { CLC_LAUNCH_CHECK(); return v; }
+  }
   if (d->ks == 1 && C > 32 && vec_ok) {   // persistent pipelined kernel (CLC_TUNE_P1X1), where the layer qualifies
     const int v = launch_p1x1(p, classes, st);
     if (v) return v;

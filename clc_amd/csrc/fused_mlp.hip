@@ -790,6 +790,105 @@ __global__ __launch_bounds__(64 * NW, 2) void lnlin_bwd_kernel(const LnLinParams
   ln_ws_row<NW>(lns + 2 * CI + NW * 512, p.ln_ws, tid);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------- plain Linear / 1x1
+// y = W x + b (+ res_scale * res) for the 128 -> 128 and 64 -> 64 1x1 layers of the ConvTransBlocks on large maps (conv1_1 / conv1_2 and the
+// attention's output projection, forward and data gradient: /root/reference/models/CLC_run.py:205-206, 121; the data gradient is the same
+// launch on the transposed filter), in the wave-private structure of the kernels above.  Round 4's first attempt at this (conv_w1x1_kernel,
+// see conv_igemm.hip) stored 16-B quads straight from the accumulator layout and was 1.2-2.1x slower than the tiled kernels; with
+// whole-line stores (store_block_lines) the same structure moves 3.7-3.9 TB/s (the LayerNorm + Linear launches above).
+// Same K order and epilogue expression as the tiled kernels -> the same bits: clc_conv2d may pick either by the row count.
+struct LinParams {
+  const float* x; const float* w; const float* b; const float* res; float* y;
+  int ldx, ldr, ldy;
+  float res_scale;
+  int M, tiles;
+  unsigned x_bytes, res_bytes, y_bytes;
+};
+
+template <int NW, int KT, int NB>   // Cin = 32 KT, Cout = 32 NB
+__global__ __launch_bounds__(64 * NW, 2) void lin_kernel(const LinParams p) {
+  static_assert(NB % 2 == 0, "output blocks are computed in pairs");
+  constexpr int CO_ = 32 * NB;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;                       // [KT][CO_][32]
+  float* bs = Ws + KT * CO_ * 32;         // [CO_]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+  float* scratch = bs + CO_ + wave * 512;
+  fill_image<NW>(Ws, p.w, CO_, 32 * KT, wave, lane);
+  for (int i = tid; i < CO_; i += 64 * NW) bs[i] = p.b ? p.b[i] : 0.f;
+  const __amdgpu_buffer_rsrc_t xr = srd(p.x, p.x_bytes), yr = srd(p.y, p.y_bytes), rr = srd(p.res ? p.res : p.x, p.res ? p.res_bytes : p.x_bytes);
+  const int sw = (li >> 1) & 7;
+  int fo[4];
+#pragma unroll
+  for (int t8 = 0; t8 < 4; ++t8) fo[t8] = ((2 * t8 + h) ^ sw) << 2;
+  const float* Wl = Ws + (li << 5);
+  auto load_x = [&](int t, f32x4 (&xf)[KT][4]) {   // a tile past the end reads zeros through the SRD's range check
+    const int p0 = (t * NW + wave) * 32;
+    const unsigned xo = ((unsigned)(p0 + li) * (unsigned)p.ldx + 4u * h) * 4u;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int t8 = 0; t8 < 4; ++t8) xf[kt][t8] = ld4(xr, p0 < p.M ? xo + (unsigned)(kt * 32 + 8 * t8) * 4u : kOOB);
+  };
+  f32x4 xf[KT][4], xn[KT][4];
+  load_x(blockIdx.x, xn);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = blockIdx.x; t < p.tiles; t += gridDim.x) {
+    const int p0 = (t * NW + wave) * 32;
+    const unsigned pix = (unsigned)(p0 + li);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int t8 = 0; t8 < 4; ++t8) xf[kt][t8] = xn[kt][t8];
+    load_x(t + gridDim.x, xn);
+    if (p0 >= p.M) continue;            // wave-uniform; no barrier below
+#pragma unroll 1
+    for (int op = 0; op < NB / 2; ++op) {
+      f32x4 rv[2][4];
+      if (p.res) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) rv[b][q] = ld4(rr, (pix * (unsigned)p.ldr + (unsigned)((2 * op + b) * 32 + 8 * q + 4 * h)) * 4u);
+      }
+      f32x16 acc[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+      const float* wb = Wl + ((op * 64) << 5);
+#pragma unroll
+      for (int j = 0; j < 4 * KT; ++j) {   // K-steps (kt, t8) in the tiled kernels' order
+        f32x4 a[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) a[b] = *reinterpret_cast<const f32x4*>(wb + (((j >> 2) * CO_ + b * 32) << 5) + fo[j & 3]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[b] = MFMA(a[b][s], xf[j >> 2][j & 3][s], acc[b]);
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        f32x4 vq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 bq = *reinterpret_cast<const f32x4*>(bs + (2 * op + b) * 32 + 8 * q + 4 * h);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) vq[q][s] = acc[b][4 * q + s] + bq[s];
+          if (p.res) {
+            const f32x4 sc = p.res_scale * rv[b][q];
+            vq[q] = vq[q] + sc;
+          }
+        }
+        store_block_lines(scratch, vq, yr, (unsigned)p0, (unsigned)p.ldy, (unsigned)((2 * op + b) * 32), lane, li, h);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 static int mlp_fill(const clc_mlp_desc* d, MlpParams& p, bool bwd, const char* who) {
@@ -952,3 +1051,30 @@ static int lnlin_dispatch(const clc_lnlin_desc* d, bool bwd, clc_stream_t stream
 }
 extern "C" int clc_lnlin_fwd(const clc_lnlin_desc* d, clc_stream_t stream) { return lnlin_dispatch(d, false, stream, "clc_lnlin_fwd"); }
 extern "C" int clc_lnlin_bwd(const clc_lnlin_desc* d, clc_stream_t stream) { return lnlin_dispatch(d, true, stream, "clc_lnlin_bwd"); }
+
+// ---- plain 1x1 layers on large maps: called by clc_conv2d (conv_igemm.hip) for the shapes it checked; returns 0 when the shape is not built
+template <int NW, int KT, int NB>
+static void lin_go(LinParams& p, hipStream_t st) {
+  p.tiles = (p.M + 32 * NW - 1) / (32 * NW);
+  const int grid = mlp_grid(p.M, NW);
+  const size_t lds = (size_t)(KT * NB * 32 * 32 + NB * 32 + NW * 512) * sizeof(float);
+  static PerDeviceOnce attr_once;
+  if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<NW, KT, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((lin_kernel<NW, KT, NB>), dim3(grid), dim3(64 * NW), lds, st, p);
+}
+int clc_lin_launch(const float* x, int ldx, const float* w, const float* bias, const float* res, int ldr, float res_scale, float* y, int ldy, long M, int Cin,
+                   int Cout, hipStream_t st) {
+  if (!((Cin == 128 && Cout == 128) || (Cin == 64 && Cout == 64)) || M % 32 || M < 32768 || M >= (1L << 24)) return 0;
+  auto bytes = [](long m, int ld, int c) { return ((size_t)(m - 1) * ld + c) * 4; };
+  if (bytes(M, ldx, Cin) >= (1ull << 31) || bytes(M, ldy, Cout) >= (1ull << 31) || (res && bytes(M, ldr, Cout) >= (1ull << 31))) return 0;
+  LinParams p;
+  p.x = x; p.w = w; p.b = bias; p.res = res; p.y = y; p.ldx = ldx; p.ldr = ldr; p.ldy = ldy; p.res_scale = res_scale; p.M = (int)M;
+  p.x_bytes = (unsigned)bytes(M, ldx, Cin); p.y_bytes = (unsigned)bytes(M, ldy, Cout); p.res_bytes = res ? (unsigned)bytes(M, ldr, Cout) : 0;
+  const int nw = mlp_waves(M);
+  if (Cin == 128) {
+    if (nw == 8) lin_go<8, 4, 4>(p, st); else lin_go<4, 4, 4>(p, st);
+  } else {
+    if (nw == 8) lin_go<8, 2, 2>(p, st); else lin_go<4, 2, 2>(p, st);
+  }
+  return (11 << 20) | (nw << 16) | (Cin >> 5 << 8) | (Cout >> 5);   // family 11 = lin_kernel<NW, KT, NB>
+}

@@ -1022,6 +1022,47 @@ def test_swin_block_fused_launches_same_bits_as_separate(dev, N, H, W, typ, stri
             assert torch.equal(a, b), f"{name} gradient differs: max {(a - b).abs().max().item():.3e}"
 
 
+@pytest.mark.parametrize("N,C,H,W,strided", [(8, 128, 64, 64, False), (2, 128, 128, 128, True), (8, 64, 64, 64, True), (2, 64, 128, 192, False), (8, 128, 128, 128, False)])
+def test_wave_private_1x1_same_bits_as_tiled(dev, N, C, H, W, strided):
+    """lin_kernel (csrc/fused_mlp.hip; tuning key 21): the 128 -> 128 / 64 -> 64 1x1 layers of the ConvTransBlocks (conv1_1, conv1_2, the
+    attention's projection: /root/reference/models/CLC_run.py:205-206, 121) on >= 32 768 rows, forward with bias + residual and the data
+    gradient with a folded residual gradient — THE SAME BITS as the tiled kernels it replaces (clc_conv2d may pick by the row count), and
+    plain torch fp32.  Source / destination as channel ranges of wider buffers."""
+    from clc_amd import layers, ops
+    from clc_amd import lib as _clib
+
+    L = _clib.load()
+    torch.manual_seed(C + H)
+    lin = layers.Linear(C, C).to(dev)
+    with torch.no_grad():
+        lin.bias.normal_(0, 0.3)
+    wide = (torch.randn(N, 2 * C, H, W, device=dev)).contiguous(memory_format=CL)
+    x0 = wide[:, C:] if strided else wide[:, :C].contiguous(memory_format=CL)
+    r0 = torch.randn(N, C, H, W, device=dev).contiguous(memory_format=CL)
+    gy = torch.randn(N, C, H, W, device=dev).contiguous(memory_format=CL)
+    res = {}
+    for key in (1, 0):
+        prev = L.clc_set_tuning(21, key)
+        try:
+            for prm in lin.parameters():
+                prm.grad = None
+            x, r = x0.detach().clone().requires_grad_(True), r0.clone().requires_grad_(True)
+            out = ops.new_act(N, 2 * C, H, W, x0)[:, C:] if strided else None
+            y = lin(x, res=r, out=out)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            res[key] = (y.detach().clone(), x.grad.clone(), r.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+        finally:
+            L.clc_set_tuning(21, prev)
+    for a, b, name in zip(res[1], res[0], ("y", "dx", "dres", "dW", "db")):
+        assert torch.equal(a, b), f"{name} differs from the tiled kernels: max {(a - b).abs().max().item():.3e}"
+    xt = x0.detach().clone().requires_grad_(True)
+    yt = F.conv2d(xt, lin.weight.detach()[:, :, None, None], lin.bias.detach()) + r0
+    yt.backward(gy)
+    _close(res[1][0], yt.detach(), 2e-5, "1x1 forward vs torch")
+    _close(res[1][1], xt.grad, 1e-4, "1x1 dx vs torch")
+
+
 @pytest.mark.parametrize("N,Cin,H,W,Cout,shuffle", [(2, 128, 64, 64, 12, True), (1, 128, 40, 72, 12, True), (2, 64, 64, 48, 16, False), (3, 256, 48, 48, 12, True)])
 def test_16_column_kernel_for_the_few_channel_tail(dev, N, Cin, H, W, Cout, shuffle):
     """conv_igemm_n16_kernel (v_mfma_f32_16x16x4_f32, 256 x 16 tiles; tuning key 20): the synthesis transform's subpel tail, 128 -> 12 with the
