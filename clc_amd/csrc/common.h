@@ -149,3 +149,71 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Building blocks of the WAVE-PRIVATE kernels (fused_mlp.hip: Swin MLP, LayerNorm + Linear, plain 1x1 layers; conv_igemm.hip: the 64-channel 3x3
+// layers): a wave owns 32 pixels and all channels, swapped MFMA roles (A = filter rows from a resident LDS image, B = pixels from registers),
+// whole-line stores through a 2 KB wave-private LDS scratch.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t srd(const float* ptr, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 ld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ void st4(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+}
+
+// Deposit a [rows][kcols] K-contiguous filter as a slot-swizzled [kcols / 32][rows][32] LDS image: the 16-B chunk c of row r of a
+// K-tile sits in slot c ^ ((r >> 1) & 7).  One LDS-DMA wave-instruction = 8 rows x 128 B; instructions are dealt round-robin to the waves.
+template <int NW>
+__device__ __forceinline__ void fill_image(float* img, const float* src, int rows, int kcols, int wave, int lane) {
+  const __amdgpu_buffer_rsrc_t sr = srd(src, (unsigned)rows * (unsigned)kcols * 4u);
+  const int per_kt = rows >> 3, n = (kcols >> 5) * per_kt;
+  for (int ii = wave; ii < n; ii += NW) {
+    const int kt = ii / per_kt, r0 = (ii - kt * per_kt) << 3;
+    const int row = r0 + (lane >> 3), chunk = (lane & 7) ^ ((row >> 1) & 7);
+    const unsigned off = ((unsigned)row * (unsigned)kcols + (unsigned)(kt * 32 + chunk * 4)) * 4u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(sr, (__attribute__((address_space(3))) void*)(img + ((kt * rows + r0) << 5)), 16, off, 0, 0, 0);
+#endif
+  }
+}
+
+
+// Store one 32-pixel x 32-channel block that a wave holds in the accumulator layout (lane (pixel li, half h): the 16-B quads q = 0..3 at
+// channels 8 q + 4 h) as FULL 128-B lines.  Stored straight from that layout every instruction would write 32-B pieces of 32 different
+// lines — measured on the plain 1x1 layers (conv_w1x1_kernel, built and removed in round 4): 1.7 TB/s where whole-line stores reach
+// 3.5-4 TB/s, and the 268 MB of dh / g per 8 x 128 x 128 block made the backward kernel store-bound.  So the block goes through a 2 KB
+// wave-private LDS scratch, 16 pixels at a time (chunk c of pixel p in slot c ^ (p & 7): conflict-free both ways), and comes back with
+// 8 lanes per pixel.  No barrier: one wave's LDS operations execute in program order.
+__device__ __forceinline__ void store_block_lines(float* scratch, const f32x4 (&v)[4], __amdgpu_buffer_rsrc_t dst, unsigned pix0, unsigned ld, unsigned ch0,
+                                                  int lane, int li, int h) {
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) {
+    if ((li >> 4) == rd) {
+      float* row = scratch + ((li & 15) << 5);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(row + ((((2 * q + h) ^ (li & 7))) << 2)) = v[q];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the other lanes' quads are in the scratch (and the compiler keeps the order)
+    f32x4 t[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int pl = 8 * k + (lane >> 3), j = lane & 7;
+      t[k] = *reinterpret_cast<const f32x4*>(scratch + (pl << 5) + ((j ^ (pl & 7)) << 2));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read out before the next round overwrites it
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int pl = 8 * k + (lane >> 3), j = lane & 7;
+      st4(t[k], dst, ((pix0 + (unsigned)(16 * rd + pl)) * ld + ch0 + (unsigned)(j * 4)) * 4u);
+    }
+  }
+}
+
+
+

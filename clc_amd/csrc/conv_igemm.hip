@@ -1784,6 +1784,11 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   // 64 x 32 block (two accumulators, 12 fragment reads and 6 DMA pieces per 32 MFMAs instead of 8 and 3 per 16): 98.1 -> 91.0 us on
   // 64 -> 64 @ 8x128x128, same bits (the K order of an output element does not depend on the tile, so the choice may look at M)
   // (filter sets: the set is chosen per workgroup, so a tile must not straddle two of them — fill_params guarantees multiples of 128 only)
+  // (Round 4 also built the wave-private structure of fused_mlp.hip for these layers — conv_wp3x3_kernel: the whole 64 x 64 x 9 filter (144 KB) resident
+  //  in LDS, a wave owns 32 pixels, the nine shifted source pixels loaded straight into registers three taps ahead, no barrier — bit-identical and
+  //  NOT faster: 96.7 vs 95.6 us at 8x128x128 (graph-replayed), step 27.15 vs 27.06 ms.  Ablated: 85.5 us without operand traffic, 47.6 without
+  //  MFMAs, 27.4 with neither — filter deposit + fragment reads + stores alone, amortised over only two tiles per wave (4096 tiles, 2048 waves);
+  //  the MFMA floor is 61 us.  Removed.)
   if (clc_tuning[CLC_TUNE_TILE256] && d->ks == 3 && C > 32 && C <= 64 && p.M >= 256 * 512 && (!p.group_rows || p.group_rows % 256 == 0))
     return launch<256, 64, 4, 2>(p, classes, st);
   if (C > 32) return launch<128, 64, 4, 2>(p, classes, st);
