@@ -865,8 +865,10 @@ void conv_igemm_dma2_kernel(const ConvParams p) {
     // training step, where operands come from HBM / Infinity Cache (between the MFMA groups measured -1.7 % in the step, round 2).
     // No block-uniform branch in this loop (round 4 removed the ablation / placement switches: every one of them split the K step
     // into separately scheduled pieces).
-    dma_a(buf ^ 1); dma_b(buf ^ 1);
-    read_frag(buf, 1, af[1], bf[1]);
+    __builtin_amdgcn_s_setprio(2);   // the wave that has just passed the barrier issues its share of the next tile FIRST, ahead of the other waves' MFMAs
+    dma_a(buf ^ 1); dma_b(buf ^ 1);   // (round 4, three interleaved builds on one box: 27.08 -> 26.92 ms per step; priority 3: 26.99; the window extended
+    __builtin_amdgcn_s_setprio(0);   //  over the first fragment read: 27.05; priority 1 around the MFMA groups instead: 27.24 vs 27.09; the same in the
+    read_frag(buf, 1, af[1], bf[1]);  //  filter-gradient kernels' K loops: no change)
     mfma_group(af[0], bf[0]);
     read_frag(buf, 2, af[0], bf[0]);
     mfma_group(af[1], bf[1]);
