@@ -828,6 +828,107 @@ __global__ __launch_bounds__(64 * NW, 2) void lin_kernel(const LinParams p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------- GDN / IGDN backward
+// The data gradient of a GDN layer on a large 128-channel map (CompressAI GDN: y = x * (beta + gamma . x^2)^-+1/2; g_a / g_s of
+// /root/reference/models/CLC_run.py:296-318, 337-353) as ONE launch.  Before: clc_gdn_bwd_elem (dy, x, v -> dx_direct, dv), then the 1x1 data-gradient
+// convolution dx = dx_direct + 2 x (gamma^T dv) — 603 MB per 8 x 128 x 128 layer.  In the wave-private structure the elementwise part is an
+// operand prologue and the epilogue reads the SAME registers (operand layout of K-tile ob, group q = accumulator layout of output block ob, quad q):
+// x, dx_direct and dv of the tile's pixels fill 192 registers, dv is the B operand, dx_direct never leaves the chip: 335 MB.  dv still goes to HBM
+// (whole lines): it is the dy operand of gamma's filter gradient.  Expressions of gdn_bwd_elem_kernel and of epilogue_math4 (norm = MUL2) -> the
+// same bits for dv and dx.
+struct GdnBwdParams {
+  const float* dy; const float* x; const float* v; const float* wt; float* dv; float* dx;
+  int M, tiles, inverse;
+  unsigned bytes;
+};
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void gdn_bwd_kernel(const GdnBwdParams p) {
+  constexpr int KT = 4, NB = 4, CC = 128;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;                       // [KT][CC][32]  gamma_eff^T: rows = input channels of the forward layer, K = its output channels
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+  float* scratch = Ws + KT * CC * 32 + wave * 512;
+  fill_image<NW>(Ws, p.wt, CC, CC, wave, lane);
+  const __amdgpu_buffer_rsrc_t xr = srd(p.x, p.bytes), gr = srd(p.dy, p.bytes), vr = srd(p.v, p.bytes), dvr = srd(p.dv, p.bytes), dxr = srd(p.dx, p.bytes);
+  const int sw = (li >> 1) & 7;
+  int fo[4];
+#pragma unroll
+  for (int t8 = 0; t8 < 4; ++t8) fo[t8] = ((2 * t8 + h) ^ sw) << 2;
+  const float* Wl = Ws + (li << 5);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = blockIdx.x; t < p.tiles; t += gridDim.x) {
+    const int p0 = (t * NW + wave) * 32;
+    if (p0 >= p.M) continue;            // wave-uniform; no barrier below
+    const unsigned base = ((unsigned)(p0 + li) * (unsigned)CC + 4u * h) * 4u;
+    f32x4 xf[KT][4], dd[KT][4], dv[KT][4];   // x, dx_direct (from dy), dv (from v)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int t8 = 0; t8 < 4; ++t8) {
+        const unsigned off = base + (unsigned)(kt * 32 + 8 * t8) * 4u;
+        xf[kt][t8] = ld4(xr, off);
+        dd[kt][t8] = ld4(gr, off);
+        dv[kt][t8] = ld4(vr, off);
+      }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+      for (int t8 = 0; t8 < 4; ++t8)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g = dd[kt][t8][e], xv = xf[kt][t8][e], vv = dv[kt][t8][e];
+          if (!p.inverse) {
+            const float rs = rsqrtf(vv);
+            dd[kt][t8][e] = g * rs;
+            dv[kt][t8][e] = g * xv * (-0.5f) * rs / vv;
+          } else {
+            const float sq = sqrtf(vv);
+            dd[kt][t8][e] = g * sq;
+            dv[kt][t8][e] = g * xv * 0.5f / sq;
+          }
+        }
+      store_block_lines(scratch, dv[kt], dvr, (unsigned)p0, (unsigned)CC, (unsigned)(kt * 32), lane, li, h);
+    }
+#pragma unroll
+    for (int op = 0; op < NB / 2; ++op) {   // (unrolled: xf / dd are indexed by op)
+      f32x16 acc[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+      const float* wb = Wl + ((op * 64) << 5);
+#pragma unroll
+      for (int j = 0; j < 4 * KT; ++j) {   // K-steps (kt, t8) in the tiled kernels' order
+        f32x4 a[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) a[b] = *reinterpret_cast<const f32x4*>(wb + (((j >> 2) * CC + b * 32) << 5) + fo[j & 3]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[b] = MFMA(a[b][s], dv[j >> 2][j & 3][s], acc[b]);
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        f32x4 vq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            float v = acc[b][4 * q + s] + 0.f;                          // (epilogue_math4: the absent bias is added as 0.f)
+            v = 2.f * (xf[op * 2 + b][q][s] * v);                        // norm = MUL2, mul = x
+            vq[q][s] = v + 1.0f * dd[op * 2 + b][q][s];                  // + res_scale * dx_direct
+          }
+        }
+        store_block_lines(scratch, vq, dxr, (unsigned)p0, (unsigned)CC, (unsigned)((2 * op + b) * 32), lane, li, h);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 static int mlp_fill(const clc_mlp_desc* d, MlpParams& p, bool bwd, const char* who) {
@@ -1016,4 +1117,26 @@ int clc_lin_launch(const float* x, int ldx, const float* w, const float* bias, c
     if (nw == 8) lin_go<8, 2, 2>(p, st); else lin_go<4, 2, 2>(p, st);
   }
   return (11 << 20) | (nw << 16) | (Cin >> 5 << 8) | (Cout >> 5);   // family 11 = lin_kernel<NW, KT, NB>
+}
+
+// ---- GDN / IGDN data gradient, 128 channels, large maps
+extern "C" int clc_gdn_bwd_fused(const float* dy, const float* x, const float* v, const float* gamma_eff_t, float* dv, float* dx, long M, int C, int inverse,
+                                 clc_stream_t stream) {
+  CLC_CHECK(dy && x && v && gamma_eff_t && dv && dx, "clc_gdn_bwd_fused: null pointer");
+  CLC_CHECK(C == 128 && M >= 32768 && M % 32 == 0 && (size_t)M * C * 4 < (1ull << 31), "clc_gdn_bwd_fused: built for 128 channels on >= 32 768 rows (a multiple of 32); got C=%d M=%ld", C, M);
+  CLC_CHECK(aligned16(dy) && aligned16(x) && aligned16(v) && aligned16(gamma_eff_t) && aligned16(dv) && aligned16(dx), "clc_gdn_bwd_fused: operands must be 16-B aligned");
+  GdnBwdParams p;
+  p.dy = dy; p.x = x; p.v = v; p.wt = gamma_eff_t; p.dv = dv; p.dx = dx; p.M = (int)M; p.inverse = inverse; p.bytes = (unsigned)((size_t)M * C * 4);
+  hipStream_t st = (hipStream_t)stream;
+  auto go = [&](auto nw_tag) {
+    constexpr int NW = decltype(nw_tag)::value;
+    p.tiles = (p.M + 32 * NW - 1) / (32 * NW);
+    const size_t lds = (size_t)(4 * 128 * 32 + NW * 512) * sizeof(float);
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gdn_bwd_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gdn_bwd_kernel<NW>), dim3(mlp_grid(p.M, NW)), dim3(64 * NW), lds, st, p);
+  };
+  if (mlp_waves(M) == 8) go(std::integral_constant<int, 8>{}); else go(std::integral_constant<int, 4>{});
+  CLC_LAUNCH_CHECK();
+  return 0;
 }

@@ -169,6 +169,7 @@ SIGNATURES = {
     "clc_mlp_blocks": (_i, [_l]),
     "clc_lnlin_fwd": (_i, [C.POINTER(LnLinDesc), fp]),
     "clc_lnlin_bwd": (_i, [C.POINTER(LnLinDesc), fp]),
+    "clc_gdn_bwd_fused": (_i, [fp, fp, fp, fp, fp, fp, _l, _i, _i, fp]),
     "clc_maxpool2d": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, fp]),
     "clc_adaptive_pool2d": (_i, [fp, _i, fp, _i, _i, _i, _i, _i, _i, fp]),
     "clc_optim_chunk_elems": (_i, []),

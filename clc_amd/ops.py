@@ -1198,6 +1198,7 @@ def mlp_ln(x, ln_g, ln_b, w1, b1, w2, b2, *, out=None):
 
 # ------------------------------------------------------------------ LayerNorm + Linear: ln1 and the attention's embedding (csrc/fused_mlp.hip)
 
+FUSED_GDN_BWD = int(os.environ.get("CLC_FUSED_GDN_BWD", "1"))   # 0: clc_gdn_bwd_elem + a transposed 1x1 clc_conv2d (A/B knob; same bits)
 FUSED_LNLIN = int(os.environ.get("CLC_FUSED_LNLIN", "1"))   # 0: clc_layernorm_fwd + a 1x1 clc_conv2d launch (A/B knob; same bits)
 
 
@@ -1713,10 +1714,18 @@ class _GDNParamFn(Function):
         N, Cc, H, W = x.shape
         dy, xx = dense(dy), dense(x)
         n = N * Cc * H * W
-        dxd, dv = new_act(N, Cc, H, W, x), new_act(N, Cc, H, W, x)
-        _lib.check(_L().clc_gdn_bwd_elem(dy.data_ptr(), xx.data_ptr(), v.data_ptr(), dxd.data_ptr(), dv.data_ptr(), n, int(inverse), _stream()), "clc_gdn_bwd_elem")
-        out_grads = [None, None] * 2
+        # large 128-channel maps: the elementwise part, the gamma^T product and the combination in ONE launch (csrc/fused_mlp.hip: gdn_bwd_kernel; same bits)
+        fused = FUSED_GDN_BWD and nset == 1 and Cc == 128 and N * H * W >= FUSED_MLP_MIN_PIX and (N * H * W) % 32 == 0 and n * 4 < (1 << 31)
         dx = None
+        if fused:
+            dv, dx = new_act(N, Cc, H, W, x), new_act(N, Cc, H, W, x)
+            _prof_hint(2.0 * N * H * W * Cc * Cc, f"gdn dgrad {Cc} {N}x{H}x{W}")
+            _lib.check(_L().clc_gdn_bwd_fused(dy.data_ptr(), xx.data_ptr(), v.data_ptr(), gts[0].data_ptr(), dv.data_ptr(), dx.data_ptr(), N * H * W, Cc,
+                                               int(inverse), _stream()), "clc_gdn_bwd_fused")
+        else:
+            dxd, dv = new_act(N, Cc, H, W, x), new_act(N, Cc, H, W, x)
+            _lib.check(_L().clc_gdn_bwd_elem(dy.data_ptr(), xx.data_ptr(), v.data_ptr(), dxd.data_ptr(), dv.data_ptr(), n, int(inverse), _stream()), "clc_gdn_bwd_elem")
+        out_grads = [None, None] * 2
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             hb = N // nset
             for k, ((gamma, beta), gm) in enumerate(zip(ctx.params, gms)):
@@ -1743,7 +1752,7 @@ class _GDNParamFn(Function):
                                                         gg.data_ptr(), gb.data_ptr(), int(direct), _stream()), "clc_gdn_reparam_bwd")
                     if not direct:
                         out_grads[2 * k], out_grads[2 * k + 1] = gg, gb
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and not fused:
             # dx = dx_direct + 2 x (gamma^T dv): the 2x factor and the add ride in the 1x1 data-gradient conv's epilogue
             dx = conv_raw(dv, gts[0], None, ks=1, transposed=True, out_hw=(H, W), norm=NORM_MUL2, mul=xx, res=dxd,
                           w2=(gts[1] if nset == 2 else None))

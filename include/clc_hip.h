@@ -508,6 +508,14 @@ typedef struct {
 int clc_lnlin_fwd(const clc_lnlin_desc* d, clc_stream_t stream);
 int clc_lnlin_bwd(const clc_lnlin_desc* d, clc_stream_t stream);
 
+/* ---- GDN / IGDN data gradient in one launch, round 4 ----
+ * CompressAI GDN (y = x * (beta + gamma . x^2)^-1/2, inverse: ^+1/2; g_a / g_s, /root/reference/models/CLC_run.py:296-318, 337-353) on a dense
+ * 128-channel map with >= 32 768 pixels: from dy, x and the saved norm v (clc_conv2d's y_pre) -> dv [M][128] = d(loss)/d(v) (the dy operand of
+ * gamma's filter gradient) and dx [M][128] = dy * v^-+1/2 + 2 x (gamma_eff^T dv).  Replaces clc_gdn_bwd_elem + the transposed 1x1 clc_conv2d with
+ * norm = CLC_NORM_MUL2 (their bits), without the dx_direct tensor.  gamma_eff_t = the [Cin][Cout] image clc_gdn_reparam_fwd writes. */
+int clc_gdn_bwd_fused(const float* dy, const float* x, const float* v, const float* gamma_eff_t, float* dv, float* dx, long M, int C, int inverse,
+                      clc_stream_t stream);
+
 /* ---- reference-retrieval feature extractor: the pooling layers of torchvision's ResNet50 as the reference uses it ----
  * clc_maxpool2d        nn.MaxPool2d(ks, stride, pad) of resnet50.maxpool (/root/reference/dataloader_ref_cluster.py:41-44, dataloader_CLC.py:275),
  *                      pixel-major in / out, C and the leading dimensions multiples of 4.

@@ -1063,6 +1063,49 @@ def test_wave_private_1x1_same_bits_as_tiled(dev, N, C, H, W, strided):
     _close(res[1][1], xt.grad, 1e-4, "1x1 dx vs torch")
 
 
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("N,H,W", [(8, 64, 64), (2, 128, 128), (3, 96, 128)])
+def test_gdn_backward_in_one_launch_same_bits(dev, N, H, W, inverse):
+    """clc_gdn_bwd_fused (csrc/fused_mlp.hip: gdn_bwd_kernel): the data gradient of a 128-channel GDN / IGDN on a large map — the elementwise part,
+    gamma^T dv and the combination in one launch, dx_direct never written — against clc_gdn_bwd_elem + the transposed 1x1 convolution with the
+    MUL2 epilogue: THE SAME BITS for dx and for the gamma / beta gradients (whose filter gradient reads the dv it stores); and torch autograd on
+    the CompressAI formula."""
+    from clc_amd import layers, ops
+
+    torch.manual_seed(17 + int(inverse))
+    gdn = layers.GDN(128, inverse=inverse).to(dev)
+    with torch.no_grad():
+        gdn.gamma.add_(torch.rand_like(gdn.gamma) * 0.02)
+        gdn.beta.add_(torch.rand_like(gdn.beta) * 0.3)
+    x0 = torch.randn(N, 128, H, W, device=dev).contiguous(memory_format=CL)
+    r0 = torch.randn(N, 128, H, W, device=dev).contiguous(memory_format=CL)
+    gy = torch.randn(N, 128, H, W, device=dev).contiguous(memory_format=CL)
+    res, old = {}, ops.FUSED_GDN_BWD
+    try:
+        for mode in (1, 0):
+            ops.FUSED_GDN_BWD = mode
+            gdn.gamma.grad = gdn.beta.grad = None
+            x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+            y = gdn(x, res=r)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            res[mode] = (y.detach().clone(), x.grad.clone(), r.grad.clone(), gdn.gamma.grad.clone(), gdn.beta.grad.clone())
+    finally:
+        ops.FUSED_GDN_BWD = old
+    for a, b, name in zip(res[1], res[0], ("y", "dx", "dres", "dgamma", "dbeta")):
+        assert torch.equal(a, b), f"{name} differs from the two-launch path: max {(a - b).abs().max().item():.3e}"
+    # the CompressAI formula in torch
+    gb, bb, ped = gdn._consts()
+    xt = x0.clone().requires_grad_(True)
+    gam = (torch.clamp(gdn.gamma.detach(), min=gb) ** 2 - ped)
+    bet = (torch.clamp(gdn.beta.detach(), min=bb) ** 2 - ped)
+    norm = F.conv2d(xt * xt, gam[:, :, None, None], bet)
+    yt = (xt * torch.sqrt(norm) if inverse else xt * torch.rsqrt(norm)) + r0
+    yt.backward(gy)
+    _close(res[1][0], yt.detach(), 2e-5, "gdn forward vs torch")
+    _close(res[1][1], xt.grad, 1e-4, "gdn dx vs torch")
+
+
 @pytest.mark.parametrize("N,Cin,H,W,Cout,shuffle", [(2, 128, 64, 64, 12, True), (1, 128, 40, 72, 12, True), (2, 64, 64, 48, 16, False), (3, 256, 48, 48, 12, True)])
 def test_16_column_kernel_for_the_few_channel_tail(dev, N, Cin, H, W, Cout, shuffle):
     """conv_igemm_n16_kernel (v_mfma_f32_16x16x4_f32, 256 x 16 tiles; tuning key 20): the synthesis transform's subpel tail, 128 -> 12 with the
