@@ -520,26 +520,25 @@ def reduced_precision_leg(args, dev, x, refs):
     return res
 
 
-def launcher_command(n_gpus: int, port: int, argv):
+def launcher_command(n_gpus: int, port, argv):
     """The command line of /root/reference/run_ddp.sh:7 (`python -m torch.distributed.run --nproc_per_node=8 train_CLC.py ...`) for this
-    script: one rank per GPU on one node, rendezvous on the loopback address (the container hostname may not resolve)."""
-    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
-            "--master-port", str(port), os.path.abspath(__file__), *argv]
+    script: one rank per GPU on one node, rendezvous on the loopback address (the container hostname may not resolve).
+    port = None: the c10d rendezvous binds port 0 itself (no window between probing a free port and using it)."""
+    rdzv = (["--rdzv-backend=c10d", "--rdzv-endpoint=127.0.0.1:0", "--local-addr", "127.0.0.1"] if port is None
+            else ["--master-addr", "127.0.0.1", "--master-port", str(port)])
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", *rdzv, os.path.abspath(__file__), *argv]
 
 
 def self_launch(n_gpus: int, argv) -> int:
     """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks as a FRESH child process tree and hand its exit code back.
     This process has not touched the GPU and never will (no exec of a GPU-initialised process, no retry); the ranks inherit stdout /
     stderr, so rank 0's JSON line is this command's JSON line."""
-    import socket
     import subprocess
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", "4")
+    port = int(os.environ["CLC_BENCH_MASTER_PORT"]) if os.environ.get("CLC_BENCH_MASTER_PORT") else None
     cmd = launcher_command(n_gpus, port, argv)
     print(f"[bench.py] --gpus {n_gpus} without WORLD_SIZE: launching the ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
     return subprocess.run(cmd, env=env).returncode
@@ -604,8 +603,19 @@ def main():
     backend = os.environ.get("CLC_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # CLC_FORCE_COLLECTIVES=1 at N = 1: a ONE-rank process group, every all-reduce of the multi-GPU step really issued — the way to make
+    # RCCL execute this code (communicator, bucket views of the arena, stream order around the three graph replays) on a one-GPU box
+    force_coll = os.environ.get("CLC_FORCE_COLLECTIVES", "0") == "1"
+    use_dist = world > 1 or force_coll
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(s.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -623,26 +633,33 @@ def main():
     x = synthetic_batch(args.batch, args.size, 100 + rank, dev)
     refs = [synthetic_batch(args.batch, args.size, 1000 + 10 * rank + i, dev) for i in range(args.n_refs)]
 
-    engine = TrainEngine(model, lmbda=args.lmbda, loss_type=args.loss, lr=1e-4, aux_lr=1e-3, clip_max_norm=1.0, use_graph=not args.no_graph)
+    engine = TrainEngine(model, lmbda=args.lmbda, loss_type=args.loss, lr=1e-4, aux_lr=1e-3, clip_max_norm=1.0, use_graph=not args.no_graph,
+                         train_mode=os.environ.get("CLC_BENCH_EVAL_ROUNDING", "0") != "1")
+    trace = [] if os.environ.get("CLC_BENCH_LOSS_TRACE", "0") == "1" else None   # (tests: the loss of every step, read after the timed region)
     for _ in range(max(1, args.warmup)):
         out = engine.step(x, refs)
+        if trace is not None:
+            trace.append(out["loss"].clone())
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = engine.step(x, refs)
+        if trace is not None:
+            trace.append(out["loss"].clone())
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(out["loss"].item())
+    exposed_comm = engine.exposed_comm_ms(x, refs) if (use_dist and not args.no_graph) else None
 
     result = {
         "metric": "images/sec fwd+bwd @256x256 bs8; bpp+PSNR parity vs ref",
@@ -655,11 +672,19 @@ def main():
         "config": {"workload": f"CLC N={args.N} lambda={args.lmbda} {'MSE' if args.loss == 'mse' else 'MS-SSIM'}, {args.size}x{args.size} bs{args.batch}/GPU, "
                                f"n_refs={args.n_refs}: fwd + RD loss + bwd + clip_grad_norm + AdamW + aux step" +
                                (" (configs[1])" if (args.N, args.loss, args.size, args.batch, args.n_refs) == (64, "mse", 256, 8, 1) else ""),
-                   "global_batch": world * args.batch, "parallelism": f"dp{world}", "ranks_seen": (dist.get_world_size() if world > 1 else 1),
+                   "global_batch": world * args.batch, "parallelism": f"dp{world}", "ranks_seen": (dist.get_world_size() if use_dist else 1),
                    "collective": ((("RCCL" if backend == "nccl" else backend) + " all-reduce of the flat fp32 gradient arena (64 MiB buckets) in two phases: everything "
                                    "downstream of the encoders goes on the wire while the analysis-transform / reference-encoder backward runs")
-                                  if world > 1 else "none"), "hip_graph": not args.no_graph, "final_loss": loss},
+                                  if use_dist else "none"), "hip_graph": not args.no_graph, "final_loss": loss},
     }
+    if use_dist:
+        # exposed_comm_ms: HIP events around the wait for the exchange (after graph A2), mean of 5 extra steps behind the timed region
+        result["config"].update({"exposed_comm_ms": exposed_comm, "collectives_issued": engine.sync.launched + engine.aux_sync.launched,
+                                 "buckets_per_step": len(engine.sync.buckets) + len(engine.aux_sync.buckets), "dist_backend": engine.sync.backend,
+                                 "graphs_per_step": (len(engine.graph) if isinstance(engine.graph, tuple) else 1),
+                                 "forced_one_rank_group": bool(force_coll and world == 1)})
+    if trace is not None:
+        result["config"]["loss_trace"] = [float(t.item()) for t in trace]
     if not args.no_roofline:  # every rank runs it (the eager step contains the gradient all-reduce); rank 0 reports
         result["roofline"] = roofline_leg(engine, x, refs)
         if rank == 0 and world == 1:
@@ -679,7 +704,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.n_refs, args.cpu_sample_batch or args.batch, args.size, N=args.N, lmbda=args.lmbda, loss=args.loss)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

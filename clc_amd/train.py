@@ -112,7 +112,12 @@ class GradSync:
 
         self.dist = dist
         self.flat, self.group = flat, group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        inited = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if inited else 1
+        # CLC_FORCE_COLLECTIVES=1: a 1-rank process group still issues every all-reduce (a one-GPU box can then execute the RCCL path —
+        # communicator, bucket views, stream ordering around the graph replays — that an 8-GPU run will take)
+        self.active = self.world > 1 or (inited and os.environ.get("CLC_FORCE_COLLECTIVES", "0") == "1")
+        self.backend = dist.get_backend(group) if inited else "none"
         n = max(1, bucket_bytes // 4)
         self.phases = []
         for a, b in (phases or [(0, flat.numel())]):
@@ -120,27 +125,31 @@ class GradSync:
         self.buckets = [bk for ph in self.phases for bk in ph]
         self.pending = []
         self.fold_scale = False   # True: finish() leaves the SUM in place, the optimizer applies 1 / world (TrainEngine._discover)
+        self.launched = 0         # all-reduces issued so far (tests / the bench line's `config.collectives_per_step`)
 
     def start(self, phase=None):
-        if self.world == 1:
+        if not self.active:
             return
         bks = self.buckets if phase is None else self.phases[phase]
         self.pending += [self.dist.all_reduce(b, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True) for b in bks]
+        self.launched += len(bks)
 
     def finish(self):
-        if self.world == 1:
+        if not self.active:
             return
         for w in self.pending:
             w.wait()
         self.pending = []
-        if not self.fold_scale:
+        if not self.fold_scale and self.world > 1:
             self.flat.mul_(1.0 / self.world)
 
 
 def broadcast_parameters(module: nn.Module, src: int = 0, group=None):
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    if dist.get_world_size(group) == 1 and os.environ.get("CLC_FORCE_COLLECTIVES", "0") != "1":
         return
     for t in list(module.parameters()) + list(module.buffers()):
         if t.numel():
@@ -326,6 +335,7 @@ class TrainEngine:
         self.graph = None
         self._static = None
         self._out = None
+        self.comm_events = None   # a list: the replayed multi-rank step brackets sync.finish() with HIP events (exposed_comm_ms())
 
     # -- discovery: which parameters does this (model, inputs) combination actually train?
     def _discover(self, x, refs):
@@ -360,7 +370,7 @@ class TrainEngine:
         self.aux_sync = GradSync(self.aux_opt.grad_flat)
         # the rank mean's 1 / world rides in the optimizer's own passes over the gradients where the optimizer can take it
         for sync, opt in ((self.sync, self.opt), (self.aux_sync, self.aux_opt)):
-            if self.with_optimizer and sync.world > 1 and hasattr(opt, "grad_scale"):
+            if self.with_optimizer and sync.active and hasattr(opt, "grad_scale"):
                 opt.grad_scale, sync.fold_scale = 1.0 / sync.world, True
 
     def _model_out(self, x, refs):
@@ -462,6 +472,21 @@ class TrainEngine:
             if self.aux_opt is not None:
                 self.aux_opt.set_lr(aux_lr)
 
+    def exposed_comm_ms(self, x, refs=None, steps: int = 5):
+        """Average time per step the compute stream spends WAITING for the gradient exchange (HIP events around sync.finish(), after
+        graph A2): what the all-reduce costs beyond the encoders' backward it overlaps.  None for the single-graph step."""
+        if self.graph is None or not isinstance(self.graph, tuple):
+            return None
+        self.comm_events = []
+        try:
+            for _ in range(steps):
+                self.step(x, refs)
+            torch.cuda.synchronize()
+            ts = [a.elapsed_time(b) for a, b in self.comm_events]
+        finally:
+            self.comm_events = None
+        return sum(ts) / max(1, len(ts))
+
     @staticmethod
     def _signature(x, refs):
         return (tuple(x.shape), None if refs is None else tuple(tuple(r.shape) for r in refs))
@@ -487,7 +512,7 @@ class TrainEngine:
             raise ValueError("TrainEngine was set up %s reference frames; build a second engine for the other mode"
                              % ("with" if self._live_refs else "without"))
         # CLC_FORCE_SPLIT_GRAPHS=1 exercises the multi-GPU structure (graph A | exchange | graph B) on one GPU
-        single = self.sync.world == 1 and os.environ.get("CLC_FORCE_SPLIT_GRAPHS", "0") != "1"
+        single = not self.sync.active and os.environ.get("CLC_FORCE_SPLIT_GRAPHS", "0") != "1"
         if self.graph is not None:
             single = not isinstance(self.graph, tuple)   # (the structure is fixed once captured)
         if not self.use_graph:
@@ -550,6 +575,15 @@ class TrainEngine:
             self.sync.start(1)
         else:
             self.sync.start()
-        self.sync.finish()
+        if self.comm_events is not None:
+            # exposed part of the exchange on the GPU timeline: the compute stream reaches e0 when graph A2 is done and e1 when the
+            # last bucket has landed (finish() makes this stream wait for the collective stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.sync.finish()
+            e1.record()
+            self.comm_events.append((e0, e1))
+        else:
+            self.sync.finish()
         self.graph[-1].replay()
         return self._finish(dict(self._out2))

@@ -19,6 +19,10 @@ def test_launcher_command_assembly():
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
     i = cmd.index(os.path.join(ROOT, "bench.py"))
     assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]   # the script's own arguments, unchanged, after the script
+    # default: the rendezvous picks its own port (no probe-then-bind window), still on the loopback address
+    cmd = bench.launcher_command(2, None, ["--gpus", "2"])
+    assert "--rdzv-endpoint=127.0.0.1:0" in cmd and "--rdzv-backend=c10d" in cmd and "--master-port" not in cmd
+    assert cmd[cmd.index("--local-addr") + 1] == "127.0.0.1"
 
 
 def _run(args, **env):

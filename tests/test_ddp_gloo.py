@@ -165,3 +165,43 @@ def test_two_rank_engine_step_two_phase_exchange():
         assert torch.allclose(torch.tensor(avg0[n]), want, atol=1e-6), f"{n}: exchanged gradient is not the mean over ranks"
         assert avg0[n] == avg1[n]
     assert par0 == par1, "ranks diverged after one step"
+
+
+def _forced_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CLC_FORCE_COLLECTIVES="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from clc_amd.train import GradSync
+
+        flat = torch.arange(1000, dtype=torch.float32)
+        sync = GradSync(flat, bucket_bytes=1024, phases=[(400, 1000), (0, 400)])
+        assert sync.world == 1 and sync.active and sync.backend == "gloo"
+        sync.start(0)
+        sync.start(1)
+        sync.finish()
+        q.put((sync.launched, len(sync.buckets), bool(torch.equal(flat, torch.arange(1000, dtype=torch.float32)))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_group_with_forced_collectives_issues_every_bucket():
+    """CLC_FORCE_COLLECTIVES=1 (the knob that makes a one-GPU box execute the RCCL path, tests/test_rccl_one_rank_gpu.py): a 1-rank group
+    still launches one all-reduce per bucket of every phase and leaves the sum (= the values) in place, unscaled."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(_free_port(), q))
+    p.start()
+    launched, n_buckets, same = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert launched == n_buckets == 5 and same
+
+
+def test_without_the_knob_a_one_rank_group_stays_silent():
+    from clc_amd.train import GradSync
+
+    sync = GradSync(torch.zeros(8))
+    assert not sync.active and sync.world == 1
+    sync.start()
+    sync.finish()
+    assert sync.launched == 0

@@ -1,0 +1,63 @@
+"""RCCL executes the multi-GPU step on the ONE GPU there is (SURVEY 8(e), configs[3]; /root/reference/run_ddp.sh:1-7 is the recipe: one
+rank per GPU, backend nccl).  CLC_FORCE_COLLECTIVES=1 makes a 1-rank `nccl` process group issue every all-reduce of the step
+(graph A1 | all-reduce phase 0 | graph A2 | phase 1 | graph B | aux all-reduce) instead of short-circuiting at world 1: communicator
+init with device_id, 64 MiB bucket views of the flat gradient arena, stream order of the collectives against three graph replays,
+destroy_process_group.  An all-reduce over one rank is the identity, so the run must reproduce the same structure without a process
+group BIT FOR BIT.  Every run is a FRESH child process (never a re-exec of a process that touched the GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(**kw):
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "CLC_FORCE_COLLECTIVES", "CLC_FORCE_SPLIT_GRAPHS", "CLC_DIST_BACKEND", "CLC_SINGLE_DEVICE"):
+        env.pop(k, None)
+    env.update(kw)
+    return env
+
+
+def test_rccl_one_rank_three_graph_step_is_bit_identical_to_no_group(dev, tmp_path):
+    ref = str(tmp_path / "ref.json")
+    tool = os.path.join(ROOT, "tools", "rehearse_2rank.py")
+    a = subprocess.run([sys.executable, tool, "--single", ref, "--steps", "3"], capture_output=True, text=True, timeout=400, env=_env(), cwd=ROOT)
+    assert a.returncode == 0, a.stderr[-2000:]
+    b = subprocess.run([sys.executable, tool, "--rccl1", ref, "--steps", "3"], capture_output=True, text=True, timeout=500, env=_env(), cwd=ROOT)
+    assert b.returncode == 0, (b.stdout[-1500:], b.stderr[-3000:])
+    rep = json.loads(next(l for l in b.stdout.splitlines() if l.startswith("REHEARSAL "))[len("REHEARSAL "):])
+    assert rep["backend"] == "nccl" and rep["graphs"] == 3 and rep["bit_identical_to_no_group"]
+    assert rep["collectives_issued"] >= 3 * 3 and len(rep["losses_rccl"]) == 3      # >= (two phases + aux) per step
+
+
+def _bench(env):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "4",
+                        "--no-roofline", "--no-parity", "--no-reduced", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus1_under_a_one_rank_rccl_group(dev):
+    """`bench.py --gpus 1` as torchrun would start its rank (WORLD_SIZE=1 RANK=0 LOCAL_RANK=0), backend nccl, collectives forced."""
+    common = dict(CLC_BENCH_LOSS_TRACE="1", CLC_BENCH_EVAL_ROUNDING="1")
+    rccl = _bench(_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", CLC_FORCE_COLLECTIVES="1", **common))
+    cfg = rccl["config"]
+    assert cfg["collective"].startswith("RCCL") and cfg["dist_backend"] == "nccl" and cfg["forced_one_rank_group"]
+    assert cfg["graphs_per_step"] == 3 and cfg["ranks_seen"] == 1 and rccl["n_gpus"] == 1
+    assert cfg["collectives_issued"] >= cfg["buckets_per_step"] * 4                 # warm-up + 3 timed steps at least
+    assert cfg["exposed_comm_ms"] is not None and 0.0 <= cfg["exposed_comm_ms"] < 50.0
+    split = _bench(_env(CLC_FORCE_SPLIT_GRAPHS="1", **common))                      # same three graphs, no process group
+    assert split["config"]["collective"] == "none"
+    assert rccl["config"]["loss_trace"] == split["config"]["loss_trace"], "RCCL's 1-rank all-reduce changed the numbers"
+    single = _bench(_env(**common))                                                 # the headline structure: ONE graph
+    a, b = rccl["config"]["loss_trace"], single["config"]["loss_trace"]
+    assert a[0] == b[0]                                                             # same forward bits from the same state
+    # (later steps: the filter-gradient groups of the two structures sum their partials in different segments -> float-level drift only)
+    assert all(abs(p - q) <= 2e-5 * abs(q) for p, q in zip(a, b)), (a, b)

@@ -46,15 +46,49 @@ def run(steps):
     aux = eng.aux_opt.p_arena.flat.detach().cpu().numpy()
     return {"losses": losses, "param_sha256": hashlib.sha256(flat.tobytes()).hexdigest(), "aux_sha256": hashlib.sha256(aux.tobytes()).hexdigest(),
             "param_l2": float((flat.astype("float64") ** 2).sum() ** 0.5), "n_params": int(flat.size), "two_phase": bool(eng.two_phase),
-            "graphs": (len(eng.graph) if isinstance(eng.graph, tuple) else 1), "world": int(eng.sync.world)}
+            "graphs": (len(eng.graph) if isinstance(eng.graph, tuple) else 1), "world": int(eng.sync.world),
+            "collectives_issued": int(eng.sync.launched + eng.aux_sync.launched)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--single", help="write the 1-rank reference values to this JSON")
     ap.add_argument("--check", help="2-rank run: compare with this JSON")
+    ap.add_argument("--rccl1", help="ONE rank, backend nccl (= RCCL), CLC_FORCE_COLLECTIVES=1: every all-reduce of the three-graph step is really "
+                    "issued on a 1-rank communicator; compare with this JSON (the 1-rank forced-split run without a process group)")
     ap.add_argument("--steps", type=int, default=3)
     a = ap.parse_args()
+    if a.rccl1:
+        import socket
+
+        import torch
+        import torch.distributed as dist
+
+        os.environ["CLC_FORCE_COLLECTIVES"] = "1"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        try:
+            res = run(a.steps)
+            with open(a.rccl1) as fh:
+                want = json.load(fh)
+            ok = res["losses"] == want["losses"] and res["param_sha256"] == want["param_sha256"] and res["aux_sha256"] == want["aux_sha256"]
+            report = {"ranks": 1, "backend": dist.get_backend(), "steps": a.steps, "graphs": res["graphs"], "two_phase": res["two_phase"],
+                      "collectives_issued": res["collectives_issued"], "losses_rccl": res["losses"], "losses_no_group": want["losses"],
+                      "bit_identical_to_no_group": bool(ok), "param_sha256": res["param_sha256"],
+                      "structure": "graph A1 | RCCL all-reduce phase 0 | graph A2 | phase 1 | graph B | aux all-reduce, 1-rank nccl communicator on one MI355X"}
+            print("REHEARSAL " + json.dumps(report), flush=True)
+            assert res["graphs"] == 3 and res["two_phase"] and res["collectives_issued"] > 0, res
+            assert ok, ("the RCCL run differs from the run without a process group", res["losses"], want["losses"])
+        finally:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if a.single:
         os.environ["CLC_FORCE_SPLIT_GRAPHS"] = "1"
         res = run(a.steps)
