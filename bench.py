@@ -272,7 +272,9 @@ def _replay_ms(fn, reps=20, warm=2):
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    from clc_amd import ops as _ops
+
+    with torch.cuda.graph(g, capture_error_mode=_ops.graph_capture_mode()):
         fn()
     g.replay()
     torch.cuda.synchronize()

@@ -162,7 +162,7 @@ class CodecEngine:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode=ops.graph_capture_mode()):
             out = fn()
         g.replay()   # capture does not execute: leave valid values behind for the next segment's warm-up passes
         return g, out

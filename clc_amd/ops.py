@@ -452,6 +452,16 @@ def _L():
     return _PLIB[0]
 
 
+def graph_capture_mode() -> str:
+    """capture_error_mode for torch.cuda.graph().  With a process group alive, ProcessGroupNCCL's watchdog THREAD polls its work events
+    (hipEventQuery) at any time; under the default global capture mode that call is illegal while another thread captures
+    ("operation not permitted when stream is capturing" -> the watchdog aborts the process: met on the MI355X the first time RCCL ran this
+    code, tests/test_rccl_one_rank_gpu.py).  thread_local restricts the legality checks to the capturing thread."""
+    import torch.distributed as dist
+
+    return "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
