@@ -629,6 +629,51 @@ def test_wmsa_and_block_vs_reference_golden(dev, typ, cfg):
     _close(yb, torch.from_numpy(g[f"block_{tag}_y"]), 2e-5, f"Block {tag} vs reference class")
 
 
+@pytest.mark.parametrize("typ", ["W", "SW"])
+def test_block_fused_large_map_path_vs_reference_class(dev, typ):
+    """The launches that carry the Swin blocks of the 128 x 128 maps — ln1 + qkv (`clc_lnlin_*`), MFMA window attention, the wave-private
+    1x1 kernel (projection), LayerNorm + MLP in one launch (`clc_mlp_*`) — against numbers produced by the reference's OWN Block class
+    (CLC_run.py:172-193) at M = 2 x 128 x 128 = 32 768 tokens, the size from which they switch on (tests/golden/block_large.npz,
+    tools/make_golden.py block_large): output, input gradient and all 13 parameter gradients under a seeded dy."""
+    import hashlib
+
+    from clc_amd import layers, ops
+    from clc_amd.recipe import apply_weight_recipe
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "block_large.npz"))
+    shape = g["shape"].tolist()
+    x0 = torch.randn(*shape, generator=torch.Generator().manual_seed(int(g["seed_x"])))
+    dy0 = torch.randn(*shape, generator=torch.Generator().manual_seed(int(g["seed_dy"])))
+    assert hashlib.sha256(x0.numpy().tobytes()).hexdigest() == str(g["x_sha256"]) and hashlib.sha256(dy0.numpy().tobytes()).hexdigest() == str(g["dy_sha256"])
+    blk = layers.Block(64, 64, 8, 8, 0, typ)
+    apply_weight_recipe(blk, 2)
+    blk = blk.to(dev).train()
+    x = _dev(x0.permute(0, 3, 1, 2), dev, grad=True)              # tokens [b, h, w, c] = the bytes of a channels_last NCHW tensor
+    dy = _dev(dy0.permute(0, 3, 1, 2), dev)
+    assert ops.lnlin_fusable(x, blk.msa.embedding_layer.weight) and ops.mlp_ln_fusable(x, blk.mlp[0].weight, blk.mlp[2].weight)
+    ops.PROFILE = []
+    try:
+        y = blk(x)
+        y.backward(dy)
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        launched = {r.fam for r in ops.PROFILE}
+    finally:
+        ops.PROFILE = None
+    for name in ("clc_lnlin_fwd", "clc_lnlin_bwd", "clc_mlp_fwd", "clc_mlp_bwd"):
+        assert name in launched, (name, sorted(launched))        # the fused launches are what ran
+    yt, dxt = y.detach().permute(0, 2, 3, 1).cpu(), x.grad.permute(0, 2, 3, 1).cpu()
+    for k, (b, r, c) in enumerate(g["patch_origins"].tolist()):
+        _close(yt[b, r:r + 8, c:c + 8], torch.from_numpy(g[f"{typ}_y_patch{k}"]), 2e-5, f"Block {typ} y patch {k} vs reference class")
+        _close(dxt[b, r:r + 8, c:c + 8], torch.from_numpy(g[f"{typ}_dx_patch{k}"]), 1e-4, f"Block {typ} dx patch {k} vs reference class")
+    for nm, t, tol in (("y", yt, 2e-5), ("dx", dxt, 1e-4)):
+        _close(t.double().sum(dim=(1, 2)), torch.from_numpy(g[f"{typ}_{nm}_row_sums"]), tol, f"Block {typ} {nm} per-channel sums")
+        assert abs(t.double().abs().sum().item() - float(g[f"{typ}_{nm}_abs_sum"])) <= tol * float(g[f"{typ}_{nm}_abs_sum"])
+    for n, q in blk.named_parameters():
+        assert q.grad is not None, n
+        _close(q.grad.cpu(), torch.from_numpy(g[f"{typ}_grad_{n}"]), 1e-4, f"Block {typ} d{n} vs reference class")
+
+
 def test_convtransblock_and_swatten_vs_reference_golden(dev):
     from clc_amd import layers
     from clc_amd.recipe import apply_weight_recipe

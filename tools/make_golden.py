@@ -101,6 +101,41 @@ def block_goldens(ref):
     print("blocks:", len(out), "arrays")
 
 
+def block_large_goldens(ref):
+    """The genuine Block (models/CLC_run.py:172-193) at the size where the product switches to its fused large-map launches
+    (ln1 + qkv, window attention, the wave-private 1x1 kernel, the fused LayerNorm + MLP; M = 2 x 128 x 128 = 32 768 tokens, C = 64,
+    head_dim 8, window 8 — the g_a / g_s blocks of the 128 x 128 maps): forward, input gradient and every parameter gradient under a seeded
+    dy -> tests/golden/block_large.npz.  x / dy are re-drawn by the test from the stored seeds (their sha256 is stored); kept are three
+    8 x 8 x 64 patches + f64 sums of the output and of the input gradient, and the parameter gradients whole (51 k numbers per block)."""
+    mod = sys.modules["models.CLC_run"]
+    out = {"seed_x": np.int64(20250), "seed_dy": np.int64(20251), "shape": np.array([2, 128, 128, 64], dtype=np.int64)}
+    x0 = torch.randn(2, 128, 128, 64, generator=torch.Generator().manual_seed(20250))
+    dy = torch.randn(2, 128, 128, 64, generator=torch.Generator().manual_seed(20251))
+    out["x_sha256"] = np.array(hashlib.sha256(x0.numpy().tobytes()).hexdigest())
+    out["dy_sha256"] = np.array(hashlib.sha256(dy.numpy().tobytes()).hexdigest())
+    patches = ((0, 0, 0), (0, 60, 100), (1, 120, 120))     # (image, row, col): a corner window, an interior one, the shifted wrap-around corner
+    out["patch_origins"] = np.array(patches, dtype=np.int64)
+    for typ in ("W", "SW"):
+        blk = mod.Block(64, 64, 8, 8, 0, typ).train()
+        apply_weight_recipe(blk, 2)
+        x = x0.clone().requires_grad_(True)
+        y = blk(x)
+        y.backward(dy)
+        for k, (b, r, c) in enumerate(patches):
+            out[f"{typ}_y_patch{k}"] = y.detach()[b, r:r + 8, c:c + 8].numpy()
+            out[f"{typ}_dx_patch{k}"] = x.grad[b, r:r + 8, c:c + 8].numpy()
+        for nm, t in (("y", y.detach()), ("dx", x.grad)):
+            out[f"{typ}_{nm}_sum"] = np.float64(t.double().sum().item())
+            out[f"{typ}_{nm}_abs_sum"] = np.float64(t.double().abs().sum().item())
+            out[f"{typ}_{nm}_row_sums"] = t.double().sum(dim=(1, 2)).numpy()          # [2, 64] per image and channel
+        for n, q in blk.named_parameters():
+            out[f"{typ}_grad_{n}"] = q.grad.numpy()
+        print("block_large", typ, "y sum", float(out[f"{typ}_y_sum"]), "dx abs sum", float(out[f"{typ}_dx_abs_sum"]),
+              "params", [n for n, _ in blk.named_parameters()])
+    np.savez_compressed(os.path.join(OUT, "block_large.npz"), **out)
+    print("block_large:", len(out), "arrays,", os.path.getsize(os.path.join(OUT, "block_large.npz")) // 1024, "KB")
+
+
 def dormant_goldens(ref):
     """The modules the reference constructs and never calls (CLC_run.py:284-313, 359-369): the genuine in-file CLM class and a
     multi_ref_fusion stack on recipe weights and seeded inputs -> pins the product's / the oracle's versions of them."""
@@ -333,9 +368,13 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "pins":
         pins_goldens(ref)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "block_large":
+        block_large_goldens(ref)
+        return
     graph_goldens(ref)
     codec_goldens(ref)
     block_goldens(ref)
+    block_large_goldens(ref)
     dormant_goldens(ref)
     rans_goldens()
     clm_goldens()
