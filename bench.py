@@ -154,7 +154,7 @@ def parity_and_codec(dev):
             ao, bo = o(xs, rs), p(xs.to(dev), [rs[0].to(dev)])
             per_seed.append({"seed": sd, "dbpp": abs(compute_bpp(ao) - compute_bpp(to_cpu(bo))),
                              "dpsnr_db": abs(psnr_of(ao["x_hat"], xs) - psnr_of(bo["x_hat"], xs))})
-    # codec: GPU path
+    # codec: GPU path, reference surface (model.compress / decompress of ONE image: captured segments since round 5) ...
     for _ in range(2):
         enc = p.compress(xd, rd)
         dec = p.decompress(enc["strings"], enc["shape"], rd)
@@ -169,6 +169,20 @@ def parity_and_codec(dev):
         dec = p.decompress(enc["strings"], enc["shape"], rd)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
+    # ... and the same calls launch by launch (what that surface cost before)
+    for _ in range(2):
+        enc_e = p._compress_eager(xd, rd)
+    torch.cuda.synchronize()
+    g0 = time.perf_counter()
+    for _ in range(3):
+        enc_e = p._compress_eager(xd, rd)
+    torch.cuda.synchronize()
+    g1 = time.perf_counter()
+    for _ in range(3):
+        dec_e = p._decompress_eager(enc_e["strings"], enc_e["shape"], rd)
+    torch.cuda.synchronize()
+    g2 = time.perf_counter()
+    surface_same = bool(enc_e["strings"] == enc["strings"] and torch.equal(dec_e["x_hat"], dec["x_hat"]))
     # the batched, graph-captured codec service (clc_amd.codec): 8 images per call
     from clc_amd.codec import CodecEngine
 
@@ -212,15 +226,92 @@ def parity_and_codec(dev):
               "C++ / C / Python coders and decoder output == encoder-side reconstruction",
               "sample": f"CLC N=64 n_refs=1, {nsd} seeded smooth 256x256 images (+1 reference each), eval mode, recipe weights; bpp_oracle / bpp_hip: seed 100"}
     codec = {"gpu_compress_ms_per_image": (t1 - t0) / n * 1e3, "gpu_decompress_ms_per_image": (t2 - t1) / n * 1e3,
+             "gpu_eager_compress_ms_per_image": (g1 - g0) / 3 * 1e3, "gpu_eager_decompress_ms_per_image": (g2 - g1) / 3 * 1e3,
+             "reference_surface_identical_to_eager": surface_same,
              "gpu_engine_compress_ms_per_image": (e1 - e0) / 24 * 1e3, "gpu_engine_decompress_ms_per_image": (e2 - e1) / 24 * 1e3,
              "cpu_compress_ms_per_image": (c1 - c0) * 1e3, "cpu_decompress_ms_per_image": (c2 - c1) * 1e3,
              "y_bytes": len(ys), "z_bytes": len(enc["strings"][1][0]),
-             "note": "gpu_*: model.compress()/decompress() (reference surface, eager launches, batch 1, 256x256); gpu_engine_*: clc_amd.codec.CodecEngine "
-                     "(hipGraph-captured segments, batch 8, per-image streams coded on 8 host threads), wall time / 8; CPU: oracle transforms + "
-                     "pure-Python rANS (the stand-in for CompressAI's coder), one pass"}
+             "note": "gpu_*: model.compress()/decompress() (the reference surface, batch 1, 256x256: hipGraph-captured segments of a lazily built "
+                     "CodecEngine); gpu_eager_*: the same methods launch by launch (round 4's reference-surface numbers); gpu_engine_*: "
+                     "clc_amd.codec.CodecEngine at batch 8, per-image streams coded on 8 host threads, wall time / 8; CPU: oracle transforms + "
+                     "pure-Python rANS (the stand-in for CompressAI's coder), one pass; eval_shape: one 512x768 (Kodak, eval_CLC.py:146-160 pads to x128) "
+                     "image through both surfaces with the device | rANS split and the forward-only roofline fraction"}
+    codec["batch1_256x256"] = codec_shape_leg(p, dev, 256, 256)
+    codec["eval_shape"] = codec_shape_leg(p, dev, 512, 768)
     bpp_16 = compute_bpp({"x_hat": b16["x_hat"].cpu(), "likelihoods": {k: v.cpu() for k, v in b16["likelihoods"].items()}})
     reduced = {"dbpp": abs(bpp_o - bpp_16), "dpsnr_db": abs(psnr(a["x_hat"]) - psnr(b16["x_hat"]))}
     return parity, codec, reduced
+
+
+def codec_shape_leg(p, dev, H, W, R=1, n=5):
+    """One image of H x W (already a multiple of 128, as eval_CLC.py:146-160 pads it) through BOTH codec surfaces at batch 1 — the way the
+    reference evaluates (eval_CLC.py:314-338): model.compress() / decompress() (which ride on the captured segments of a CodecEngine) and the
+    eager launch-by-launch methods; wall ms per image, the split device segments (+ their D2H / H2D hops) | host rANS, and the forward-only
+    roofline fraction of the device part: algorithmic FLOPs of the launches of one pass (recorded through the C ABI) / graph-replay time."""
+    import torch
+
+    from clc_amd import ops
+    from clc_amd.recipe import synthetic_image
+
+    x = synthetic_image(1, H, W, 700, smooth=True).to(dev)
+    refs = [synthetic_image(1, H, W, 701 + j, smooth=True).to(dev) for j in range(R)]
+    out = {"shape": f"{H}x{W}", "batch": 1, "n_refs": R}
+
+    def wall(fn, reps):
+        fn()
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3, r
+
+    out["compress_ms"], enc = wall(lambda: p.compress(x, refs), n)
+    eng = p.__dict__.get("_codec_eng")
+    out["compress_split"] = {k: round(v, 3) for k, v in eng.last.items() if k != "op"} if eng is not None else None
+    out["decompress_ms"], dec = wall(lambda: p.decompress(enc["strings"], enc["shape"], refs), n)
+    out["decompress_split"] = {k: round(v, 3) for k, v in eng.last.items() if k != "op"} if eng is not None else None
+    out["eager_compress_ms"], enc_e = wall(lambda: p._compress_eager(x, refs), 3)
+    out["eager_decompress_ms"], dec_e = wall(lambda: p._decompress_eager(enc["strings"], enc["shape"], refs), 3)
+    out["streams_identical_to_eager"] = bool(enc["strings"] == enc_e["strings"] and torch.equal(dec["x_hat"], dec_e["x_hat"]))
+    out["y_bytes"], out["z_bytes"] = len(enc["strings"][0][0]), len(enc["strings"][1][0])
+    out["bpp"] = 8.0 * (out["y_bytes"] + out["z_bytes"]) / (H * W)
+    if eng is not None:
+        # device part alone: the encoder graph / the six decoder graphs replayed back to back (no host hop in between), HIP events
+        pe = next(iter(eng._enc.values()))
+        pd = next(iter(eng._dec.values()))
+
+        def flops_of(fns):
+            ops.PROFILE = []
+            try:
+                for f in fns:
+                    f()
+                torch.cuda.synchronize()
+                return sum(r.flops for r in ops.PROFILE), len(ops.PROFILE)
+            finally:
+                ops.PROFILE = None
+
+        def replay_ms(graphs, reps=10):
+            ts = []
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for g in graphs:
+                    g.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            return sorted(ts)[len(ts) // 2]
+
+        for name, fns, graphs in (("encoder", [pe.run], [pe.graph]), ("decoder", [f for _, f, _ in pd.segs], [g for g, _, _ in pd.segs])):
+            if any(g is None for g in graphs):
+                continue
+            fl, nl = flops_of(fns)
+            ms = replay_ms(graphs)
+            out[name + "_device"] = {"gflop": round(fl / 1e9, 2), "graph_ms": round(ms, 3), "tflops": round(fl / ms / 1e9, 2),
+                                     "frac_of_f32_mfma_peak": round(fl / ms / 1e9 / F32_MFMA_PEAK_TFLOPS, 4), "c_abi_launches": nl}
+    return out
 
 
 def _kernel_name(L, r):
@@ -522,6 +613,83 @@ def reduced_precision_leg(args, dev, x, refs):
     return res
 
 
+def reference_loop_leg(args, dev, x, refs, steps: int = 5, warm: int = 2):
+    """The LITERAL loop body of /root/reference/train_CLC.py:137-183 on clc_amd.models.CLC, eager (no TrainEngine, no hipGraph, no fused
+    optimizer, no arenas): optimizer.zero_grad / aux_optimizer.zero_grad, model(sample, ref_samples), criterion, loss.backward(),
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0), the per-parameter `p.grad.nan_to_num_()` loop, optimizer.step(),
+    model.aux_loss().backward(), aux_optimizer.step() — with the reference's own optimizer pair (configure_optimizers, train_CLC.py:81-117:
+    two torch.optim.AdamW).  What `train_CLC.py` gets when it runs unmodified over this package.  Reported beside `value`, never as it.
+    The split comes from a second pass with a device synchronisation after each phase (so its parts sum to more than the free-running step)."""
+    import types
+
+    import torch
+
+    from clc_amd import models
+    from clc_amd.recipe import apply_weight_recipe
+    from clc_amd.train import RateDistortionLoss, configure_optimizers
+
+    torch.manual_seed(0)
+    model = models.CLC(N=args.N, num_ref_frames=args.n_refs)
+    apply_weight_recipe(model, 0)
+    model = model.to(dev).train()
+    criterion = RateDistortionLoss(lmbda=args.lmbda, type=args.loss)
+    optimizer, aux_optimizer = configure_optimizers(model, types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3))
+    clip_max_norm = 1.0
+    marks = []
+
+    def body(sync_phases=False):
+        def mark(name):
+            if sync_phases:
+                torch.cuda.synchronize()
+                marks.append((name, time.perf_counter()))
+        mark("start")
+        optimizer.zero_grad()
+        aux_optimizer.zero_grad()
+        out_net = model(x, refs)
+        out_criterion = criterion(out_net, x)
+        mark("forward + criterion")
+        out_criterion["loss"].backward()
+        mark("backward")
+        if clip_max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), clip_max_norm)
+        for p in model.parameters():
+            if p.grad is not None:
+                p.grad.nan_to_num_()
+        mark("clip_grad_norm_ + nan_to_num_ loop")
+        optimizer.step()
+        mark("optimizer.step (torch.optim.AdamW)")
+        aux_loss = model.aux_loss()
+        aux_loss.backward()
+        aux_optimizer.step()
+        mark("aux loss + aux optimizer")
+        return out_criterion
+
+    for _ in range(warm):
+        out = body()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = body()
+    host_issue = (time.perf_counter() - t0) / steps     # the host has returned from the last launch; the GPU may still be busy
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    split = {}
+    for _ in range(2):
+        marks.clear()
+        body(sync_phases=True)
+    for (_, ta), (name, tb) in zip(marks[:-1], marks[1:]):
+        split[name] = round((tb - ta) * 1e3, 2)
+    n_params = sum(1 for p in model.parameters() if p.grad is not None)
+    res = {"value": args.batch / dt, "unit": "images/sec", "ms_per_step": round(dt * 1e3, 2), "host_issue_ms_per_step": round(host_issue * 1e3, 2),
+           "steps": steps, "warmup": warm, "final_loss": float(out["loss"].item()), "parameters_with_grad": n_params,
+           "phase_ms_with_a_sync_after_each": split,
+           "what": ("literal body of train_CLC.py:137-183 on clc_amd.models.CLC, eager: two torch.optim.AdamW from configure_optimizers "
+                    "(train_CLC.py:81-117), clip_grad_norm_, per-parameter nan_to_num_ loop, aux_loss.backward(); no TrainEngine / hipGraph / arenas")}
+    del optimizer, aux_optimizer, model
+    torch.cuda.empty_cache()
+    return res
+
+
 def launcher_command(n_gpus: int, port, argv):
     """The command line of /root/reference/run_ddp.sh:7 (`python -m torch.distributed.run --nproc_per_node=8 train_CLC.py ...`) for this
     script: one rank per GPU on one node, rendezvous on the loopback address (the container hostname may not resolve).
@@ -563,6 +731,7 @@ def main():
     ap.add_argument("--cpu-sample-batch", type=int, default=0, help="CPU-baseline batch (default: the GPU batch, BASELINE.md §3)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-reduced", action="store_true", help="skip the reduced-precision (bf16 MFMA) leg")
+    ap.add_argument("--no-reference-loop", action="store_true", help="skip the leg that times the reference's literal (eager) training loop body")
     ap.add_argument("--launch-selftest", action="store_true", help="ranks only rendezvous (gloo, CPU), all-reduce a counter and exit: checks the "
                     "self-launcher / torchrun wiring of --gpus N on a box without N GPUs")
     args = ap.parse_args()
@@ -694,6 +863,12 @@ def main():
             # (flat copy: a consumer that keeps only the top level of `roofline` still sees the number north_star's target is stated on)
             result["roofline"]["transforms_frac"] = result["roofline"]["transforms"]["total"]["frac_of_f32_mfma_peak"]
             result["roofline"]["transforms_ms"] = result["roofline"]["transforms"]["total"]["ms"]
+        if rank == 0:
+            # flat copies (a consumer that keeps only the top level of `roofline` sees them): the whole step's algorithmic FLOPs over the
+            # TIMED region's ms_per_step, and the transforms' share of one step by owner-tagged launches
+            rl = result["roofline"]
+            rl["whole_step_frac"] = round(rl["all_mfma_kernels"]["gflop_per_step"] / result["ms_per_step"] / F32_MFMA_PEAK_TFLOPS, 4)
+            rl["in_step_transforms_frac"] = rl["in_step_by_owner"].get("transforms", {}).get("frac_of_f32_mfma_peak")
     if rank == 0:
         reduced_parity = None
         if world == 1 and not args.no_parity:
@@ -703,6 +878,9 @@ def main():
             if reduced_parity:
                 result["reduced_precision"].update(reduced_parity)
             result["reduced_precision"]["vs_f32_value"] = result["reduced_precision"]["value"] / result["value"]
+        if world == 1 and not use_dist and not args.no_reference_loop:
+            result["reference_loop"] = reference_loop_leg(args, dev, x, refs)
+            result["reference_loop"]["vs_engine_value"] = round(result["reference_loop"]["value"] / result["value"], 4)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.n_refs, args.cpu_sample_batch or args.batch, args.size, N=args.N, lmbda=args.lmbda, loss=args.loss)
         print(json.dumps(result), flush=True)

@@ -22,6 +22,7 @@ reference's own compress() by tests/golden/codec_*.npz.
 from __future__ import annotations
 
 import struct
+import time
 from concurrent.futures import ThreadPoolExecutor
 from typing import List, Optional, Sequence
 
@@ -122,6 +123,7 @@ class CodecEngine:
         self.pool = ThreadPoolExecutor(max_workers=max(1, threads))
         self._enc = {}
         self._dec = {}
+        self.last = {}   # wall-clock split of the last compress() / decompress() call (ms): device segments incl. the hops' copies and waits | host rANS
         self.zc = int(model.entropy_bottleneck.channels)   # hyper-latent channels (192 in the reference configuration)
         model.update()   # CDF tables (no-op when present)
 
@@ -220,6 +222,7 @@ class CodecEngine:
         pl = self._enc.get(sig)
         if pl is None:
             pl = self._enc[sig] = self._build_encoder(x, refs)
+        t0 = time.perf_counter()
         pl.x.copy_(x, non_blocking=True)
         if refs is not None:
             for d, r in zip(pl.refs, refs):
@@ -230,6 +233,7 @@ class CodecEngine:
             pl.packed, _ = pl.run()
         pl.host.copy_(pl.packed, non_blocking=True)
         torch.cuda.current_stream().synchronize()        # the ONE device->host hop of the encoder
+        t1 = time.perf_counter()
         arr = pl.host.numpy()
         gcdf, gln, goff = self.model.gaussian_conditional.host_tables()
         ecdf, eln, eoff = self.model.entropy_bottleneck.host_tables()
@@ -239,7 +243,8 @@ class CodecEngine:
             row = arr[b]
             return (ans.encode(row[:ny], row[ny:2 * ny], gcdf, gln, goff), ans.encode(row[2 * ny:], pl.zidx, ecdf, eln, eoff))
 
-        streams = list(self.pool.map(encode_one, range(arr.shape[0])))
+        streams = list(self.pool.map(encode_one, range(arr.shape[0]))) if arr.shape[0] > 1 else [encode_one(0)]
+        self.last = {"op": "compress", "device_ms": (t1 - t0) * 1e3, "rans_ms": (time.perf_counter() - t1) * 1e3, "hops": 1}
         return [{"strings": [[ys], [zs]], "shape": torch.Size(pl.zshape)} for ys, zs in streams]
 
     # ---------------------------------------------------------------- decoder
@@ -323,31 +328,44 @@ class CodecEngine:
         C = self.zc
         zidx = np.ascontiguousarray(np.broadcast_to(np.arange(C, dtype=np.int32).reshape(C, 1, 1), (C,) + zshape)).reshape(-1)
         zh = pl.z_host.numpy()
+        t_dev = t_rans = 0.0
+        tm = time.perf_counter()
 
         def dec_z(b):
             zh[b] = ans.decode(items[b]["strings"][1][0], zidx, ecdf, eln, eoff).reshape(zh.shape[1:])
 
-        list(self.pool.map(dec_z, range(B)))
+        run_all = (lambda f: list(self.pool.map(f, range(B)))) if B > 1 else (lambda f: f(0))
+        run_all(dec_z)
+        t_rans += time.perf_counter() - tm
         pl.z_in.copy_(pl.z_host, non_blocking=True)
         decoders = [ans._Decoder(items[b]["strings"][0][0]) for b in range(B)]
         try:
             S = m.num_slices
             for i in range(S + 1):
+                tm = time.perf_counter()
                 g, fn, out = pl.segs[i]
                 if g is not None:
                     g.replay()
                 else:
                     out = fn()
                 if i == S:
-                    return out.clone() if g is not None else out
+                    res = out.clone() if g is not None else out
+                    # (the last segment — refinement of the last slice + the synthesis transform — is still running: the caller's first
+                    #  use of x_hat waits for it; `device_ms` covers the segments up to the last hop, `tail_issue_ms` issuing the last one)
+                    self.last = {"op": "decompress", "device_ms": t_dev * 1e3, "rans_ms": t_rans * 1e3, "hops": S + 1,
+                                 "tail_issue_ms": (time.perf_counter() - tm) * 1e3}
+                    return res
                 pl.idx_host[i].copy_(out, non_blocking=True)
                 torch.cuda.current_stream().synchronize()          # hop i: CDF indexes of slice i for every image
                 ih, rh = pl.idx_host[i].numpy(), pl.rv_host[i].numpy()
+                t_dev += time.perf_counter() - tm
+                tm = time.perf_counter()
 
                 def dec_y(b):
                     rh[b] = decoders[b].decode(ih[b].reshape(-1), gcdf, gln, goff).reshape(rh.shape[1:])
 
-                list(self.pool.map(dec_y, range(B)))
+                run_all(dec_y)
+                t_rans += time.perf_counter() - tm
                 pl.rv_in[i].copy_(pl.rv_host[i], non_blocking=True)
         finally:
             for d in decoders:

@@ -47,8 +47,9 @@ def test_engine_matches_model_codec(dev, kind, R):
     want = []
     for i in range(B):
         ri = [r[i:i + 1] for r in refs]
-        enc = m.compress(x[i:i + 1], ri) if R else m.compress(x[i:i + 1])
-        dec = m.decompress(enc["strings"], enc["shape"], ri) if R else m.decompress(enc["strings"], enc["shape"])
+        # (the eager launch-by-launch methods: model.compress() itself rides on a CodecEngine for single images, test below)
+        enc = m._compress_eager(x[i:i + 1], ri if R else None)
+        dec = m._decompress_eager(enc["strings"], enc["shape"], ri if R else None)
         want.append((enc, dec["x_hat"]))
     results = {}
     for use_graph in (True, False):
@@ -75,3 +76,55 @@ def test_engine_matches_model_codec(dev, kind, R):
         assert torch.equal(eng.decompress(items, refs), x_hat)
         results[use_graph] = (outs, x_hat)
     assert torch.equal(results[True][1], results[False][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,R,H,W", [("clc", 1, 256, 256), ("clc", 3, 256, 384), ("tcm", 0, 256, 256)])
+def test_reference_surface_single_image_codec_rides_on_captured_graphs(dev, kind, R, H, W):
+    """model.compress() / decompress() — what /root/reference/eval_CLC.py:314-338 calls, one padded image at a time
+    (CLC_run.py:629-716, 738-814) — run on the captured segments of a lazily built CodecEngine: byte-identical streams and bit-identical
+    images to the eager methods; a second image of the same shape reuses the graphs; re-homed parameters (what TrainEngine does) or a
+    changed precision mode rebuild them; batches > 1 and CLC_CODEC_GRAPH=0 keep the eager path."""
+    import clc_amd
+    from clc_amd import models as pm
+    from clc_amd.models import clc as mclc
+    from clc_amd.recipe import apply_weight_recipe, synthetic_image
+
+    m = pm.CLC(N=64, num_ref_frames=R) if kind == "clc" else pm.TCM(N=64)
+    apply_weight_recipe(m, 0)
+    m = m.to(dev).eval()
+    m.update(force=True)
+    imgs = [synthetic_image(1, H, W, 500 + 3 * i, smooth=True).to(dev) for i in range(2)]
+    refs = [[synthetic_image(1, H, W, 600 + 10 * i + j, smooth=True).to(dev) for j in range(R)] for i in range(2)]
+    engines = []
+    for x, rf in zip(imgs, refs):
+        a = m.compress(x, rf) if R else m.compress(x)
+        b = m._compress_eager(x, rf if R else None)
+        assert a["strings"] == b["strings"] and tuple(a["shape"]) == tuple(b["shape"])
+        da = m.decompress(a["strings"], a["shape"], rf) if R else m.decompress(a["strings"], a["shape"])
+        db = m._decompress_eager(b["strings"], b["shape"], rf if R else None)
+        assert torch.equal(da["x_hat"], db["x_hat"])
+        engines.append(m.__dict__.get("_codec_eng"))
+    eng = engines[0]
+    assert eng is not None and engines[1] is eng and len(eng._enc) == 1 and len(eng._dec) == 1     # one set of graphs, reused
+    assert next(iter(eng._enc.values())).graph is not None
+    assert not m.training
+    # re-homed parameters: the captured graphs would read the old storage -> the engine must be rebuilt, results unchanged
+    with torch.no_grad():
+        for q in m.parameters():
+            q.data = q.data.clone(memory_format=torch.preserve_format)
+    a2 = m.compress(imgs[0], refs[0]) if R else m.compress(imgs[0])
+    assert m.__dict__["_codec_eng"] is not eng and a2["strings"] == (m._compress_eager(imgs[0], refs[0] if R else None))["strings"]
+    # batch > 1: the reference's joint y stream (eager path), untouched
+    xb = torch.cat(imgs)
+    rb = [torch.cat([refs[0][j], refs[1][j]]) for j in range(R)]
+    eb = m.compress(xb, rb) if R else m.compress(xb)
+    assert len(eb["strings"][0]) == 1 and len(eb["strings"][1]) == 2
+    old = mclc.CODEC_GRAPH
+    mclc.CODEC_GRAPH = False
+    try:
+        assert m._codec_engine(imgs[0]) is None
+        a3 = m.compress(imgs[0], refs[0]) if R else m.compress(imgs[0])
+        assert a3["strings"] == a2["strings"]
+    finally:
+        mclc.CODEC_GRAPH = old
