@@ -279,8 +279,8 @@ def codec_shape_leg(p, dev, H, W, R=1, n=5):
     out["bpp"] = 8.0 * (out["y_bytes"] + out["z_bytes"]) / (H * W)
     if eng is not None:
         # device part alone: the encoder graph / the six decoder graphs replayed back to back (no host hop in between), HIP events
-        pe = next(iter(eng._enc.values()))
-        pd = next(iter(eng._dec.values()))
+        pe = list(eng._enc.values())[-1]      # (the plans of THIS shape: the newest of the engine's signatures)
+        pd = list(eng._dec.values())[-1]
 
         def flops_of(fns):
             ops.PROFILE = []

@@ -321,14 +321,19 @@ class _SliceCodec(CompressionModel):
     def _codec_stamp(self):
         from ..codec import kernel_config_tag
 
-        ps = list(self.parameters())
-        return (kernel_config_tag(), len(ps), sum(q.data_ptr() for q in ps[::8]), sum(b.data_ptr() for b in self.buffers()),
+        # (the Parameter / buffer OBJECTS are stable; walking the module tree for them costs 3 ms per call, their data_ptr()s 30 us)
+        probe = self.__dict__.get("_codec_probe")
+        if probe is None:
+            ps = list(self.parameters())
+            probe = self.__dict__["_codec_probe"] = (ps[::8], list(self.buffers()), len(ps))
+        return (kernel_config_tag(), probe[2], sum(q.data_ptr() for q in probe[0]), sum(b.data_ptr() for b in probe[1]),
                 bool(getattr(self, "wire_clm", False)), getattr(self, "max_support_slices", None), getattr(self, "use_ref", None))
 
     def __getstate__(self):   # (copy.deepcopy / pickling of the model: the lazily built engine — graphs, a thread pool — stays behind)
         d = dict(self.__dict__)
         d.pop("_codec_eng", None)
         d.pop("_codec_eng_stamp", None)
+        d.pop("_codec_probe", None)
         return d
 
     def _codec_engine(self, x_like):

@@ -6,6 +6,7 @@ reference is summation order): rel 2e-5 of the output scale for forward, 1e-4 fo
 """
 import math
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT}
 cd $R
 N=$1; shift
 mkdir -p gpurun_out/ab
-extra="--no-cpu-baseline --no-reduced --no-parity"
+extra="--no-cpu-baseline --no-reduced --no-parity --no-reference-loop"
 [ "${TR:-1}" = "0" ] && extra="$extra --no-roofline"
 for i in $(seq 1 $N); do
   for v in "$@"; do

@@ -7,7 +7,7 @@ A="$1"; B="$2"; N=${3:-3}
 cd "$R"
 for i in $(seq 1 $N); do
   for cfg in "$A" "$B"; do
-    v=$(CLC_TUNING="$cfg" python bench.py --no-cpu-baseline --no-parity --no-roofline --no-reduced --steps 30 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('%.1f img/s %.3f ms' % (d['value'], d['ms_per_step']))")
+    v=$(CLC_TUNING="$cfg" python bench.py --no-cpu-baseline --no-parity --no-roofline --no-reduced --no-reference-loop --steps 30 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('%.1f img/s %.3f ms' % (d['value'], d['ms_per_step']))")
     echo "round $i  [$cfg]  $v"
   done
 done
