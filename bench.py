@@ -222,7 +222,10 @@ def parity_and_codec(dev):
     parity = {"dbpp": sum(q["dbpp"] for q in per_seed) / nsd, "dpsnr_db": sum(q["dpsnr_db"] for q in per_seed) / nsd,
               "dbpp_max": max(q["dbpp"] for q in per_seed), "dpsnr_db_max": max(q["dpsnr_db"] for q in per_seed), "per_seed": per_seed,
               "bitstream_identical": bool(identical),
-              "bpp_oracle": bpp_o, "bpp_hip": bpp_p, "bars": "mean dbpp <= 1e-4, mean dpsnr <= 0.01 dB over the seeded images; y/z streams byte-identical across the "
+              "within_bars": bool(sum(q["dbpp"] for q in per_seed) / nsd <= 1e-4 and max(q["dbpp"] for q in per_seed) <= 1e-3
+                                  and sum(q["dpsnr_db"] for q in per_seed) / nsd <= 0.01 and max(q["dpsnr_db"] for q in per_seed) <= 0.02),
+              "bpp_oracle": bpp_o, "bpp_hip": bpp_p, "bars": "mean dbpp <= 1e-4 and mean dpsnr <= 0.01 dB over the seeded images, AND no single image over 1e-3 bpp / 0.02 dB (the footprint of one "
+              "hyper-latent rounding flip; tests/test_model_gpu.py::test_forward_parity_over_a_sample_of_images asserts both); y/z streams byte-identical across the "
               "C++ / C / Python coders and decoder output == encoder-side reconstruction",
               "sample": f"CLC N=64 n_refs=1, {nsd} seeded smooth 256x256 images (+1 reference each), eval mode, recipe weights; bpp_oracle / bpp_hip: seed 100"}
     codec = {"gpu_compress_ms_per_image": (t1 - t0) / n * 1e3, "gpu_decompress_ms_per_image": (t2 - t1) / n * 1e3,
@@ -335,7 +338,7 @@ def _kernel_name(L, r):
     f, bm, bn = (variant >> 20) & 15, (variant >> 3) & 0x1FF, (variant & 7) << 5
     if f == 3:   # <BN, TR, KW, PF>: 4-wave tiles keep one K-tile in flight, 8-wave ones CLC_TUNE_SPLITK_PF (key 6)
         kw = (variant >> 16) & 15
-        ops_arith = "true" if ("+actbwd" in shape) else "false"   # (<..., OPS>: the instantiation with operand arithmetic; GDN's squared-input launches on small maps also take it)
+        ops_arith = "true" if ("+actbwd" in shape or "+sq" in shape) else "false"   # (<..., OPS>: operand arithmetic — a fused activation derivative or GDN's squared input: launch_splitk_o's rule)
         return f"conv_igemm_splitk_kernel<{bn}, {tr}, {kw}, {1 if kw == 4 or splitk_pf == 1 else 3}, {ops_arith}>"
     if f in (4, 5):   # family 5 = the 1x1 instantiation (its own symbol)
         return (f"conv_igemm_dma2_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}, {1 if f == 5 else 3}, "

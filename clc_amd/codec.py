@@ -50,23 +50,48 @@ def kernel_config_tag() -> int:
     return int(lib.load().clc_kernel_config_tag())
 
 
-def pack(strings, shape, image_hw, n_refs: int = 0, model_id: int = 0) -> bytes:
+def kernel_config():
+    """(tag, 32-bit hash) of the kernel state this process would run NOW.  compress() records it in its result WHEN THE KERNELS RAN, so a
+    pack() after the caller restored another tuning / precision state still writes the state that encoded."""
+    from . import lib
+
+    L = lib.load()
+    return int(L.clc_kernel_config_tag()), int(L.clc_kernel_config_hash()) & 0xFFFFFFFF
+
+
+def pack(strings, shape, image_hw, n_refs: int = 0, model_id: int = 0, kernel_config_=None) -> bytes:
     """One image: header + z stream + y stream.
-    header (little endian): magic 'CLC1' | u8 version=1 | u8 model_id | u8 n_refs | u8 kernel-config tag | u16 H | u16 W (original image) |
-    u16 zh | u16 zw (hyper-latent shape = `shape`) | u32 len(y) | u32 len(z).
+    header (little endian): magic 'CLC1' | u8 version | u8 model_id | u8 n_refs | u8 kernel-config tag | u16 H | u16 W (original image) |
+    u16 zh | u16 zw (hyper-latent shape = `shape`) | u32 len(y) | u32 len(z) [| u32 kernel-config hash: version 2].
     The tag records which generation of context-model kernels encoded the image: the slice loop is autoregressive through the
     arithmetic decoder, so the decoder only stays in sync when it reproduces the encoder's means / scales bit for bit (the
-    reference has the same property across devices and library versions; it records nothing)."""
+    reference has the same property across devices and library versions; it records nothing).  Version 1 (24-byte header) under the
+    build's default kernel state; version 2 (28 bytes) when an order-affecting tuning key was off its default at ENCODE time: the tag
+    then holds 7 bits of a hash and the full 32 bits follow.  kernel_config_: the `kernel_config` entry of compress()'s result
+    (default: the state at the time of this call)."""
     y, z = strings[0][0], strings[1][0]
-    return MAGIC + struct.pack("<BBBBHHHHII", 1, model_id, n_refs, kernel_config_tag(), image_hw[0], image_hw[1], int(shape[0]), int(shape[1]), len(y), len(z)) + z + y
+    tag, h = kernel_config_ if kernel_config_ is not None else kernel_config()
+    ver = 2 if tag >= 128 else 1
+    head = MAGIC + struct.pack("<BBBBHHHHII", ver, model_id, n_refs, tag, image_hw[0], image_hw[1], int(shape[0]), int(shape[1]), len(y), len(z))
+    if ver == 2:
+        head += struct.pack("<I", h)
+    return head + z + y
+
+
+def pack_item(item: dict, image_hw, n_refs: int = 0, model_id: int = 0) -> bytes:
+    """pack() of one compress() result, under the kernel state that result was ENCODED with."""
+    return pack(item["strings"], item["shape"], image_hw, n_refs, model_id, item.get("kernel_config"))
 
 
 def check_kernel_config(meta, what="container"):
     """Raise KernelConfigMismatch unless `meta` (from unpack) carries the tag of the kernels that are about to decode.  Tag 0 (files
     written before the tag existed) never matches: those builds summed in other orders."""
-    tag, now = int(meta.get("kernel_config_tag", 0)), kernel_config_tag()
-    if tag != now:
-        raise KernelConfigMismatch(f"{what} was encoded under kernel-config tag {tag}, this build / tuning state decodes under tag {now}: the "
+    tag = int(meta.get("kernel_config_tag", 0))
+    now, now_h = kernel_config()
+    h = meta.get("kernel_config_hash")
+    if tag != now or (h is not None and int(h) != now_h):
+        raise KernelConfigMismatch(f"{what} was encoded under kernel-config tag {tag}" + (f" (hash {int(h):08x})" if h is not None else "") +
+                                   f", this build / tuning state decodes under tag {now} (hash {now_h:08x}): the "
                                    "context model would leave the encoder's bit-exact means / scales and the arithmetic decoder would "
                                    "desynchronise silently.  Decode with the build (and CLC_TUNING / precision mode) that encoded, or "
                                    "pass strict=False to read the streams anyway.")
@@ -78,12 +103,17 @@ def unpack(blob: bytes, strict: bool = True):
     if len(blob) < 24 or blob[:4] != MAGIC:
         raise ValueError("not a CLC1 container (shorter than its 24-byte header, or wrong magic)")
     ver, model_id, n_refs, tag, H, W, zh, zw, ny, nz = struct.unpack("<BBBBHHHHII", blob[4:24])
-    if ver != 1:
+    if ver not in (1, 2):
         raise ValueError(f"unsupported container version {ver}")
-    if len(blob) != 24 + ny + nz:
+    hl = 24 if ver == 1 else 28
+    if len(blob) != hl + ny + nz:
         raise ValueError("truncated / oversized container")
-    z, y = blob[24:24 + nz], blob[24 + nz:24 + nz + ny]
-    meta = {"image_hw": (H, W), "n_refs": n_refs, "model_id": model_id, "kernel_config_tag": tag, "same_kernel_config": tag == kernel_config_tag()}
+    z, y = blob[hl:hl + nz], blob[hl + nz:hl + nz + ny]
+    now, now_h = kernel_config()
+    meta = {"image_hw": (H, W), "n_refs": n_refs, "model_id": model_id, "kernel_config_tag": tag, "same_kernel_config": tag == now}
+    if ver == 2:
+        meta["kernel_config_hash"] = struct.unpack("<I", blob[24:28])[0]
+        meta["same_kernel_config"] = tag == now and meta["kernel_config_hash"] == now_h
     if strict:
         check_kernel_config(meta)
     return [[y], [z]], torch.Size([zh, zw]), meta
@@ -150,7 +180,9 @@ class CodecEngine:
 
     # ---------------------------------------------------------------- shared pieces
     def _sig(self, x, refs):
-        return (tuple(x.shape), None if refs is None else tuple(tuple(r.shape) for r in refs))
+        # (the kernel state is part of the signature: a captured graph keeps the kernels it was captured with, so a changed tuning /
+        #  precision state must not replay the old plan — and the result's `kernel_config` must be the one that encoded)
+        return (tuple(x.shape), None if refs is None else tuple(tuple(r.shape) for r in refs), kernel_config())
 
     def _capture(self, fn):
         """run fn() twice eagerly on a side stream (allocator / lazy kernel attributes), then capture it; -> (graph, outputs)."""
@@ -173,6 +205,7 @@ class CodecEngine:
     def _build_encoder(self, x, refs):
         m = self.model
         pl = _Plan()
+        pl.kernel_config = kernel_config()
         pl.x = x.clone()
         pl.refs = [r.clone() for r in refs] if refs is not None else None
         B = x.shape[0]
@@ -245,7 +278,8 @@ class CodecEngine:
 
         streams = list(self.pool.map(encode_one, range(arr.shape[0]))) if arr.shape[0] > 1 else [encode_one(0)]
         self.last = {"op": "compress", "device_ms": (t1 - t0) * 1e3, "rans_ms": (time.perf_counter() - t1) * 1e3, "hops": 1}
-        return [{"strings": [[ys], [zs]], "shape": torch.Size(pl.zshape)} for ys, zs in streams]
+        # (a replayed graph holds the kernels of the state it was CAPTURED under: plans are keyed by it, see _sig)
+        return [{"strings": [[ys], [zs]], "shape": torch.Size(pl.zshape), "kernel_config": pl.kernel_config} for ys, zs in streams]
 
     # ---------------------------------------------------------------- decoder
     def _build_decoder(self, B, zshape, refs, dev):
@@ -310,13 +344,15 @@ class CodecEngine:
         for k, it in enumerate(items):      # items that came out of a container carry its header: refuse another kernel generation's
             if it.get("meta") is not None:
                 check_kernel_config(it["meta"], f"item {k}")
+            elif it.get("kernel_config") is not None and tuple(it["kernel_config"]) != kernel_config():
+                raise KernelConfigMismatch(f"item {k} was encoded under kernel state {tuple(it['kernel_config'])}, this process now decodes under {kernel_config()}")
         refs = list(ref_frames) if ref_frames else None
         if not getattr(m, "use_ref", True) or not hasattr(m, "ref_encoder"):
             refs = None
         B = len(items)
         zshape = tuple(int(v) for v in items[0]["shape"])
         dev = next(m.parameters()).device
-        sig = (B, zshape, None if refs is None else tuple(tuple(r.shape) for r in refs))
+        sig = (B, zshape, None if refs is None else tuple(tuple(r.shape) for r in refs), kernel_config())
         pl = self._dec.get(sig)
         if pl is None:
             pl = self._dec[sig] = self._build_decoder(B, zshape, refs, dev)

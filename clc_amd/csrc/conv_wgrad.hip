@@ -411,14 +411,14 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int 
     const int piece = tid + i * 256, xp = piece >> 4, q = piece & 15;
     const int wy = xp / XW, wx = xp - wy * XW, ci = ci0 + q * 4;
     x_rel[i] = ((wy - 1) * pW + (wx - 1)) * pldx + ci;
-    x_flag[i] = (wy == 0 ? 1 : 0) | (wy == XH - 1 ? 2 : 0) | (wx == 0 ? 4 : 0) | (wx == XW - 1 ? 8 : 0) | ((piece < XP * 16 && ci < pCin) ? 0 : 16);
+    x_flag[i] = (wy == 0 ? 1 : 0) | (wy == XH - 1 ? 2 : 0) | (wx == 0 ? 4 : 0) | (wx == XW - 1 ? 8 : 0) | ((piece < XP * 16 && ci < pCin) ? 0 : 16) | 32;   // (bit 5: always set, masked in only by a disabled tile)
   }
   auto dma_tile = [&](int t, int buf, bool en) {   // en = false: deposits zeros (the K loop stays free of a block-uniform branch)
     const int bc = t & ((1 << lcols) - 1), t2 = t >> lcols;
     const int br = t2 & ((1 << lrows) - 1), n = t2 >> lrows;
     const int oy0 = br * TH, ox0 = bc * TW;
     const int a_org = ((n * pOH + oy0) * pOW + ox0) * plddy, x_org = ((n * pH + oy0) * pW + ox0) * pldx;   // scalars
-    const int tmask = (en ? 0 : 31) | (oy0 == 0 ? 1 : 0) | (oy0 + TH == pH ? 2 : 0) | (ox0 == 0 ? 4 : 0) | (ox0 + TW == pW ? 8 : 0) | 16;
+    const int tmask = (en ? 0 : 63) | (oy0 == 0 ? 1 : 0) | (oy0 + TH == pH ? 2 : 0) | (ox0 == 0 ? 4 : 0) | (ox0 + TW == pW ? 8 : 0) | 16;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       dma16(dr, As + buf * 32 * 64 + (i * 256 + wave_base) * 4, (en && a_okc[i]) ? (unsigned)(a_org + a_rel[i]) * 4u : kOOB);

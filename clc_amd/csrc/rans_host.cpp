@@ -51,7 +51,9 @@ extern "C" int clc_get_tuning(int key) {
 // same float means / scales bit for bit.  kGeneration is bumped by hand whenever a kernel the codec path launches changes the order
 // in which it sums; the tuning keys that select between kernels of DIFFERENT order (kernel family limits, the reduced-precision mode,
 // the forward halves of the attention tiling, the diagnostic ablation) are folded in when they are off their defaults.
-extern "C" int clc_kernel_config_tag(void) {
+// (key 11 — K split of under-filled data gradients, with a threshold value — reaches TRANSPOSED launches only, i.e. backward passes: not an
+//  order key of the codec path.)
+static uint32_t clc_order_hash(bool* dflt_out) {
   const int kGeneration = 6;
   static const int order_keys[] = {0, 4, 5, 12, 14, 16};
   uint32_t h = 2166136261u ^ (uint32_t)kGeneration;
@@ -62,8 +64,17 @@ extern "C" int clc_kernel_config_tag(void) {
     if (v != d) dflt = false;
     h = (h ^ (uint32_t)v) * 16777619u;
   }
+  if (dflt_out) *dflt_out = dflt;
+  return h;
+}
+extern "C" int clc_kernel_config_tag(void) {
+  const int kGeneration = 6;
+  bool dflt = true;
+  const uint32_t h = clc_order_hash(&dflt);
   return dflt ? kGeneration : (int)(128u | (h & 127u));   // 1..127: default tuning of generation g; 128..255: a non-default order
 }
+// The full 32-bit hash behind a non-default tag (7 bits of it collide once in 128 states): version-2 containers carry it beside the tag.
+extern "C" unsigned clc_kernel_config_hash(void) { return clc_order_hash(nullptr); }
 
 namespace {
 constexpr int kPrec = 16, kBypassBits = 4;

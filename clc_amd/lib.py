@@ -93,6 +93,7 @@ SIGNATURES = {
     "clc_set_tuning": (_i, [_i, _i]),
     "clc_get_tuning": (_i, [_i]),
     "clc_kernel_config_tag": (_i, []),
+    "clc_kernel_config_hash": (C.c_uint, []),
     "clc_conv2d": (_i, [C.POINTER(ConvDesc), fp]),
     "clc_conv2d_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
     "clc_conv2d_wgrad_workspace_bytes": (_sz, [C.POINTER(WgradDesc)]),

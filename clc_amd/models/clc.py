@@ -319,14 +319,14 @@ class _SliceCodec(CompressionModel):
     # (tests/test_codec_service_gpu.py).  CLC_CODEC_GRAPH=0 keeps the eager path; batches > 1 always take it (the reference's y stream of a
     # batch is ONE joint stream, CLC_run.py:695-714, which the per-image engine does not produce).
     def _codec_stamp(self):
-        from ..codec import kernel_config_tag
+        from ..codec import kernel_config
 
         # (the Parameter / buffer OBJECTS are stable; walking the module tree for them costs 3 ms per call, their data_ptr()s 30 us)
         probe = self.__dict__.get("_codec_probe")
         if probe is None:
             ps = list(self.parameters())
             probe = self.__dict__["_codec_probe"] = (ps[::8], list(self.buffers()), len(ps))
-        return (kernel_config_tag(), probe[2], sum(q.data_ptr() for q in probe[0]), sum(b.data_ptr() for b in probe[1]),
+        return (kernel_config(), probe[2], sum(q.data_ptr() for q in probe[0]), sum(b.data_ptr() for b in probe[1]),
                 bool(getattr(self, "wire_clm", False)), getattr(self, "max_support_slices", None), getattr(self, "use_ref", None))
 
     def __getstate__(self):   # (copy.deepcopy / pickling of the model: the lazily built engine — graphs, a thread pool — stays behind)
@@ -358,7 +358,7 @@ class _SliceCodec(CompressionModel):
             eng = self._codec_engine(x)
             if eng is not None:
                 o = eng.compress(self._prep(x), ref_frames)[0]
-                return {"strings": o["strings"], "shape": o["shape"]}
+                return {"strings": o["strings"], "shape": o["shape"], "kernel_config": o["kernel_config"]}
         return self._compress_eager(x, ref_frames)
 
     @torch.no_grad()
@@ -389,7 +389,10 @@ class _SliceCodec(CompressionModel):
             sym_parts.append(sym)
             idx_parts.append(idx)
             y_hat_slices.append(self._refine(i, mean_support, y_hat_slice, ref_features))
-        return {"strings": [self._encode_y(sym_parts, idx_parts), z_strings], "shape": z.size()[-2:]}
+        from ..codec import kernel_config
+
+        # (`kernel_config`: beyond the reference's two keys — which kernel state encoded, for clc_amd.codec.pack_item)
+        return {"strings": [self._encode_y(sym_parts, idx_parts), z_strings], "shape": z.size()[-2:], "kernel_config": kernel_config()}
 
     def _encode_y(self, sym_parts, idx_parts):
         """Per-slice int32 symbol / index tensors (logical NCHW) -> [one y stream]: slices concatenated in order, element order

@@ -597,7 +597,7 @@ def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_
         nbytes = 4.0 * (N * H * W * Cin + Cout * ks * ks * Cin
                         + opix * Cout * (1 + (res is not None) + (mul is not None) + (y_pre is not None) + (out_gate is not None)))
         PROFILE.append(ProfRec("conv_igemm" if variant != 1 else "conv_direct_small", variant, 2.0 * pix * ks * ks * Cin * Cout, e0, e1,
-                               f"{'dgrad' if transposed else 'fwd'} {Cin}->{Cout} k{ks} s{stride} {N}x{H}x{W}" + (" +actbwd" if xs is not None else "")
+                               f"{'dgrad' if transposed else 'fwd'} {Cin}->{Cout} k{ks} s{stride} {N}x{H}x{W}" + (" +actbwd" if xs is not None else "") + (" +sq" if in_op == IN_SQUARE else "")
                                + "".join(t for t, on in ((" b", bias is not None), (f" a{act}", act != ACT_NONE), (" res", res is not None), (" mul", mul is not None),
                                                          (" pre", y_pre is not None), (" rg", res_gate is not None), (" og", out_gate is not None), (" w2", w2 is not None and wx is None), (" w4", wx is not None)) if on),
                                nbytes, relaunch=(lambda d=d, keep=keep: _lib.load().clc_conv2d(C.byref(d), _stream()))))
@@ -1725,7 +1725,8 @@ class _GDNParamFn(Function):
         dy, xx = dense(dy), dense(x)
         n = N * Cc * H * W
         # large 128-channel maps: the elementwise part, the gamma^T product and the combination in ONE launch (csrc/fused_mlp.hip: gdn_bwd_kernel; same bits)
-        fused = FUSED_GDN_BWD and nset == 1 and Cc == 128 and N * H * W >= FUSED_MLP_MIN_PIX and (N * H * W) % 32 == 0 and n * 4 < (1 << 31)
+        fused = FUSED_GDN_BWD and nset == 1 and Cc == 128 and N * H * W >= max(FUSED_MLP_MIN_PIX, 32768) and (N * H * W) % 32 == 0   # (clc_gdn_bwd_fused builds M >= 32 768 only, whatever CLC_FUSED_MLP_MIN says)
+        fused = fused and n * 4 < (1 << 31)
         dx = None
         if fused:
             dv, dx = new_act(N, Cc, H, W, x), new_act(N, Cc, H, W, x)

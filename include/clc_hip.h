@@ -45,6 +45,9 @@ int clc_get_tuning(int key);
  * when any is off its default.  A stream decodes only under the tag it was encoded with (the slice loop is autoregressive through
  * the arithmetic decoder: CLC_run.py:738-814 has the same property across devices and records nothing). */
 int clc_kernel_config_tag(void);
+/* ... and the full 32-bit hash of the same state (generation + order-affecting keys): containers written under a NON-default state (tag >= 128,
+ * 7 hash bits) carry it too, so that two such states cannot be mistaken for each other (clc_amd/codec.py, header version 2). */
+unsigned clc_kernel_config_hash(void);
 
 /* ---- activation / epilogue codes ---------------------------------------------------- */
 enum { CLC_ACT_NONE = 0, CLC_ACT_LRELU = 1, CLC_ACT_RELU = 2, CLC_ACT_GELU = 3, CLC_ACT_HALFTANH = 4 /* 0.5*tanh(v), LRP head */,

@@ -186,3 +186,39 @@ def test_container_header_errors_and_kernel_tag():
         finally:
             L.clc_set_tuning(key, prev)
     assert codec.kernel_config_tag() == tag and L.clc_get_tuning(16) == 3
+    # the state is captured WHEN THE KERNELS RAN (compress() returns it as `kernel_config`), not when pack() is called: an image encoded
+    # under a temporary non-default state and packed after the default was restored carries the encoding state — as a version-2 header
+    # with the full 32-bit hash beside the 7-bit tag (two non-default states cannot be mistaken for each other)
+    default_cfg = codec.kernel_config()
+    assert default_cfg[0] == tag
+    prev = L.clc_set_tuning(14, 1)
+    try:
+        cfg_a = codec.kernel_config()
+    finally:
+        L.clc_set_tuning(14, prev)
+    prev = L.clc_set_tuning(4, 256)
+    try:
+        cfg_b = codec.kernel_config()
+    finally:
+        L.clc_set_tuning(4, prev)
+    assert cfg_a[0] >= 128 and cfg_b[0] >= 128 and cfg_a[1] != cfg_b[1] and cfg_a[1] != default_cfg[1]
+    item = {"strings": [[b"yyyy"], [b"zz"]], "shape": (4, 4), "kernel_config": cfg_a}
+    blob2 = codec.pack_item(item, (256, 256), n_refs=1)           # packed under the DEFAULT state, encoded under state a
+    assert blob2[4] == 2 and len(blob2) == 28 + 6 and blob[4] == 1 and len(blob) == 24 + 6
+    with pytest.raises(codec.KernelConfigMismatch):
+        codec.unpack(blob2)
+    _, _, m3 = codec.unpack(blob2, strict=False)
+    assert m3["kernel_config_tag"] == cfg_a[0] and m3["kernel_config_hash"] == cfg_a[1] and not m3["same_kernel_config"]
+    prev = L.clc_set_tuning(14, 1)
+    try:
+        s4, _, m4 = codec.unpack(blob2)                           # decodes under the state that encoded
+        assert s4 == item["strings"] and m4["same_kernel_config"]
+        # same 7-bit tag, other hash -> refused (forged: state b's hash under state a's tag)
+        forged = blob2[:24] + cfg_b[1].to_bytes(4, "little") + blob2[28:]
+        with pytest.raises(codec.KernelConfigMismatch):
+            codec.unpack(forged)
+    finally:
+        L.clc_set_tuning(14, prev)
+    for bad in (blob2[:27], blob2 + b"!"):
+        with pytest.raises(ValueError):
+            codec.unpack(bad, strict=False)
