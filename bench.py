@@ -410,6 +410,8 @@ def transforms_leg(model, x, refs, engine=None):
     cached = engine is not None and getattr(engine, "transposer", None) is not None
     if cached:
         engine.transposer.refresh()
+        if getattr(engine, "halo_packer", None) is not None:
+            engine.halo_packer.refresh()
         engine.gdn_cache.refresh()
     for name, fwd in cases.items():
         with torch.no_grad():

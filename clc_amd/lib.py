@@ -33,7 +33,7 @@ class ConvDesc(C.Structure):
                 ("res_gate", fp), ("ldg", C.c_int), ("res_gate_act", C.c_int), ("res_gate_pre", C.c_int),
                 ("out_gate", fp), ("ldog", C.c_int), ("out_gate_act", C.c_int), ("out_gate_pre", C.c_int),
                 ("w3", fp), ("bias3", fp), ("w4", fp), ("bias4", fp),
-                ("workspace", fp), ("workspace_bytes", C.c_size_t), ("batch_variant_ok", C.c_int)]
+                ("workspace", fp), ("workspace_bytes", C.c_size_t), ("batch_variant_ok", C.c_int), ("w_packed", fp)]
 
 
 class WgradDesc(C.Structure):
@@ -75,6 +75,10 @@ class TransposeEntry(C.Structure):
     _fields_ = [("w", fp), ("wt", fp), ("Cout", C.c_int), ("T", C.c_int), ("Cin", C.c_int), ("tile_begin", C.c_int)]
 
 
+class HaloPackEntry(C.Structure):
+    _fields_ = [("w", fp), ("out", fp), ("N", C.c_int), ("block_begin", C.c_int)]
+
+
 class ReduceEntry(C.Structure):
     _fields_ = [("partial", fp), ("nblocks", C.c_int), ("n", C.c_int), ("out0", fp), ("out1", fp), ("split", C.c_int), ("accumulate", C.c_int)]
 
@@ -104,6 +108,8 @@ SIGNATURES = {
     "clc_conv2d_wgrad_variant": (_i, [C.POINTER(WgradDesc)]),
     "clc_conv2d_wgrad_batched_sk": (_i, [C.POINTER(WgradDesc), _i, fp, _sz, fp]),
     "clc_filter_transpose": (_i, [fp, fp, _i, _i, _i, fp]),
+    "clc_filter_pack_halo": (_i, [fp, fp, _i, fp]),
+    "clc_filter_pack_halo_batched": (_i, [fp, _i, _i, fp]),
     "clc_filter_transpose_batched": (_i, [fp, _i, _i, fp]),
     "clc_partial_reduce_batched": (_i, [C.POINTER(ReduceEntry), _i, fp]),
     "clc_act_bwd": (_i, [fp, _i, fp, _i, _i, _i, fp, _i, _l, _i, fp]),

@@ -517,10 +517,51 @@ def to_kernel_weight(w: torch.Tensor) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------ conv
 
 
+# ---- halo-resident 3x3 kernel (csrc/conv_halo.hip): the filter is ALSO needed in fragment order.  Where the packed image comes from:
+#   * inside a TrainEngine step (WT_CACHE_VALID): one batched launch per step packs every eligible filter and transposed filter
+#     (clc_amd.train.HaloPacker -> w._clc_hpk / w._clc_hpk_t), like the transposed images themselves;
+#   * anywhere else: packed on first use and cached on the parameter, keyed by (its version counter, its storage, WEIGHTS_EPOCH) —
+#     torch optimizers bump the version, TrainEngine (whose kernels update the arena through raw pointers) bumps WEIGHTS_EPOCH per step.
+HALO = os.environ.get("CLC_HALO", "1") != "0"
+WEIGHTS_EPOCH = 0
+
+
+def halo_ok(N, H, W, Cin, rows, ks, stride):
+    """may a [rows][3][3][Cin] filter on an N x H x W map take the halo kernel?  (the C side re-checks everything and falls through)"""
+    return (HALO and ks == 3 and stride == 1 and Cin == 128 and rows % 128 == 0 and H % 8 == 0 and W % 16 == 0
+            and N * (H // 8) * (W // 16) * (rows // 128) >= 128)
+
+
+def halo_pack(wk, rows):
+    """[rows][9][128] filter rows (K-contiguous) -> fragment order (clc_filter_pack_halo)."""
+    out = torch.empty(rows * 9 * 128, device=wk.device, dtype=torch.float32)
+    _lib.check(_L().clc_filter_pack_halo(wk.data_ptr(), out.data_ptr(), int(rows), _stream()), "clc_filter_pack_halo")
+    return out
+
+
+def halo_packed(w, transposed_image=None):
+    """packed image of parameter `w`'s forward filter, or (transposed_image given: the [Cin][9][Cout] image of this step) of its transposed one"""
+    if WT_CACHE_VALID:
+        pk = getattr(w, "_clc_hpk_t" if transposed_image is not None else "_clc_hpk", None)
+        if pk is not None:
+            return pk
+    if transposed_image is not None:     # (a fresh transpose per backward pass outside the engine: packed per use)
+        return halo_pack(transposed_image, transposed_image.shape[0])
+    key = (w._version, w.data_ptr(), WEIGHTS_EPOCH)
+    c = getattr(w, "_clc_hpk_cache", None)
+    if c is not None and c[0] == key:
+        return c[1]
+    pk = halo_pack(to_kernel_weight(w), w.shape[0])
+    w._clc_hpk_cache = (key, pk)
+    return pk
+
+
 def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_NONE, norm=NORM_NONE, mul=None,
              res=None, res_scale=1.0, res_first=False, y_pre=None, shuffle=False, transposed=False, out=None, out_hw=None,
-             xs=None, xs_act=ACT_NONE, xs_pre=False, w2=None, bias2=None, pre_deriv=False, res_gate=None, out_gate=None, wx=None, batch_variant_ok=False):
+             xs=None, xs_act=ACT_NONE, xs_pre=False, w2=None, bias2=None, pre_deriv=False, res_gate=None, out_gate=None, wx=None, batch_variant_ok=False,
+             wpk=None):
     """One clc_conv2d launch. ``w`` must already be in kernel layout [Cout][ks][ks][Cin].
+    wpk: the same filter in the halo kernel's fragment order (halo_packed / halo_pack), or None.
     batch_variant_ok: the summation order may depend on the batch size (training forward passes only, never the codec path).
     wx: ((w3, bias3), (w4, bias4)) — with (w2, bias2), four filter sets on the four quarters of the batch."""
     _require_gpu(x, "conv2d")
@@ -578,6 +619,9 @@ def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_
         d.xs, d.ldxs, d.xs_act, d.xs_pre = xsp, ldxs, xs_act, int(xs_pre)
         keep.append(xs_t)
     d.batch_variant_ok = int(bool(batch_variant_ok))
+    if wpk is not None:   # the same filter in conv_halo3x3_kernel's fragment order: clc_conv2d takes that kernel when the launch qualifies
+        d.w_packed = wpk.data_ptr()
+        keep.append(wpk)
     if (transposed and H * W <= 1024) or (batch_variant_ok and ks == 3 and OH * OW <= 256):   # scratch for the K split of under-filled grids (0 bytes: no split)
         nws = _lib.load().clc_conv2d_workspace_bytes(C.byref(d))
         if nws:
@@ -787,8 +831,9 @@ class _ConvFn(Function):
         # GELU: the epilogue stores gelu'(v) (it has v in a register) instead of v, so the backward is one multiply inside
         # the gradient kernels' loaders — no erf/exp there and no elementwise dz pass
         deriv = save_pre and act == ACT_GELU
+        wpk = halo_packed(w) if (w2 is None and halo_ok(N, H, W, w.shape[1], Cout, ks, stride) and wk is w) else None
         y = conv_raw(x, wk, b, ks=ks, stride=stride, act=act, res=res, res_scale=res_scale, res_first=res_first, y_pre=y_pre, shuffle=shuffle,
-                     w2=wk2, bias2=b2, pre_deriv=deriv, out=out_buf, wx=wkx, batch_variant_ok=need_grad)
+                     w2=wk2, bias2=b2, pre_deriv=deriv, out=out_buf, wx=wkx, batch_variant_ok=need_grad, wpk=wpk)
         if out_buf is not None:   # written in place into the caller's (strided) buffer: hand autograd a fresh alias of it
             y = out_buf.detach()
         ctx.cfg = (ks, stride, ACT_SAVED_DERIV if deriv else act, res_scale, shuffle, b is not None, res is not None, res_first)
@@ -910,9 +955,12 @@ class _ConvFn(Function):
                 # this layer is the only consumer of the producer's activated output: hand it d(pre-activation)
                 og = (gate_in.saved, gate_in.act, gate_in.pre)
                 gate_in.done = True
-            dx = conv_raw(dz, wt_of(w), None, ks=ks, stride=stride, pad=pad, transposed=True, out_hw=(x.shape[2], x.shape[3]),
+            wt1 = wt_of(w)
+            # (data gradient of a 128 -> 128 layer: rows = Cin, K = 9 x Cout = 9 x 128)
+            wpk = (halo_packed(w, wt1) if (w2 is None and not fa and halo_ok(dz.shape[0], dz.shape[2], dz.shape[3], Cout, Cin, ks, stride)) else None)
+            dx = conv_raw(dz, wt1, None, ks=ks, stride=stride, pad=pad, transposed=True, out_hw=(x.shape[2], x.shape[3]),
                           w2=(wt_of(w2) if w2 is not None else None), wx=(((wt_of(w3), None), (wt_of(w4), None)) if w3 is not None else None),
-                          res=extra, res_scale=extra_scale, res_gate=gate, out=dx_out, out_gate=og, **fa)
+                          res=extra, res_scale=extra_scale, res_gate=gate, out=dx_out, out_gate=og, wpk=wpk, **fa)
         elif fold_in is not None:
             fold_in.consumed = True
         if dx is not None and ctx.park_dx is not None and ctx.park_dx.park(dx):

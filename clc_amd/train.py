@@ -267,6 +267,43 @@ class FilterTransposer:
             _lib.check(ops._L().clc_filter_transpose_batched(self.table.data_ptr(), self.n, self.total_tiles, ops._stream()), "clc_filter_transpose_batched")
 
 
+class HaloPacker:
+    """Fragment-order images of the filters the halo-resident 3x3 kernel takes (csrc/conv_halo.hip: [k * 128, 128, 3, 3] forward; the
+    transposed image of the [128, 128, 3, 3] ones for their data gradients), refreshed by ONE launch per step
+    (clc_filter_pack_halo_batched) right behind the batched transpose, whose output it reads.  ops.halo_packed() hands them out while
+    ops.WT_CACHE_VALID is set."""
+
+    def __init__(self, params: List[nn.Parameter]):
+        ws = [p for p in params if p.dim() == 4 and tuple(p.shape[2:]) == (3, 3) and getattr(p, "_clc_is_filter", False) and ops.HALO
+              and p.shape[1] == 128 and p.shape[0] % 128 == 0 and ops.to_kernel_weight(p) is p]
+        jobs = []   # (source tensor, rows, attribute)
+        for p in ws:
+            jobs.append((p, p, p.shape[0], "_clc_hpk"))
+            wt = getattr(p, "_clc_wt", None)
+            if p.shape[0] == 128 and wt is not None:    # [Cin = 128][9][Cout = 128]: rows = Cin
+                jobs.append((p, wt, p.shape[1], "_clc_hpk_t"))
+        self.n = len(jobs)
+        if not jobs:
+            return
+        dev = ws[0].device
+        total = sum(rows * 9 * 128 for _, _, rows, _ in jobs)
+        self.buf = torch.empty(total, dtype=torch.float32, device=dev)
+        entries, off, blocks = [], 0, 0
+        for p, src, rows, attr in jobs:
+            n = rows * 9 * 128
+            out = self.buf[off: off + n]
+            off += n
+            setattr(p, attr, out)
+            entries.append(_lib.HaloPackEntry(src.data_ptr(), out.data_ptr(), int(rows), blocks))
+            blocks += (n // 4 + 255) // 256
+        self.total_blocks = blocks
+        self.table = torch.frombuffer(bytearray(b"".join(bytes(e) for e in entries)), dtype=torch.uint8).to(dev)
+
+    def refresh(self):
+        if self.n:
+            _lib.check(ops._L().clc_filter_pack_halo_batched(self.table.data_ptr(), self.n, self.total_blocks, ops._stream()), "clc_filter_pack_halo_batched")
+
+
 class GDNReparamCache:
     """The effective (re-parametrised) gamma / beta of every GDN module — and gamma transposed for the data-gradient conv — refreshed by ONE
     launch per step (clc_gdn_reparam_fwd_batched) instead of one launch per module inside the forward pass.  Like the transposed filter
@@ -360,6 +397,7 @@ class TrainEngine:
         self.opt = self._make_opt(live, self.lr, self.clip)
         self.aux_opt = self._make_opt(aux, self.aux_lr, 0.0)
         self.transposer = FilterTransposer(live)
+        self.halo_packer = HaloPacker(live)
         self.gdn_cache = GDNReparamCache(self.model, live)
         cut = self.opt.p_arena.offsets[len(late)] if (late and early) else 0
         n_el = self.opt.grad_flat.numel()
@@ -385,6 +423,7 @@ class TrainEngine:
         self.opt.zero_grad()
         self.aux_opt.zero_grad()
         self.transposer.refresh()
+        self.halo_packer.refresh()
         self.gdn_cache.refresh()
         ops.WT_CACHE_VALID = True      # (the transposed filter images are this step's: see ops.WT_CACHE_VALID)
         try:
@@ -401,6 +440,7 @@ class TrainEngine:
         self.opt.zero_grad()
         self.aux_opt.zero_grad()
         self.transposer.refresh()
+        self.halo_packer.refresh()
         self.gdn_cache.refresh()
         self.model._keep_boundary = True
         ops.WT_CACHE_VALID = True
@@ -503,6 +543,7 @@ class TrainEngine:
             set_precision(old)
 
     def _step(self, x, refs=None):
+        ops.WEIGHTS_EPOCH += 1   # this engine's kernels update the parameters through raw pointers (no version-counter bump): cached images keyed on it go stale
         refs = list(refs) if refs is not None else None
         if self.opt is None:
             self._discover(x, refs)

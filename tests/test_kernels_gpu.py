@@ -5,6 +5,7 @@ reference is summation order): rel 2e-5 of the output scale for forward, 1e-4 fo
 (long split-K reductions).  Integer outputs (symbols / indexes) must be bit-exact.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -1182,3 +1183,69 @@ def test_16_column_kernel_for_the_few_channel_tail(dev, N, Cin, H, W, Cout, shuf
     _close(outs[1], want, 2e-5, "n16 kernel vs torch")
     _close(outs[1], outs[0], 4e-6, "n16 kernel vs the 32-column kernel")
     assert torch.equal(one, outs[1][:1]), "an image's bits depend on the batch"
+
+
+@pytest.mark.parametrize("N,H,W,Cout,mode", [(8, 64, 64, 128, "plain"), (2, 128, 128, 128, "lrelu_res"), (8, 32, 32, 512, "shuffle_lrelu"), (2, 64, 64, 512, "shuffle"),
+                                             (8, 64, 64, 128, "dgrad_gate"), (12, 40, 48, 128, "plain"), (1, 256, 256, 128, "pre"), (8, 128, 128, 128, "plain")])
+def test_halo_conv_same_bits_as_tiled(dev, N, H, W, Cout, mode):
+    """conv_halo3x3_kernel (csrc/conv_halo.hip: 3x3 / stride 1 / 128 input channels; input halo resident in LDS, filter streamed from L2 in
+    fragment order, no barrier in the K loop) against the LDS-tiled kernels on the same launch: THE SAME BITS — forward with bias /
+    LeakyReLU / residual / saved pre-activation epilogues, the PixelShuffle store of the sub-pixel convolutions
+    (/root/reference/models/CLC_run.py:28-30 via compressai.layers.subpel_conv3x3), and the data gradient of a 128 -> 128 layer with the
+    consumer-side activation gate; image borders, a map that is not a power of two, and a workgroup that walks several tiles."""
+    from clc_amd import lib, ops
+    from clc_amd.ops import ACT_LRELU, ACT_NONE
+
+    L = lib.load()
+    g = torch.Generator().manual_seed(N * 1000 + H + Cout)
+    x = _dev(torch.randn(N, 128, H, W, generator=g), dev)
+    w = (torch.randn(Cout, 128, 3, 3, generator=g) * 0.05).to(dev).contiguous(memory_format=CL)
+    b = (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    wk = ops.to_kernel_weight(w)
+    assert ops.halo_ok(N, H, W, 128, Cout, 3, 1)
+    kw = dict(ks=3, stride=1)
+    if mode == "plain":
+        kw.update(bias=b)
+    elif mode == "lrelu_res":
+        kw.update(bias=b, act=ACT_LRELU, res=_dev(torch.randn(N, Cout, H, W, generator=g), dev), res_scale=0.5)
+    elif mode == "pre":
+        kw.update(bias=b, act=ACT_LRELU, res=_dev(torch.randn(N, Cout, H, W, generator=g), dev), y_pre=ops.new_act(N, Cout, H, W, x))
+    elif mode == "shuffle_lrelu":
+        kw.update(bias=b, act=ACT_LRELU, shuffle=True)
+    elif mode == "shuffle":
+        kw.update(bias=b, shuffle=True)
+    if mode == "dgrad_gate":
+        wt = ops.filter_transpose(wk, Cout, 9, 128).view(128, -1)
+        gate = _dev(torch.randn(N, 128, H, W, generator=g), dev)
+        run = lambda wpk: ops.conv_raw(x, wt, None, ks=3, stride=1, pad=1, transposed=True, out_hw=(H, W), out_gate=(gate, ACT_LRELU, False),
+                                       res=_dev(torch.ones(N, 128, H, W), dev), res_scale=0.25, wpk=wpk)
+        pk = ops.halo_pack(wt, 128)
+    else:
+        run = lambda wpk: ops.conv_raw(x, wk, kw.get("bias"), **{k: v for k, v in kw.items() if k != "bias"}, wpk=wpk)
+        pk = ops.halo_pack(wk, Cout)
+    ops.PROFILE = []
+    try:
+        y_halo = run(pk).clone()
+        pre_halo = kw["y_pre"].clone() if "y_pre" in kw else None
+        y_tiled = run(None).clone()
+        torch.cuda.synchronize()
+        variants = [r.variant >> 20 for r in ops.PROFILE if r.fam == "conv_igemm"]
+    finally:
+        ops.PROFILE = None
+    assert variants[0] == 12 and variants[1] != 12, variants          # the halo kernel ran, then a tiled one
+    assert torch.equal(y_halo, y_tiled), f"max diff {(y_halo - y_tiled).abs().max().item():.3e}"
+    if pre_halo is not None:
+        assert torch.equal(pre_halo, kw["y_pre"])
+    # ... and against torch for the plain forward (the tiled kernels are held to torch by test_conv_fwd_bwd)
+    if mode == "plain":
+        ref = F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=1)
+        _close(y_halo, ref, 2e-5, f"halo conv {N}x{H}x{W} -> {Cout}")
+    # the tuning key switches it off
+    old = L.clc_set_tuning(22, 0)
+    try:
+        ops.PROFILE = []
+        run(pk)
+        assert (ops.PROFILE[0].variant >> 20) != 12
+    finally:
+        ops.PROFILE = None
+        L.clc_set_tuning(22, old)

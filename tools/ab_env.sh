@@ -7,7 +7,7 @@ N=$1; NAME=$2; shift 2
 mkdir -p gpurun_out/ab
 for i in $(seq 1 $N); do
   for v in "$@"; do
-    env $NAME=$v timeout -k 10 200 python bench.py --steps 30 --warmup 5 --no-roofline --no-cpu-baseline --no-reduced --no-parity > gpurun_out/ab/step.json 2> gpurun_out/ab/step.err || { tail -20 gpurun_out/ab/step.err; exit 1; }
+    env $NAME=$v timeout -k 10 200 python bench.py --steps 30 --warmup 5 --no-roofline --no-cpu-baseline --no-reduced --no-reference-loop --no-parity > gpurun_out/ab/step.json 2> gpurun_out/ab/step.err || { tail -20 gpurun_out/ab/step.err; exit 1; }
     python - <<PY
 import json
 d=json.loads(open("gpurun_out/ab/step.json").read().strip().splitlines()[-1])

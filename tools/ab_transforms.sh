@@ -6,7 +6,7 @@ cd $R
 mkdir -p gpurun_out/ab
 for i in 1 2; do
 for v in "$@"; do
-  CLC_TUNING=$v timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-reduced --no-parity > gpurun_out/ab/t.json 2> gpurun_out/ab/t.err || { tail -20 gpurun_out/ab/t.err; exit 1; }
+  CLC_TUNING=$v timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-reduced --no-reference-loop --no-parity > gpurun_out/ab/t.json 2> gpurun_out/ab/t.err || { tail -20 gpurun_out/ab/t.err; exit 1; }
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/ab/t.json").read().strip().splitlines()[-1])

@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT}
 cd $R; mkdir -p gpurun_out
 run() {
   name=$1; shift
-  timeout -k 10 400 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-reduced --no-parity "$@" > gpurun_out/${tag}_bench_$name.json 2> gpurun_out/${tag}_bench_$name.err || { echo "bench [$name] failed"; tail -5 gpurun_out/${tag}_bench_$name.err; return 1; }
+  timeout -k 10 400 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-reduced --no-reference-loop --no-parity "$@" > gpurun_out/${tag}_bench_$name.json 2> gpurun_out/${tag}_bench_$name.err || { echo "bench [$name] failed"; tail -5 gpurun_out/${tag}_bench_$name.err; return 1; }
   python - gpurun_out/${tag}_bench_$name.json "$name" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}
 O=$R/gpurun_out/${tag}kt
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o $tag -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-parity --no-reduced > $O/kt.log 2>&1 || { echo "kernel-trace failed"; tail -5 $O/kt.log; exit 4; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o $tag -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-parity --no-reduced --no-reference-loop > $O/kt.log 2>&1 || { echo "kernel-trace failed"; tail -5 $O/kt.log; exit 4; }
 db=$(find $O/kt -name "*results.db" | head -1)
 python3 $R/tools/prof_db.py stats $db --md $O/kernel_stats.md --csv $O/kernel_stats.csv > /dev/null || { echo "kernel stats summary failed"; exit 4; }
 python3 $R/tools/prof_db.py step $db --top 120 > $O/step_timeline.txt || { echo "timeline summary failed"; exit 4; }

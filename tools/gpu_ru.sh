@@ -10,7 +10,7 @@ timeout -k 10 200 python tools/bench_ru.py > gpurun_out/ru/micro.log 2>&1 || { t
 cat gpurun_out/ru/micro.log
 for i in 1 2; do
   for v in 0 1; do
-    CLC_FUSED_RU=$v timeout -k 10 200 python bench.py --steps 30 --warmup 5 --no-roofline --no-cpu-baseline --no-reduced --no-parity > gpurun_out/ru/step_${v}_$i.json 2> gpurun_out/ru/step_${v}_$i.err || { tail -20 gpurun_out/ru/step_${v}_$i.err; exit 1; }
+    CLC_FUSED_RU=$v timeout -k 10 200 python bench.py --steps 30 --warmup 5 --no-roofline --no-cpu-baseline --no-reduced --no-reference-loop --no-parity > gpurun_out/ru/step_${v}_$i.json 2> gpurun_out/ru/step_${v}_$i.err || { tail -20 gpurun_out/ru/step_${v}_$i.err; exit 1; }
     python - <<PY
 import json
 d=json.loads(open("gpurun_out/ru/step_${v}_$i.json").read().strip().splitlines()[-1])
