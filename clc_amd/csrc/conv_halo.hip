@@ -238,6 +238,12 @@ int clc_conv_halo_launch(const void* conv_params, const float* wpk, hipStream_t 
   hp.items = p.N * (p.H / TH) * (p.W / TW) * hp.ntn;
   hp.wpk_bytes = (unsigned)((size_t)p.Cout * 9 * CIN * 4);
   if (hp.items < 128) return 0;   // a quarter-filled chip: the 64 x 64 tiles do better
+  // Data gradients whose workgroups each walk several pixel tiles (128 -> 128 on 8 x 128 x 128: 1024 tiles): every tile boundary is a halo
+  // deposit all 256 workgroups make at once (6-8 us of a 61-us tile) plus an epilogue with gate / residual operands that only two waves per
+  // SIMD overlap — measured inside the step 316 / 345 us against 301 / 311 on the tiled kernel (forward launches of the same shape: 293
+  // against 307).  A double-buffered variant with a dedicated loader wave (4 x 16 tiles, nine waves) was built to hide the deposit and
+  // measured SLOWER everywhere (profiles/r5_halo_v2_loader_wave_microbench.txt): shorter items, more restarts of the operand pipeline.
+  if (p.transposed && hp.items >= 1024) return 0;
   int ncu = 256;
   const int grid = hp.items < ncu ? hp.items : ncu;
   static PerDeviceOnce once[4];
