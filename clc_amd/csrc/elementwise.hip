@@ -395,6 +395,46 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
   }
   if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + scale * sm[0];
 }
+// The scalar tail of the rate-distortion loss (train_CLC.py:43-59) in ONE launch: the three fixed-order sums (sum_partials_kernel's tree: the
+// same bits as three clc_sum_partials calls) and the arithmetic the reference writes as tensor expressions, rounding step by rounding step:
+//   bpp = (0 + s_y + s_z) / (-num_pixels);  mse = sq / numel;  loss = float(lmbda * 255^2) * mse + bpp
+__device__ __forceinline__ float block_sum_256(const float* __restrict__ p, int n, float* sm) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += p[i];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float r = sm[0];
+  __syncthreads();
+  return r;
+}
+__global__ __launch_bounds__(256) void rd_combine_kernel(const float* __restrict__ py, int ny, const float* __restrict__ pz, int nz, const float* __restrict__ psq, int nsq,
+                                                         float neg_num_pixels, float numel, float c, float* bpp, float* mse, float* loss) {
+  __shared__ float sm[256];
+  const float sy = block_sum_256(py, ny, sm), sz = block_sum_256(pz, nz, sm), sq = block_sum_256(psq, nsq, sm);
+  if (threadIdx.x == 0) {
+    const float b = (sy + sz) / neg_num_pixels;
+    const float m = sq / numel;
+    const float cm = c * m;
+    bpp[0] = b;
+    mse[0] = m;
+    loss[0] = cm + b;
+  }
+}
+// ... and of its backward: the device scalars the three gradient kernels take (g_* may be NULL = no gradient arrived for that output)
+__global__ void rd_grad_scalars_kernel(const float* g_bpp, const float* g_mse, const float* g_loss, float neg_num_pixels, float numel, float c, float* g_logsum, float* g_sq) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float gl = g_loss ? g_loss[0] : 0.f;
+  float gb = gl;                       // d loss / d bpp = 1
+  if (g_bpp) gb = gb + g_bpp[0];
+  float gm = gl * c;                   // MulBackward
+  if (g_mse) gm = gm + g_mse[0];
+  g_logsum[0] = gb / neg_num_pixels;   // DivBackward
+  g_sq[0] = gm / numel;
+}
 __global__ __launch_bounds__(256) void sqdiff_partials_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, float* __restrict__ partials) {
   __shared__ float sm[256];
   float s = 0.f;
@@ -810,6 +850,20 @@ extern "C" int clc_copy2d(const float* src, int lds, float* dst, int ldd, long r
 extern "C" int clc_sum_partials(const float* partials, int n, float scale, float* out, int accumulate, clc_stream_t stream) {
   CLC_CHECK(partials && out && n > 0, "clc_sum_partials: bad args");
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ST, partials, n, scale, out, accumulate);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int clc_rd_combine(const float* py, int ny, const float* pz, int nz, const float* psq, int nsq, float neg_num_pixels, float numel, float c,
+                              float* bpp, float* mse, float* loss, clc_stream_t stream) {
+  CLC_CHECK(py && pz && psq && ny > 0 && nz > 0 && nsq > 0 && bpp && mse && loss && neg_num_pixels < 0.f && numel > 0.f, "clc_rd_combine: bad args");
+  hipLaunchKernelGGL(rd_combine_kernel, dim3(1), dim3(256), 0, ST, py, ny, pz, nz, psq, nsq, neg_num_pixels, numel, c, bpp, mse, loss);
+  CLC_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int clc_rd_grad_scalars(const float* g_bpp, const float* g_mse, const float* g_loss, float neg_num_pixels, float numel, float c, float* g_logsum,
+                                   float* g_sq, clc_stream_t stream) {
+  CLC_CHECK(g_logsum && g_sq && neg_num_pixels < 0.f && numel > 0.f, "clc_rd_grad_scalars: bad args");
+  hipLaunchKernelGGL(rd_grad_scalars_kernel, dim3(1), dim3(64), 0, ST, g_bpp, g_mse, g_loss, neg_num_pixels, numel, c, g_logsum, g_sq);
   CLC_LAUNCH_CHECK();
   return 0;
 }

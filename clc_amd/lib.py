@@ -152,6 +152,8 @@ SIGNATURES = {
     "clc_scaled_recip": (_i, [fp, _i, _l, _i, fp, _f, fp, _i, fp]),
     "clc_scaled_diff": (_i, [fp, fp, _l, fp, _f, fp, fp]),
     "clc_sum_partials": (_i, [fp, _i, _f, fp, _i, fp]),
+    "clc_rd_combine": (_i, [fp, _i, fp, _i, fp, _i, _f, _f, _f, fp, fp, fp, fp]),
+    "clc_rd_grad_scalars": (_i, [fp, fp, fp, _f, _f, _f, fp, fp, fp]),
     "clc_sqdiff_partials": (_i, [fp, fp, _l, fp, _i, fp]),
     "clc_clm_sim_colsum_workspace_bytes": (_sz, [_i, _i]),
     "clc_clm_sim_colsum": (_i, [fp, _i, fp, _i, _i, _i, _i, _f, fp, fp, _sz, fp]),

@@ -2222,6 +2222,58 @@ def sqdiff_sum(a, b):
     return _SqDiffSumFn.apply(a, b)
 
 
+class _RDLossMseFn(Function):
+    """(bpp_loss, mse_loss, loss) of the reference's RateDistortionLoss in its MSE form (/root/reference/train_CLC.py:43-59):
+        bpp = (sum log2 lik_y + sum log2 lik_z) / (-num_pixels);  mse = mean (x_hat - x)^2;  loss = lmbda * 255^2 * mse + bpp
+    as 4 launches forward (three partial-sum passes + clc_rd_combine) and 4 backward, instead of 6 reduction launches + 5 scalar tensor
+    expressions forward and their autograd nodes backward.  Every rounding step of the reference's expressions is kept (see
+    rd_combine_kernel): the same bits as the chain of ops it replaces."""
+
+    @staticmethod
+    def forward(ctx, lik_y, lik_z, x_hat, target, lmbda, num_pixels):
+        L, st = _L(), _stream()
+        parts = []
+        for lik in (lik_y, lik_z):
+            lk, lp, N, H, W, Cc, ld = nhwc(lik)
+            rows = N * H * W
+            nb = max(1, min(1024, (rows * Cc + 1023) // 1024))
+            part = torch.empty(nb, device=lk.device, dtype=torch.float32)
+            _lib.check(L.clc_log2_sum_partials(lp, ld, rows, Cc, part.data_ptr(), nb, st), "clc_log2_sum_partials")
+            parts.append((part, nb, lk))
+        a, b = dense(x_hat), dense(target)
+        n = a.numel()
+        nb = max(1, min(1024, (n + 4095) // 4096))
+        psq = torch.empty(nb, device=a.device, dtype=torch.float32)
+        _lib.check(L.clc_sqdiff_partials(a.data_ptr(), b.data_ptr(), n, psq.data_ptr(), nb, st), "clc_sqdiff_partials")
+        out = [torch.empty(1, device=a.device, dtype=torch.float32) for _ in range(3)]
+        ctx.consts = (float(-num_pixels), float(n), float(lmbda * 255 ** 2))
+        _lib.check(L.clc_rd_combine(parts[0][0].data_ptr(), parts[0][1], parts[1][0].data_ptr(), parts[1][1], psq.data_ptr(), nb, *ctx.consts,
+                                    out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), st), "clc_rd_combine")
+        ctx.save_for_backward(parts[0][2], parts[1][2], a, b)
+        return tuple(o.reshape(()) for o in out)
+
+    @staticmethod
+    def backward(ctx, g_bpp, g_mse, g_loss):
+        ly, lz, a, b = ctx.saved_tensors
+        L, st = _L(), _stream()
+        gs = torch.empty(2, device=a.device, dtype=torch.float32)
+        ptr = lambda g: (g.contiguous().data_ptr() if g is not None else None)
+        _lib.check(L.clc_rd_grad_scalars(ptr(g_bpp), ptr(g_mse), ptr(g_loss), *ctx.consts, gs.data_ptr(), gs.data_ptr() + 4, st), "clc_rd_grad_scalars")
+        grads = []
+        for lik in (ly, lz):
+            lk, lp, N, H, W, Cc, ld = nhwc(lik)
+            d = new_act(N, Cc, H, W, lk)
+            _lib.check(L.clc_scaled_recip(lp, ld, N * H * W, Cc, gs.data_ptr(), 1.0 / math.log(2.0), d.data_ptr(), Cc, st), "clc_scaled_recip")
+            grads.append(d)
+        dx = new_act(*a.shape, a)
+        _lib.check(L.clc_scaled_diff(a.data_ptr(), b.data_ptr(), a.numel(), gs.data_ptr() + 4, 2.0, dx.data_ptr(), st), "clc_scaled_diff")
+        return grads[0], grads[1], dx, None, None, None
+
+
+def rd_loss_mse(lik_y, lik_z, x_hat, target, lmbda, num_pixels):
+    return _RDLossMseFn.apply(lik_y, lik_z, x_hat, target, lmbda, num_pixels)
+
+
 # ------------------------------------------------------------------------------------- MS-SSIM
 
 

@@ -30,6 +30,7 @@ from . import ops
 
 
 # ------------------------------------------------------------------------------------------ loss
+FUSED_RD_LOSS = os.environ.get("CLC_FUSED_RD_LOSS", "1") != "0"
 
 
 def ms_ssim(X, Y, data_range=1.0):
@@ -48,6 +49,12 @@ class RateDistortionLoss(nn.Module):
         N, _, H, W = target.size()
         num_pixels = N * H * W
         out = {}
+        liks = output["likelihoods"]
+        if self.type == "mse" and FUSED_RD_LOSS and isinstance(liks, dict) and list(liks.keys()) == ["y", "z"] and output["x_hat"].is_cuda:
+            # the whole scalar tail (three sums, the divisions, lmbda * 255^2 * mse + bpp) in one launch; same bits as the expressions below
+            tgt = target.float().contiguous(memory_format=ops.CL)
+            out["bpp_loss"], out["mse_loss"], out["loss"] = ops.rd_loss_mse(liks["y"], liks["z"], output["x_hat"], tgt, self.lmbda, num_pixels)
+            return out
         # sum(log(l)) / (-ln2 * n) == sum(log2(l)) / (-n); the sums are fixed-order two-stage reductions
         out["bpp_loss"] = sum(ops.sum_log2(l) for l in output["likelihoods"].values()) / (-num_pixels)
         if self.type == "mse":
@@ -411,6 +418,13 @@ class TrainEngine:
             if self.with_optimizer and sync.active and hasattr(opt, "grad_scale"):
                 opt.grad_scale, sync.fold_scale = 1.0 / sync.world, True
 
+    def _one_like(self, t):
+        """the gradient seed of a scalar loss, allocated once per device (outside any capture: the eager warm-up steps come first)"""
+        one = getattr(self, "_one", None)
+        if one is None or one.device != t.device or one.shape != t.shape:
+            one = self._one = torch.ones_like(t)
+        return one
+
     def _model_out(self, x, refs):
         # (the built-in criterion reads x_hat and the likelihoods only: the concatenated means / scales of the output dict are not assembled)
         self.model._lean_outputs = self.lean_outputs
@@ -428,7 +442,7 @@ class TrainEngine:
         ops.WT_CACHE_VALID = True      # (the transposed filter images are this step's: see ops.WT_CACHE_VALID)
         try:
             out = self.criterion(self._model_out(x, refs), x)
-            out["loss"].backward()
+            out["loss"].backward(self._one_like(out["loss"]))   # (a cached 1: no ones_like fill launch per step)
         finally:
             ops.WT_CACHE_VALID = False
         ops.join_side_streams()   # filter gradients computed on the side stream are complete from here on
@@ -456,7 +470,7 @@ class TrainEngine:
         # (retain_graph: the engine would otherwise also release the saved tensors of the boundary's producers, which stage 2 needs)
         ops.WT_CACHE_VALID = True
         try:
-            torch.autograd.backward([out["loss"]], inputs=list(self.early_params) + self._bt, retain_graph=True)
+            torch.autograd.backward([out["loss"]], [self._one_like(out["loss"])], inputs=list(self.early_params) + self._bt, retain_graph=True)
         finally:
             ops.WT_CACHE_VALID = False
         ops.join_side_streams()
@@ -476,7 +490,7 @@ class TrainEngine:
         if self.with_optimizer:
             self.opt.step()
         aux_loss = self.model.aux_loss()
-        aux_loss.backward()
+        aux_loss.backward(self._one_like(aux_loss))
         out["aux_loss"] = aux_loss.detach()
         return out
 
@@ -567,7 +581,9 @@ class TrainEngine:
             # warm up on a side stream (allocator + lazy kernel attributes), then capture.  The warm-up steps must not count as
             # training steps: parameters, Adam moments and step counters are restored afterwards, so the FIRST replay is the
             # first optimizer update (the reference applies exactly one per batch, train_CLC.py:137-183)
-            self._static = (x.clone(), [r.clone() for r in refs] if refs is not None else None)
+            # (kept channels_last: the model's / criterion's `.contiguous(channels_last)` is then a no-op instead of a copy per step and image)
+            cl = lambda t: t.float().clone(memory_format=ops.CL) if t.dim() == 4 else t.clone()
+            self._static = (cl(x), [cl(r) for r in refs] if refs is not None else None)
             self._static_sig = sig
             snap = (self.opt.state_snapshot(), self.aux_opt.state_snapshot())
             s = torch.cuda.Stream()

@@ -350,6 +350,14 @@ int clc_scaled_diff(const float* a, const float* b, long n, const float* g_dev, 
                     clc_stream_t stream);                        /* out = g*coef*(a-b) */
 /* sum of n floats (fixed order) -> out[0] (+)= scale * sum */
 int clc_sum_partials(const float* partials, int n, float scale, float* out, int accumulate, clc_stream_t stream);
+/* the scalar tail of RateDistortionLoss (train_CLC.py:43-59, MSE form) in one launch: the three fixed-order sums of the partials of
+ * sum log2(lik_y), sum log2(lik_z), sum (x_hat - x)^2 and  bpp = (s_y + s_z) / neg_num_pixels, mse = sq / numel, loss = c * mse + bpp
+ * (c = float(lmbda * 255^2)), each rounded as the reference's tensor expressions round; and the device scalars its backward hands to
+ * clc_scaled_recip / clc_scaled_diff (g_* NULL: no gradient for that output). */
+int clc_rd_combine(const float* py, int ny, const float* pz, int nz, const float* psq, int nsq, float neg_num_pixels, float numel, float c,
+                   float* bpp, float* mse, float* loss, clc_stream_t stream);
+int clc_rd_grad_scalars(const float* g_bpp, const float* g_mse, const float* g_loss, float neg_num_pixels, float numel, float c, float* g_logsum,
+                        float* g_sq, clc_stream_t stream);
 /* sum((a-b)^2) partials */
 int clc_sqdiff_partials(const float* a, const float* b, long n, float* partials, int n_partials, clc_stream_t stream);
 
