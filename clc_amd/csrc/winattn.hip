@@ -186,14 +186,26 @@ __device__ __forceinline__ void stage_rows(float (*St)[LDQ], const f32x16& acc, 
   }
 }
 
-template <int HD, bool B4>
-__global__ __launch_bounds__(64, 4) void winattn_fwd_mfma_kernel(const AttnParams p) {
+// NH > 1 (round 5): NH waves per workgroup, one HEAD each — the NH = 128 B / (4 HD) heads whose q (k, v) shares of a token lie in ONE 128-byte
+// line.  With one head per single-wave workgroup every wave read 32 B (head_dim 8) of each of its 192 lines and the other three heads' workgroups
+// — other times, other XCDs — fetched the same lines again: 219.8 MB at the L2s' memory side for the 100.7-MB qkv tensor of an 8 x 128 x 128 map,
+// all in 128-byte requests (tools/pmc_attn_traffic.sh).  Running the four heads back to back in one wave made it worse (390 MB: an XCD's 4 MB
+// L2 does not hold 256 resident workgroups' 24 KB across a head's compute).  Here the workgroup's NH x 64 threads fetch each line ONCE, whole
+// (8 consecutive threads = one line), deposit every head's share in that head's LDS images, and store the result the same way.
+// Everything between the load and the store is the single-wave kernel, per wave: same arithmetic, same bits.
+template <int HD, bool B4, int NH = 1>
+__global__ __launch_bounds__(64 * NH, NH == 1 ? 4 : 3) void winattn_fwd_mfma_kernel(const AttnParams p) {
   constexpr int T = 64, WS = 8, LDQ = HD + 4, NBW = 2 * WS - 1, NB = NBW * NBW;
-  __shared__ __attribute__((aligned(16))) float Qs[T][LDQ], Ks[T][LDQ], Vs[T][LDQ];
-  __shared__ float Bias[NB];
-  const int lane = threadIdx.x, li = lane & 31, h = lane >> 5;
+  __shared__ __attribute__((aligned(16))) float QsA[NH][T][LDQ], KsA[NH][T][LDQ], VsA[NH][T][LDQ];
+  __shared__ float BiasA[NH][NB];
+  const int wave = NH == 1 ? 0 : (int)(threadIdx.x >> 6);
+  float (*Qs)[LDQ] = QsA[wave];
+  float (*Ks)[LDQ] = KsA[wave];
+  float (*Vs)[LDQ] = VsA[wave];
+  float* Bias = BiasA[wave];
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
   const int ty = lane >> 3, tx = lane & 7;          // the token whose rows this lane loads / stores
-  const int head = blockIdx.y;
+  const int head = blockIdx.y * NH + wave;
   const float scale = rsqrtf((float)HD);
   const int nwin = p.nwin_y * p.nwin_x;
   int cur_side = -1;
@@ -217,11 +229,26 @@ __global__ __launch_bounds__(64, 4) void winattn_fwd_mfma_kernel(const AttnParam
     const size_t row = (size_t)pix * p.ldq;
     const bool edge_y = p.shift && wy == p.nwin_y - 1, edge_x = p.shift && wx == p.nwin_x - 1;
     __syncthreads();
+    if constexpr (NH == 1) {
 #pragma unroll
-    for (int c = 0; c < HD; c += 4) {
-      *reinterpret_cast<f32x4*>(&Qs[lane][c]) = *reinterpret_cast<const f32x4*>(p.qkv + row + head * HD + c) * scale;
-      *reinterpret_cast<f32x4*>(&Ks[lane][c]) = *reinterpret_cast<const f32x4*>(p.qkv + row + p.C + head * HD + c);
-      *reinterpret_cast<f32x4*>(&Vs[lane][c]) = *reinterpret_cast<const f32x4*>(p.qkv + row + 2 * p.C + head * HD + c);
+      for (int c = 0; c < HD; c += 4) {
+        *reinterpret_cast<f32x4*>(&Qs[lane][c]) = *reinterpret_cast<const f32x4*>(p.qkv + row + head * HD + c) * scale;
+        *reinterpret_cast<f32x4*>(&Ks[lane][c]) = *reinterpret_cast<const f32x4*>(p.qkv + row + p.C + head * HD + c);
+        *reinterpret_cast<f32x4*>(&Vs[lane][c]) = *reinterpret_cast<const f32x4*>(p.qkv + row + 2 * p.C + head * HD + c);
+      }
+    } else {
+      // whole lines: thread t takes 16-B chunk t & 7 of the line of token (t >> 3) + k * (8 NH); chunk ch belongs to head ch / (HD / 4)
+      constexpr int CPH = HD / 4;                                   // chunks per head
+      const int t = threadIdx.x, ch = t & 7, hl = ch / CPH, cc = (ch % CPH) * 4;
+      const int line0 = blockIdx.y * NH * HD;                       // first channel of this workgroup's heads
+#pragma unroll
+      for (int k = 0; k < 8 / NH; ++k) {
+        const int tok = (t >> 3) + k * 8 * NH;
+        const size_t rw = (size_t)token_pixel(p, b, wy, wx, tok >> 3, tok & 7) * p.ldq + line0 + ch * 4;
+        *reinterpret_cast<f32x4*>(&QsA[hl][tok][cc]) = *reinterpret_cast<const f32x4*>(p.qkv + rw) * scale;
+        *reinterpret_cast<f32x4*>(&KsA[hl][tok][cc]) = *reinterpret_cast<const f32x4*>(p.qkv + rw + p.C);
+        *reinterpret_cast<f32x4*>(&VsA[hl][tok][cc]) = *reinterpret_cast<const f32x4*>(p.qkv + rw + 2 * p.C);
+      }
     }
     __syncthreads();
     // ---- S'[j][i]: tiles s[tj][ti] ----
@@ -300,12 +327,21 @@ __global__ __launch_bounds__(64, 4) void winattn_fwd_mfma_kernel(const AttnParam
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) stage_rows<HD, LDQ, B4>(Qs, o[ti], ti, lane, 1.f);
     __syncthreads();
-    {
+    if constexpr (NH == 1) {
       float* op = p.out + (size_t)pix * p.ldo + head * HD;
 #pragma unroll
       for (int c = 0; c < HD; c += 4) *reinterpret_cast<f32x4*>(op + c) = *reinterpret_cast<const f32x4*>(&Qs[lane][c]);
-      if (p.lse) p.lse[(size_t)pix * p.heads + head] = lse_out;
+    } else {   // the NH heads' results of a token are one 128-byte line of `out`: stored whole
+      constexpr int CPH = HD / 4;
+      const int t = threadIdx.x, ch = t & 7, hl = ch / CPH, cc = (ch % CPH) * 4;
+#pragma unroll
+      for (int k = 0; k < 8 / NH; ++k) {
+        const int tok = (t >> 3) + k * 8 * NH;
+        float* op = p.out + (size_t)token_pixel(p, b, wy, wx, tok >> 3, tok & 7) * p.ldo + blockIdx.y * NH * HD + ch * 4;
+        *reinterpret_cast<f32x4*>(op) = *reinterpret_cast<const f32x4*>(&QsA[hl][tok][cc]);
+      }
     }
+    if (p.lse) p.lse[(size_t)pix * p.heads + head] = lse_out;
   }
 }
 
@@ -746,12 +782,20 @@ static int winattn_fwd_impl(const float* qkv, int ldq, const float* relbias, con
   if (relbias2 && pair_ok("clc_winattn_fwd_pair", B, H, W, ws)) return -1;
   AttnParams p{};
   p.qkv = qkv; p.relbias = relbias; p.out = out; p.lse = lse; p.ldq = ldq; p.ldo = ldo;
-  fill(p, B, H, W, C, heads, ws, shift, 8192, relbias2 != nullptr);
-  p.relbias2 = relbias2;
-  dim3 grid((p.groups_total + p.groups_per_block - 1) / p.groups_per_block, heads);
   const int hd = C / heads;
   static const int use_mfma = getenv("CLC_ATTN_MFMA") ? atoi(getenv("CLC_ATTN_MFMA")) : 1;   // 0: VALU kernels (A/B knob)
-  if (ws == 8 && use_mfma) {
+  static const int nh_on = getenv("CLC_ATTN_NH") ? atoi(getenv("CLC_ATTN_NH")) : 1;          // 0: one head per single-wave workgroup (A/B knob)
+  // forward MFMA kernel: the heads that share a 128-byte line of a token's row as the waves of ONE workgroup (whole-line loads and stores)
+  const int nh = (ws == 8 && use_mfma && nh_on && (hd == 8 || hd == 16) && heads % (32 / hd) == 0 && ldq % 4 == 0 && ldo % 4 == 0 && (hd * (32 / hd)) % 32 == 0) ? 32 / hd : 1;
+  fill(p, B, H, W, C, heads / nh, ws, shift, nh > 1 ? 4096 : 8192, relbias2 != nullptr);
+  p.heads = heads;
+  p.relbias2 = relbias2;
+  dim3 grid((p.groups_total + p.groups_per_block - 1) / p.groups_per_block, heads / nh);
+  if (nh > 1) {
+    const int m4 = clc_tuning[CLC_TUNE_ATTN_4B];
+    if (hd == 8) { if (m4 & 4) hipLaunchKernelGGL((winattn_fwd_mfma_kernel<8, true, 4>), grid, dim3(256), 0, (hipStream_t)stream, p); else hipLaunchKernelGGL((winattn_fwd_mfma_kernel<8, false, 4>), grid, dim3(256), 0, (hipStream_t)stream, p); }
+    else { if (m4 & 1) hipLaunchKernelGGL((winattn_fwd_mfma_kernel<16, true, 2>), grid, dim3(128), 0, (hipStream_t)stream, p); else hipLaunchKernelGGL((winattn_fwd_mfma_kernel<16, false, 2>), grid, dim3(128), 0, (hipStream_t)stream, p); }
+  } else if (ws == 8 && use_mfma) {
     // head_dim <= 16: the N = head_dim products on 4-block 16x16x1 MFMAs (key 16, bit mask: 1 = head_dim 16, 2 = head_dim-8 backward,
     // 4 = head_dim-8 forward).  The head_dim-8 FORWARD (the analysis / synthesis transforms) is off by default: another summation order
     // moves y by ~4e-6, and on the parity sample one hyper-latent sits that close to .5 — its flip costs 9e-4 bpp against the oracle
