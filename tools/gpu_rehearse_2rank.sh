@@ -11,3 +11,9 @@ rc=$?
 echo "2-rank rc=$rc" >> gpurun_out/rehearse_2rank.txt
 grep -h "REHEARSAL\|single-rank\|rc=" gpurun_out/rehearse_2rank.txt | cut -c1-1200
 [ $rc -eq 0 ] || { grep -v "^\[W\|amdgpu.ids\|^\*\*\*\|OMP_NUM" gpurun_out/rehearse_2rank.err | tail -30 | cut -c1-300; exit $rc; }
+# ... and the SAME structure with ONE rank over RCCL (backend nccl, CLC_FORCE_COLLECTIVES=1): every all-reduce really issued on a 1-rank communicator
+timeout -k 10 ${LIMIT:-300} python tools/rehearse_2rank.py --rccl1 gpurun_out/rehearse_ref.json >> gpurun_out/rehearse_2rank.txt 2> gpurun_out/rehearse_rccl1.err
+rc1=$?
+echo "rccl 1-rank rc=$rc1" >> gpurun_out/rehearse_2rank.txt
+grep -h "REHEARSAL" gpurun_out/rehearse_2rank.txt | tail -1 | cut -c1-1200
+[ $rc1 -eq 0 ] || { grep -v "^\[W\|amdgpu.ids" gpurun_out/rehearse_rccl1.err | tail -20 | cut -c1-300; exit $rc1; }
