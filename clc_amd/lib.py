@@ -76,7 +76,7 @@ class TransposeEntry(C.Structure):
 
 
 class HaloPackEntry(C.Structure):
-    _fields_ = [("w", fp), ("out", fp), ("N", C.c_int), ("block_begin", C.c_int)]
+    _fields_ = [("w", fp), ("out", fp), ("N", C.c_int), ("K", C.c_int), ("block_begin", C.c_int)]
 
 
 class ReduceEntry(C.Structure):
@@ -108,7 +108,7 @@ SIGNATURES = {
     "clc_conv2d_wgrad_variant": (_i, [C.POINTER(WgradDesc)]),
     "clc_conv2d_wgrad_batched_sk": (_i, [C.POINTER(WgradDesc), _i, fp, _sz, fp]),
     "clc_filter_transpose": (_i, [fp, fp, _i, _i, _i, fp]),
-    "clc_filter_pack_halo": (_i, [fp, fp, _i, fp]),
+    "clc_filter_pack_halo": (_i, [fp, fp, _i, _i, fp]),
     "clc_filter_pack_halo_batched": (_i, [fp, _i, _i, fp]),
     "clc_filter_transpose_batched": (_i, [fp, _i, _i, fp]),
     "clc_partial_reduce_batched": (_i, [C.POINTER(ReduceEntry), _i, fp]),

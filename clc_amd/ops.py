@@ -527,31 +527,38 @@ WEIGHTS_EPOCH = 0
 
 
 def halo_ok(N, H, W, Cin, rows, ks, stride):
-    """may a [rows][3][3][Cin] filter on an N x H x W map take the halo kernel?  (the C side re-checks everything and falls through)"""
-    return (HALO and ks == 3 and stride == 1 and Cin == 128 and rows % 128 == 0 and H % 8 == 0 and W % 16 == 0
-            and N * (H // 8) * (W // 16) * (rows // 128) >= 128)
+    """input-channel count (128 / 64) if a [rows][3][3][Cin] filter on an N x H x W map may take the halo kernel, else 0 (the C side re-checks
+    everything and falls through to the tiled kernels)"""
+    if not (HALO and ks == 3 and stride == 1 and Cin in (128, 64) and rows % Cin == 0 and H % 8 == 0 and W % 16 == 0):
+        return 0
+    if not (_L().clc_get_tuning(22) & (1 if Cin == 128 else 2)):   # tuning key 22: bit 0 = 128-channel layers, bit 1 = 64-channel layers (off by default)
+        return 0
+    return Cin if N * (H // 8) * (W // 16) * (rows // Cin) >= 128 else 0
 
 
-def halo_pack(wk, rows):
-    """[rows][9][128] filter rows (K-contiguous) -> fragment order (clc_filter_pack_halo)."""
-    out = torch.empty(rows * 9 * 128, device=wk.device, dtype=torch.float32)
-    _lib.check(_L().clc_filter_pack_halo(wk.data_ptr(), out.data_ptr(), int(rows), _stream()), "clc_filter_pack_halo")
+def halo_pack(wk, rows, K=128):
+    """[rows][9][K] filter rows (K-contiguous; K = 128 or 64) -> fragment order (clc_filter_pack_halo)."""
+    out = torch.empty(rows * 9 * K, device=wk.device, dtype=torch.float32)
+    _lib.check(_L().clc_filter_pack_halo(wk.data_ptr(), out.data_ptr(), int(rows), int(K), _stream()), "clc_filter_pack_halo")
     return out
 
 
 def halo_packed(w, transposed_image=None):
-    """packed image of parameter `w`'s forward filter, or (transposed_image given: the [Cin][9][Cout] image of this step) of its transposed one"""
+    """packed image of parameter `w`'s forward filter, or (transposed_image given: the [Cin][9][Cout] image of this step) of its transposed one.
+    The parameter is marked as a user (`_clc_halo_use` / `_clc_halo_use_t`): clc_amd.train.HaloPacker packs exactly the marked ones."""
+    tr = transposed_image is not None
+    setattr(w, "_clc_halo_use_t" if tr else "_clc_halo_use", True)
     if WT_CACHE_VALID:
-        pk = getattr(w, "_clc_hpk_t" if transposed_image is not None else "_clc_hpk", None)
+        pk = getattr(w, "_clc_hpk_t" if tr else "_clc_hpk", None)
         if pk is not None:
             return pk
-    if transposed_image is not None:     # (a fresh transpose per backward pass outside the engine: packed per use)
-        return halo_pack(transposed_image, transposed_image.shape[0])
+    if tr:     # (a fresh transpose per backward pass outside the engine: packed per use)
+        return halo_pack(transposed_image, transposed_image.shape[0], w.shape[0])
     key = (w._version, w.data_ptr(), WEIGHTS_EPOCH)
     c = getattr(w, "_clc_hpk_cache", None)
     if c is not None and c[0] == key:
         return c[1]
-    pk = halo_pack(to_kernel_weight(w), w.shape[0])
+    pk = halo_pack(to_kernel_weight(w), w.shape[0], w.shape[1])
     w._clc_hpk_cache = (key, pk)
     return pk
 

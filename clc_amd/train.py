@@ -275,33 +275,35 @@ class FilterTransposer:
 
 
 class HaloPacker:
-    """Fragment-order images of the filters the halo-resident 3x3 kernel takes (csrc/conv_halo.hip: [k * 128, 128, 3, 3] forward; the
-    transposed image of the [128, 128, 3, 3] ones for their data gradients), refreshed by ONE launch per step
-    (clc_filter_pack_halo_batched) right behind the batched transpose, whose output it reads.  ops.halo_packed() hands them out while
+    """Fragment-order images of the filters the halo-resident 3x3 kernel takes (csrc/conv_halo.hip: [k * C, C, 3, 3], C = 128 or 64, forward;
+    the transposed image of the [C, C, 3, 3] ones for their data gradients), refreshed by ONE launch per step (clc_filter_pack_halo_batched)
+    right behind the batched transpose, whose output it reads.  Which filters: the ones the discovery pass marked (ops.halo_packed sets
+    `_clc_halo_use` on a forward use, `_clc_halo_use_t` on a data-gradient use).  ops.halo_packed() hands the images out while
     ops.WT_CACHE_VALID is set."""
 
     def __init__(self, params: List[nn.Parameter]):
-        ws = [p for p in params if p.dim() == 4 and tuple(p.shape[2:]) == (3, 3) and getattr(p, "_clc_is_filter", False) and ops.HALO
-              and p.shape[1] == 128 and p.shape[0] % 128 == 0 and ops.to_kernel_weight(p) is p]
-        jobs = []   # (source tensor, rows, attribute)
-        for p in ws:
-            jobs.append((p, p, p.shape[0], "_clc_hpk"))
+        jobs = []   # (parameter, source tensor, rows, K, attribute)
+        for p in params:
+            if p.dim() != 4 or not getattr(p, "_clc_is_filter", False) or ops.to_kernel_weight(p) is not p:
+                continue
+            if getattr(p, "_clc_halo_use", False):
+                jobs.append((p, p, p.shape[0], p.shape[1], "_clc_hpk"))
             wt = getattr(p, "_clc_wt", None)
-            if p.shape[0] == 128 and wt is not None:    # [Cin = 128][9][Cout = 128]: rows = Cin
-                jobs.append((p, wt, p.shape[1], "_clc_hpk_t"))
+            if getattr(p, "_clc_halo_use_t", False) and wt is not None:    # [Cin][9][Cout]: rows = Cin, K = Cout
+                jobs.append((p, wt, p.shape[1], p.shape[0], "_clc_hpk_t"))
         self.n = len(jobs)
         if not jobs:
             return
-        dev = ws[0].device
-        total = sum(rows * 9 * 128 for _, _, rows, _ in jobs)
+        dev = jobs[0][0].device
+        total = sum(rows * 9 * K for _, _, rows, K, _ in jobs)
         self.buf = torch.empty(total, dtype=torch.float32, device=dev)
         entries, off, blocks = [], 0, 0
-        for p, src, rows, attr in jobs:
-            n = rows * 9 * 128
+        for p, src, rows, K, attr in jobs:
+            n = rows * 9 * K
             out = self.buf[off: off + n]
             off += n
             setattr(p, attr, out)
-            entries.append(_lib.HaloPackEntry(src.data_ptr(), out.data_ptr(), int(rows), blocks))
+            entries.append(_lib.HaloPackEntry(src.data_ptr(), out.data_ptr(), int(rows), int(K), blocks))
             blocks += (n // 4 + 255) // 256
         self.total_blocks = blocks
         self.table = torch.frombuffer(bytearray(b"".join(bytes(e) for e in entries)), dtype=torch.uint8).to(dev)

@@ -122,18 +122,18 @@ typedef struct {
    * with a K split sized to the grid (needs `workspace`). */
   int batch_variant_ok;
   /* optional: the same filter in the fragment order of conv_halo3x3_kernel (clc_filter_pack_halo; for transposed = 1: of the transposed
-   * filter).  With it, 3x3 / stride-1 / pad-1 layers with 128 input channels and a multiple of 128 output channels on maps whose height is a
-   * multiple of 8 and width of 16 run on the halo-resident kernel (csrc/conv_halo.hip) — same bits as the tiled kernels.  NULL: tiled kernels. */
+   * filter).  With it, 3x3 / stride-1 / pad-1 layers with 128 (64) input channels and a multiple of 128 (64) output channels on maps whose
+   * height is a multiple of 8 and width of 16 run on the halo-resident kernel (csrc/conv_halo.hip) — same bits as the tiled kernels.  NULL: tiled. */
   const float* w_packed;
 } clc_conv_desc;
 
 int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream);
-/* [N][3][3][128] filter rows (N a multiple of 128: the forward filter [Cout][kh][kw][Cin = 128], or the transposed filter [Cin][kh][kw][Cout = 128]
- * of a 128 -> 128 layer) -> `out` (same number of floats) in the fragment order clc_conv_desc.w_packed expects. */
-int clc_filter_pack_halo(const float* w, float* out, int N, clc_stream_t stream);
-/* ... for every such filter of a model in ONE launch: device table of entries; block_begin = running sum of ceil(N * 288 / 256) (blocks of 256
+/* [N][3][3][K] filter rows, K = 128 or 64, N a multiple of K (the forward filter [Cout][kh][kw][Cin = K], or the transposed filter
+ * [Cin][kh][kw][Cout = K] of a K -> K layer) -> `out` (same number of floats) in the fragment order clc_conv_desc.w_packed expects. */
+int clc_filter_pack_halo(const float* w, float* out, int N, int K, clc_stream_t stream);
+/* ... for every such filter of a model in ONE launch: device table of entries; block_begin = running sum of ceil(N * 9 * K / 4 / 256) (blocks of 256
  * 16-B elements) over the preceding entries, total_blocks = the grand total */
-typedef struct { const float* w; float* out; int N, block_begin; } clc_halo_pack_entry;
+typedef struct { const float* w; float* out; int N, K, block_begin; } clc_halo_pack_entry;
 int clc_filter_pack_halo_batched(const clc_halo_pack_entry* table_dev, int n_entries, int total_blocks, clc_stream_t stream);
 /* scratch bytes with which clc_conv2d would split this launch's K range (0: it would not split) */
 size_t clc_conv2d_workspace_bytes(const clc_conv_desc* d);

@@ -1185,44 +1185,61 @@ def test_16_column_kernel_for_the_few_channel_tail(dev, N, Cin, H, W, Cout, shuf
     assert torch.equal(one, outs[1][:1]), "an image's bits depend on the batch"
 
 
-@pytest.mark.parametrize("N,H,W,Cout,mode", [(8, 64, 64, 128, "plain"), (2, 128, 128, 128, "lrelu_res"), (8, 32, 32, 512, "shuffle_lrelu"), (2, 64, 64, 512, "shuffle"),
-                                             (8, 64, 64, 128, "dgrad_gate"), (12, 40, 48, 128, "plain"), (1, 256, 256, 128, "pre"), (8, 128, 128, 128, "plain")])
-def test_halo_conv_same_bits_as_tiled(dev, N, H, W, Cout, mode):
-    """conv_halo3x3_kernel (csrc/conv_halo.hip: 3x3 / stride 1 / 128 input channels; input halo resident in LDS, filter streamed from L2 in
+@pytest.mark.parametrize("N,H,W,Cin,Cout,mode", [
+    (8, 64, 64, 128, 128, "plain"), (2, 128, 128, 128, 128, "lrelu_res"), (8, 32, 32, 128, 512, "shuffle_lrelu"), (2, 64, 64, 128, 512, "shuffle"),
+    (8, 64, 64, 128, 128, "dgrad_gate"), (12, 40, 48, 128, 128, "plain"), (1, 256, 256, 128, 128, "pre"), (8, 128, 128, 128, 128, "plain"),
+    (8, 128, 128, 64, 64, "plain"), (2, 128, 128, 64, 64, "lrelu_res"), (8, 128, 128, 64, 64, "dgrad_gate"), (3, 72, 80, 64, 128, "pre"), (8, 64, 64, 64, 64, "strided")])
+def test_halo_conv_same_bits_as_tiled(dev, N, H, W, Cin, Cout, mode):
+    """conv_halo3x3_kernel (csrc/conv_halo.hip: 3x3 / stride 1 / 128 or 64 input channels; input halo resident in LDS, filter streamed from L2 in
     fragment order, no barrier in the K loop) against the LDS-tiled kernels on the same launch: THE SAME BITS — forward with bias /
     LeakyReLU / residual / saved pre-activation epilogues, the PixelShuffle store of the sub-pixel convolutions
-    (/root/reference/models/CLC_run.py:28-30 via compressai.layers.subpel_conv3x3), and the data gradient of a 128 -> 128 layer with the
-    consumer-side activation gate; image borders, a map that is not a power of two, and a workgroup that walks several tiles."""
+    (/root/reference/models/CLC_run.py:28-30 via compressai.layers.subpel_conv3x3), the data gradient with the consumer-side activation
+    gate, input and output as channel ranges of wider buffers (ConvTransBlock's halves); image borders, maps that are not powers of
+    two, a workgroup that walks several tiles."""
     from clc_amd import lib, ops
     from clc_amd.ops import ACT_LRELU, ACT_NONE
 
     L = lib.load()
+    restore = L.clc_set_tuning(22, 3)     # (the 64-channel instantiation is off by default: slower inside the step)
+    try:
+        _halo_case(dev, L, ops, N, H, W, Cin, Cout, mode, ACT_LRELU)
+    finally:
+        L.clc_set_tuning(22, restore)
+
+
+def _halo_case(dev, L, ops, N, H, W, Cin, Cout, mode, ACT_LRELU):
     g = torch.Generator().manual_seed(N * 1000 + H + Cout)
-    x = _dev(torch.randn(N, 128, H, W, generator=g), dev)
-    w = (torch.randn(Cout, 128, 3, 3, generator=g) * 0.05).to(dev).contiguous(memory_format=CL)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).to(dev).contiguous(memory_format=CL)
     b = (torch.randn(Cout, generator=g) * 0.1).to(dev)
     wk = ops.to_kernel_weight(w)
-    assert ops.halo_ok(N, H, W, 128, Cout, 3, 1)
     kw = dict(ks=3, stride=1)
-    if mode == "plain":
-        kw.update(bias=b)
-    elif mode == "lrelu_res":
-        kw.update(bias=b, act=ACT_LRELU, res=_dev(torch.randn(N, Cout, H, W, generator=g), dev), res_scale=0.5)
-    elif mode == "pre":
-        kw.update(bias=b, act=ACT_LRELU, res=_dev(torch.randn(N, Cout, H, W, generator=g), dev), y_pre=ops.new_act(N, Cout, H, W, x))
-    elif mode == "shuffle_lrelu":
-        kw.update(bias=b, act=ACT_LRELU, shuffle=True)
-    elif mode == "shuffle":
-        kw.update(bias=b, shuffle=True)
-    if mode == "dgrad_gate":
-        wt = ops.filter_transpose(wk, Cout, 9, 128).view(128, -1)
-        gate = _dev(torch.randn(N, 128, H, W, generator=g), dev)
+    tr = mode.startswith("dgrad")
+    if tr:   # "x" is dY [N, Cout, H, W]; the launch's K channels = Cout, its rows = Cin
+        x = _dev(torch.randn(N, Cout, H, W, generator=g), dev)
+        assert ops.halo_ok(N, H, W, Cout, Cin, 3, 1) == Cout
+        wt = ops.filter_transpose(wk, Cout, 9, Cin).view(Cin, -1)
+        pk = ops.halo_pack(wt, Cin, Cout)
+        gate = _dev(torch.randn(N, Cin, H, W, generator=g), dev)
         run = lambda wpk: ops.conv_raw(x, wt, None, ks=3, stride=1, pad=1, transposed=True, out_hw=(H, W), out_gate=(gate, ACT_LRELU, False),
-                                       res=_dev(torch.ones(N, 128, H, W), dev), res_scale=0.25, wpk=wpk)
-        pk = ops.halo_pack(wt, 128)
+                                       res=_dev(torch.ones(N, Cin, H, W), dev), res_scale=0.25, wpk=wpk)
     else:
-        run = lambda wpk: ops.conv_raw(x, wk, kw.get("bias"), **{k: v for k, v in kw.items() if k != "bias"}, wpk=wpk)
-        pk = ops.halo_pack(wk, Cout)
+        wide = _dev(torch.randn(N, 2 * Cin, H, W, generator=g), dev)
+        x = wide[:, Cin:] if mode == "strided" else _dev(torch.randn(N, Cin, H, W, generator=g), dev)
+        assert ops.halo_ok(N, H, W, Cin, Cout, 3, 1) == Cin
+        if mode in ("plain", "strided"):
+            kw.update(bias=b)
+        elif mode == "lrelu_res":
+            kw.update(bias=b, act=ACT_LRELU, res=_dev(torch.randn(N, Cout, H, W, generator=g), dev), res_scale=0.5)
+        elif mode == "pre":
+            kw.update(bias=b, act=ACT_LRELU, res=_dev(torch.randn(N, Cout, H, W, generator=g), dev), y_pre=ops.new_act(N, Cout, H, W, x))
+        elif mode == "shuffle_lrelu":
+            kw.update(bias=b, act=ACT_LRELU, shuffle=True)
+        elif mode == "shuffle":
+            kw.update(bias=b, shuffle=True)
+        outw = ops.new_act(N, 2 * Cout, H, W, wide) if mode == "strided" else None
+        run = lambda wpk: ops.conv_raw(x, wk, kw.get("bias"), **{k: v for k, v in kw.items() if k != "bias"}, wpk=wpk,
+                                       out=(outw[:, :Cout] if outw is not None else None))
+        pk = ops.halo_pack(wk, Cout, Cin)
     ops.PROFILE = []
     try:
         y_halo = run(pk).clone()
@@ -1239,7 +1256,7 @@ def test_halo_conv_same_bits_as_tiled(dev, N, H, W, Cout, mode):
     # ... and against torch for the plain forward (the tiled kernels are held to torch by test_conv_fwd_bwd)
     if mode == "plain":
         ref = F.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=1)
-        _close(y_halo, ref, 2e-5, f"halo conv {N}x{H}x{W} -> {Cout}")
+        _close(y_halo, ref, 2e-5, f"halo conv {N}x{H}x{W} {Cin} -> {Cout}")
     # the tuning key switches it off
     old = L.clc_set_tuning(22, 0)
     try:
@@ -1249,3 +1266,6 @@ def test_halo_conv_same_bits_as_tiled(dev, N, H, W, Cout, mode):
     finally:
         ops.PROFILE = None
         L.clc_set_tuning(22, old)
+    assert L.clc_set_tuning(22, 1) == 3     # the default mask: 128-channel layers only
+    assert ops.halo_ok(8, 64, 64, 64, 64, 3, 1) == 0 and ops.halo_ok(8, 64, 64, 128, 128, 3, 1) == 128
+    L.clc_set_tuning(22, 3)
