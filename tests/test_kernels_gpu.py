@@ -1269,3 +1269,28 @@ def _halo_case(dev, L, ops, N, H, W, Cin, Cout, mode, ACT_LRELU):
     assert L.clc_set_tuning(22, 1) == 3     # the default mask: 128-channel layers only
     assert ops.halo_ok(8, 64, 64, 64, 64, 3, 1) == 0 and ops.halo_ok(8, 64, 64, 128, 128, 3, 1) == 128
     L.clc_set_tuning(22, 3)
+
+
+@pytest.mark.parametrize("rows,K", [(128, 128), (512, 128), (64, 64), (192, 64)])
+def test_halo_filter_pack_is_the_documented_fragment_order(dev, rows, K):
+    """clc_filter_pack_halo against its layout statement (include/clc_hip.h, csrc/conv_halo.hip): element (n-tile, wave column wc, K step kt, block j,
+    quarter t8, lane) x 4 floats = filter row nt * 64 NWC + wc * 64 + j * 32 + (lane & 31), tap kt / (K / 32), channels (kt % (K / 32)) * 32 + 8 t8 +
+    4 (lane >> 5) .. + 3 — i.e. what lane (n, k-half) of a v_mfma_f32_32x32x2_f32 B operand needs for MFMA steps ss = 0..3 of that quarter."""
+    from clc_amd import ops
+
+    w = torch.arange(rows * 9 * K, dtype=torch.float32).reshape(rows, 9 * K).to(dev)      # every element its own value: a pure permutation check
+    pk = ops.halo_pack(w, rows, K).cpu().numpy().reshape(-1, 4)
+    KCN, NWC = K // 32, K // 64
+    KST = 9 * KCN
+    e = np.arange(pk.shape[0])
+    lane, r = e & 63, e >> 6
+    t8, r = r & 3, r >> 2
+    j, r = r & 1, r >> 1
+    kt, r = r % KST, r // KST
+    wc, nt = r % NWC, r // NWC
+    row = nt * 64 * NWC + wc * 64 + j * 32 + (lane & 31)
+    k0 = (kt % KCN) * 32 + 8 * t8 + 4 * (lane >> 5)
+    src = (row * 9 + kt // KCN) * K + k0
+    want = src[:, None] + np.arange(4)[None, :]
+    assert pk.shape[0] == rows * 9 * K // 4 and np.array_equal(pk, want.astype(np.float32))
+    assert np.array_equal(np.sort(pk.reshape(-1)), np.arange(rows * 9 * K, dtype=np.float32))    # a permutation: nothing dropped, nothing twice
