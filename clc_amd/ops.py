@@ -463,7 +463,10 @@ def graph_capture_mode() -> str:
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """raw handle of the current HIP stream of the current device.  (torch.cuda.current_stream() builds a Stream object through four layers of
+    Python — 8 us a call on the host, 1 400 calls per eager backward pass: a fifth of the reference-style loop's host time.  The two C
+    accessors cost 0.3 us.)"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _require_gpu(t: torch.Tensor, what: str):
