@@ -27,8 +27,8 @@ namespace {
 
 constexpr int TH = 8, TW = 16, HH = TH + 2, HW = TW + 2, HPIX = HH * HW;   // output tile, halo
 // CI = input channels: 128 (8 waves = 4 pixel-row pairs x 2 column halves, n-tile 128, halo 90 KB: one PERSISTENT workgroup per CU) or
-// 64 (the ResidualBlocks of the ConvTransBlocks: 4 waves = 4 row pairs, n-tile 64, halo 45 KB: THREE workgroups per CU, one tile each — a
-// new workgroup's halo deposit and an old one's epilogue run under the other two's MFMAs, which the single persistent workgroup cannot do)
+// 64 (the ResidualBlocks of the ConvTransBlocks: 4 waves = 4 row pairs, n-tile 64, halo 45 KB: TWO workgroups per CU — one's halo deposit
+// and epilogue run under the other's MFMAs, which the single persistent workgroup of the 128-channel form cannot do; three fit the LDS but spill)
 
 struct HaloParams {
   ConvParams c;
@@ -42,7 +42,7 @@ struct HaloParams {
 // TR: data gradient of a stride-1 'same' convolution: "x" is dY, the packed filter is the transposed one, tap (tj, ti) reads source pixel
 // (oy + 1 - tj, ox + 1 - ti).  SHUF: PixelShuffle(2) store with bias + {none, LeakyReLU, ReLU} (the sub-pixel convolutions).
 template <int CI, bool TR, bool SHUF>
-__global__ __launch_bounds__(CI == 128 ? 512 : 256, CI == 128 ? 1 : 3) void conv_halo3x3_kernel(const HaloParams hp) {
+__global__ __launch_bounds__(CI == 128 ? 512 : 256, CI == 128 ? 1 : 2) void conv_halo3x3_kernel(const HaloParams hp) {
   constexpr int KCN = CI / 32, KSTEPS = 9 * KCN;                 // 32-channel groups per tap, K steps
   constexpr int PXB = CI * 4;                                    // bytes per halo pixel
   constexpr int NWAVE = CI == 128 ? 8 : 4, NWC = NWAVE / 4, NTW = 64 * NWC;
@@ -223,9 +223,10 @@ int clc_conv_halo_launch(const void* conv_params, const float* wpk, hipStream_t 
   const ConvParams& p = *reinterpret_cast<const ConvParams*>(conv_params);
   const int CI = p.Cin;
   // bit 0: the 128-channel layers; bit 1: the 64-channel ones — OFF by default: graph-replayed alone the 64 -> 64 layers gain (8 x 128 x 128:
-  // 92.9 -> 89.2 us, 8 x 64 x 64: 30.8 -> 28.1), inside the training step they lose (26.52 -> 26.68 ms over three interleaved rounds: their
-  // epilogues — bias + LeakyReLU + residual + saved pre-activation, gates — are heavier than the micro-benchmark's and two or three waves per
-  // SIMD hide less of them than the tiled kernel's four)
+  // 91.9 -> 83.4 us, 8 x 64 x 64: 30.7 -> 27.0 at two workgroups per CU; three per CU spill 18 registers in the epilogue: 89.2), inside the
+  // training step they gain NOTHING (26.625 vs 26.619 ms over three interleaved rounds; the three-per-CU build lost 0.15 ms): their epilogues —
+  // bias + LeakyReLU + residual + saved pre-activation, gates — are heavier than the micro-benchmark's and two waves per SIMD hide less of them
+  // than the tiled kernel's four
   if (!(clc_tuning[CLC_TUNE_HALO] & (CI == 128 ? 1 : 2))) return 0;
   if (!wpk || p.ks != 3 || p.stride != 1 || p.pad != 1 || (CI != 128 && CI != 64) || p.Cout % CI || p.H % TH || p.W % TW || p.OH != p.H || p.OW != p.W) return 0;
   if (p.xs || p.in_op != CLC_IN_NONE || p.group_rows || p.bf16 || p.ksplit > 1 || p.ldx % 4 || !aligned16(p.x) || !aligned16(wpk)) return 0;
