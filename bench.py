@@ -370,7 +370,7 @@ def _replay_ms(fn, reps=20, warm=2):
     g = torch.cuda.CUDAGraph()
     from clc_amd import ops as _ops
 
-    with torch.cuda.graph(g, capture_error_mode=_ops.graph_capture_mode()):
+    with _ops.capture_guard(), torch.cuda.graph(g, capture_error_mode=_ops.graph_capture_mode()):
         fn()
     g.replay()
     torch.cuda.synchronize()

@@ -148,7 +148,8 @@ class CodecEngine:
     """engine = CodecEngine(model); outs = engine.compress(x[B], refs); xs = engine.decompress(outs, refs)."""
 
     def __init__(self, model, threads: int = 8, use_graph: bool = True):
-        self.model = model.eval()
+        model.eval()
+        self.model = model          # (may be a weakref.proxy: the engine a model builds for its own compress() must not keep the model alive)
         self.use_graph = use_graph
         self.pool = ThreadPoolExecutor(max_workers=max(1, threads))
         self._enc = {}
@@ -196,7 +197,7 @@ class CodecEngine:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode=ops.graph_capture_mode()):
+        with ops.capture_guard(), torch.cuda.graph(g, capture_error_mode=ops.graph_capture_mode()):
             out = fn()
         g.replay()   # capture does not execute: leave valid values behind for the next segment's warm-up passes
         return g, out

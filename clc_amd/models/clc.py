@@ -349,8 +349,12 @@ class _SliceCodec(CompressionModel):
 
             if eng is not None:
                 eng.close()
+            import weakref
+
             was_training = self.training
-            eng = CodecEngine(self, threads=1)
+            # (a proxy: model -> engine -> model would be a reference cycle, freed only by a garbage collection at some later time — e.g.
+            #  inside another engine's graph capture, where releasing this one's graphs and pinned buffers is illegal)
+            eng = CodecEngine(weakref.proxy(self), threads=1)
             self.train(was_training)
             self.__dict__["_codec_eng"], self.__dict__["_codec_eng_stamp"] = eng, self._codec_stamp()
         return eng

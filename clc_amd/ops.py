@@ -462,6 +462,28 @@ def graph_capture_mode() -> str:
     return "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
 
 
+class capture_guard:
+    """Around a hipGraph capture: the cyclic garbage collector stays off.  A collection that happens to run inside a capture may finalise
+    objects of an EARLIER engine (captured graphs, pinned host buffers: hipFreeHost / hipGraphDestroy) — calls that are illegal while a stream
+    captures and abort the process (met in the full GPU test run: "Fatal Python error: Aborted ... Garbage-collecting" inside
+    CodecEngine._capture).  torch.cuda.graph collects BEFORE it starts capturing, not during."""
+
+    def __enter__(self):
+        import gc
+
+        self._was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+
+        if self._was:
+            gc.enable()
+        return False
+
+
 def _stream():
     """raw handle of the current HIP stream of the current device.  (torch.cuda.current_stream() builds a Stream object through four layers of
     Python — 8 us a call on the host, 1 400 calls per eager backward pass: a fifth of the reference-style loop's host time.  The two C

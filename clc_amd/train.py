@@ -600,24 +600,24 @@ class TrainEngine:
             del snap
             if single:
                 self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph, capture_error_mode=ops.graph_capture_mode()):
+                with ops.capture_guard(), torch.cuda.graph(self.graph, capture_error_mode=ops.graph_capture_mode()):
                     self._out = self._eager_step(*self._static)
             elif self.two_phase:
                 # collectives stay outside the graphs: A1 = forward + backward down to the encoders' outputs | exchange of those
                 # gradients starts | A2 = the encoders' backward (overlaps the exchange) | rest of the exchange | B = optimizer + aux
                 self.graph = (torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph())
-                with torch.cuda.graph(self.graph[0], capture_error_mode=ops.graph_capture_mode()):
+                with ops.capture_guard(), torch.cuda.graph(self.graph[0], capture_error_mode=ops.graph_capture_mode()):
                     self._mid = self._fwd_bwd_early(*self._static)
-                with torch.cuda.graph(self.graph[1], pool=self.graph[0].pool(), capture_error_mode=ops.graph_capture_mode()):
+                with ops.capture_guard(), torch.cuda.graph(self.graph[1], pool=self.graph[0].pool(), capture_error_mode=ops.graph_capture_mode()):
                     self._bwd_late()
-                with torch.cuda.graph(self.graph[2], pool=self.graph[0].pool(), capture_error_mode=ops.graph_capture_mode()):
+                with ops.capture_guard(), torch.cuda.graph(self.graph[2], pool=self.graph[0].pool(), capture_error_mode=ops.graph_capture_mode()):
                     self._out2 = self._opt_steps(dict(self._mid))
             else:
                 # collectives stay outside the graphs: graph A = fwd+bwd, exchange, graph B = optimizer + aux
                 self.graph = (torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph())
-                with torch.cuda.graph(self.graph[0], capture_error_mode=ops.graph_capture_mode()):
+                with ops.capture_guard(), torch.cuda.graph(self.graph[0], capture_error_mode=ops.graph_capture_mode()):
                     self._mid = self._fwd_bwd(*self._static)
-                with torch.cuda.graph(self.graph[1], pool=self.graph[0].pool(), capture_error_mode=ops.graph_capture_mode()):
+                with ops.capture_guard(), torch.cuda.graph(self.graph[1], pool=self.graph[0].pool(), capture_error_mode=ops.graph_capture_mode()):
                     self._out2 = self._opt_steps(dict(self._mid))
         sx, srefs = self._static
         sx.copy_(x, non_blocking=True)
