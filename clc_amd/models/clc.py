@@ -326,10 +326,9 @@ class _SliceCodec(CompressionModel):
         if probe is None:
             ps = list(self.parameters())
             probe = self.__dict__["_codec_probe"] = (ps[::8], list(self.buffers()), len(ps))
-        # (parameter VALUES may change under captured graphs — they read the same storage — except where a graph replays a cached
-        #  derived image of a filter (ops.halo_packed): version counters and the engine's step counter cover those)
+        # (parameter VALUES may change under the captured graphs: they read the same storage, and every derived image of a parameter — GDN
+        #  re-parametrisation, fragment-order filters — is computed inside the graphs)
         return (kernel_config(), probe[2], sum(q.data_ptr() for q in probe[0]), sum(b.data_ptr() for b in probe[1]),
-                sum(q._version for q in probe[0]), ops.WEIGHTS_EPOCH,
                 bool(getattr(self, "wire_clm", False)), getattr(self, "max_support_slices", None), getattr(self, "use_ref", None))
 
     def __getstate__(self):   # (copy.deepcopy / pickling of the model: the lazily built engine — graphs, a thread pool — stays behind)

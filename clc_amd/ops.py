@@ -545,10 +545,12 @@ def to_kernel_weight(w: torch.Tensor) -> torch.Tensor:
 # ---- halo-resident 3x3 kernel (csrc/conv_halo.hip): the filter is ALSO needed in fragment order.  Where the packed image comes from:
 #   * inside a TrainEngine step (WT_CACHE_VALID): one batched launch per step packs every eligible filter and transposed filter
 #     (clc_amd.train.HaloPacker -> w._clc_hpk / w._clc_hpk_t), like the transposed images themselves;
-#   * anywhere else: packed on first use and cached on the parameter, keyed by (its version counter, its storage, WEIGHTS_EPOCH) —
-#     torch optimizers bump the version, TrainEngine (whose kernels update the arena through raw pointers) bumps WEIGHTS_EPOCH per step.
+#   * anywhere else: packed PER USE (one 5-us launch in front of a >= 75-us convolution).  No cache across calls: nothing tells this module
+#     that `w.data.copy_(...)` or a kernel writing through a raw pointer changed the weights (neither moves a version counter), and a stale
+#     image would be silently wrong results.  Inside a captured graph (CodecEngine) the pack launch is part of the graph, so a replay
+#     always packs the weights of the moment.
 HALO = os.environ.get("CLC_HALO", "1") != "0"
-WEIGHTS_EPOCH = 0
+WEIGHTS_EPOCH = 0   # bumped by TrainEngine per step (its kernels update the arena through raw pointers); informational
 
 
 def halo_ok(N, H, W, Cin, rows, ks, stride):
@@ -577,15 +579,9 @@ def halo_packed(w, transposed_image=None):
         pk = getattr(w, "_clc_hpk_t" if tr else "_clc_hpk", None)
         if pk is not None:
             return pk
-    if tr:     # (a fresh transpose per backward pass outside the engine: packed per use)
+    if tr:
         return halo_pack(transposed_image, transposed_image.shape[0], w.shape[0])
-    key = (w._version, w.data_ptr(), WEIGHTS_EPOCH)
-    c = getattr(w, "_clc_hpk_cache", None)
-    if c is not None and c[0] == key:
-        return c[1]
-    pk = halo_pack(to_kernel_weight(w), w.shape[0], w.shape[1])
-    w._clc_hpk_cache = (key, pk)
-    return pk
+    return halo_pack(to_kernel_weight(w), w.shape[0], w.shape[1])
 
 
 def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_NONE, norm=NORM_NONE, mul=None,

@@ -97,8 +97,11 @@ def test_reference_surface_single_image_codec_rides_on_captured_graphs(dev, kind
     imgs = [synthetic_image(1, H, W, 500 + 3 * i, smooth=True).to(dev) for i in range(2)]
     refs = [[synthetic_image(1, H, W, 600 + 10 * i + j, smooth=True).to(dev) for j in range(R)] for i in range(2)]
     engines = []
+    engines_first_strings = None
     for x, rf in zip(imgs, refs):
         a = m.compress(x, rf) if R else m.compress(x)
+        if engines_first_strings is None:
+            engines_first_strings = a["strings"]
         b = m._compress_eager(x, rf if R else None)
         assert a["strings"] == b["strings"] and tuple(a["shape"]) == tuple(b["shape"])
         da = m.decompress(a["strings"], a["shape"], rf) if R else m.decompress(a["strings"], a["shape"])
@@ -109,6 +112,17 @@ def test_reference_surface_single_image_codec_rides_on_captured_graphs(dev, kind
     assert eng is not None and engines[1] is eng and len(eng._enc) == 1 and len(eng._dec) == 1     # one set of graphs, reused
     assert next(iter(eng._enc.values())).graph is not None
     assert not m.training
+    # weights changed IN PLACE through `.data` (no version counter moves): the captured graphs read the live storage and compute every derived
+    # image (fragment-order filters of the halo kernel, GDN re-parametrisation) inside the graph -> same engine, new streams, still == eager
+    with torch.no_grad():
+        for q in m.parameters():
+            if q.dim() == 4:
+                q.data.mul_(1.003)
+    a1 = m.compress(imgs[0], refs[0]) if R else m.compress(imgs[0])
+    b1 = m._compress_eager(imgs[0], refs[0] if R else None)
+    assert m.__dict__["_codec_eng"] is eng and a1["strings"] == b1["strings"] and a1["strings"] != engines_first_strings
+    d1 = m.decompress(a1["strings"], a1["shape"], refs[0]) if R else m.decompress(a1["strings"], a1["shape"])
+    assert torch.equal(d1["x_hat"], m._decompress_eager(b1["strings"], b1["shape"], refs[0] if R else None)["x_hat"])
     # re-homed parameters: the captured graphs would read the old storage -> the engine must be rebuilt, results unchanged
     with torch.no_grad():
         for q in m.parameters():
