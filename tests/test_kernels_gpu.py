@@ -676,6 +676,47 @@ def test_block_fused_large_map_path_vs_reference_class(dev, typ):
         _close(q.grad.cpu(), torch.from_numpy(g[f"{typ}_grad_{n}"]), 1e-4, f"Block {typ} d{n} vs reference class")
 
 
+def test_convtransblock_large_map_path_vs_reference_class(dev):
+    """A whole ConvTransBlock on a [2, 128, 128, 128] input (32 768 pixels: conv1_1 / conv1_2 on the wave-private 1x1 kernel, the ResidualBlock's
+    64-channel 3x3 layers on the LDS-tiled kernels with their activation gates and gradient folds, the Swin Block on its fused launches, the two
+    branches written / differentiated in place through channel halves) against numbers produced by the reference's OWN ConvTransBlock class
+    (CLC_run.py:195-220; tests/golden/block_large.npz ctb_*, tools/make_golden.py block_large): output, input gradient, 21 parameter gradients."""
+    import hashlib
+
+    from clc_amd import layers, ops
+    from clc_amd.recipe import apply_weight_recipe
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "block_large.npz"))
+    x0 = torch.randn(2, 128, 128, 128, generator=torch.Generator().manual_seed(int(g["ctb_seed_x"])))
+    dy0 = torch.randn(2, 128, 128, 128, generator=torch.Generator().manual_seed(int(g["ctb_seed_dy"])))
+    assert hashlib.sha256(x0.numpy().tobytes()).hexdigest() == str(g["ctb_x_sha256"])
+    ctb = layers.ConvTransBlock(64, 64, 8, 8, 0, "SW")
+    apply_weight_recipe(ctb, 3)
+    ctb = ctb.to(dev).train()
+    x, dy = _dev(x0, dev, grad=True), _dev(dy0, dev)
+    ops.PROFILE = []
+    try:
+        y = ctb(x)
+        y.backward(dy)
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        fams = {(r.fam, r.variant >> 20) for r in ops.PROFILE}
+    finally:
+        ops.PROFILE = None
+    assert ("conv_igemm", 11) in fams, sorted(fams)                                   # conv1_1 / conv1_2: lin_kernel (family 11)
+    assert {"clc_lnlin_fwd", "clc_mlp_bwd"} <= {f for f, _ in fams}                   # the Swin Block's fused launches
+    yt, dxt = y.detach().cpu(), x.grad.cpu()
+    for k, (b, r, c) in enumerate(g["patch_origins"].tolist()):
+        _close(yt[b, :, r:r + 8, c:c + 8], torch.from_numpy(g[f"ctb_y_patch{k}"]), 2e-5, f"ConvTransBlock y patch {k} vs reference class")
+        _close(dxt[b, :, r:r + 8, c:c + 8], torch.from_numpy(g[f"ctb_dx_patch{k}"]), 1e-4, f"ConvTransBlock dx patch {k} vs reference class")
+    for nm, t, tol in (("y", yt, 2e-5), ("dx", dxt, 1e-4)):
+        _close(t.double().sum(dim=(2, 3)), torch.from_numpy(g[f"ctb_{nm}_chan_sums"]), tol, f"ConvTransBlock {nm} per-channel sums")
+        assert abs(t.double().abs().sum().item() - float(g[f"ctb_{nm}_abs_sum"])) <= tol * float(g[f"ctb_{nm}_abs_sum"])
+    for n, q in ctb.named_parameters():
+        assert q.grad is not None, n
+        _close(q.grad.cpu(), torch.from_numpy(g[f"ctb_grad_{n}"]), 1e-4, f"ConvTransBlock d{n} vs reference class")
+
+
 def test_convtransblock_and_swatten_vs_reference_golden(dev):
     from clc_amd import layers
     from clc_amd.recipe import apply_weight_recipe

@@ -132,6 +132,27 @@ def block_large_goldens(ref):
             out[f"{typ}_grad_{n}"] = q.grad.numpy()
         print("block_large", typ, "y sum", float(out[f"{typ}_y_sum"]), "dx abs sum", float(out[f"{typ}_dx_abs_sum"]),
               "params", [n for n, _ in blk.named_parameters()])
+    # ... and the genuine ConvTransBlock (CLC_run.py:195-220: conv1_1 | ResidualBlock + identity || Block | conv1_2 + residual) at the same size:
+    # [2, 128, 128, 128] NCHW, 32 768 pixels -> the wave-private 1x1 kernel (conv1_1 / conv1_2), the 64-channel 3x3 layers, the fused Block,
+    # the gradient folds / slots of the product's ConvTransBlock
+    xc0 = torch.randn(2, 128, 128, 128, generator=torch.Generator().manual_seed(20252))
+    dyc = torch.randn(2, 128, 128, 128, generator=torch.Generator().manual_seed(20253))
+    out["ctb_seed_x"], out["ctb_seed_dy"] = np.int64(20252), np.int64(20253)
+    out["ctb_x_sha256"] = np.array(hashlib.sha256(xc0.numpy().tobytes()).hexdigest())
+    ctb = mod.ConvTransBlock(64, 64, 8, 8, 0, "SW").train()
+    apply_weight_recipe(ctb, 3)
+    xc = xc0.clone().requires_grad_(True)
+    yc = ctb(xc)
+    yc.backward(dyc)
+    for k, (b, r, c) in enumerate(patches):
+        out[f"ctb_y_patch{k}"] = yc.detach()[b, :, r:r + 8, c:c + 8].numpy()
+        out[f"ctb_dx_patch{k}"] = xc.grad[b, :, r:r + 8, c:c + 8].numpy()
+    for nm, t in (("y", yc.detach()), ("dx", xc.grad)):
+        out[f"ctb_{nm}_abs_sum"] = np.float64(t.double().abs().sum().item())
+        out[f"ctb_{nm}_chan_sums"] = t.double().sum(dim=(2, 3)).numpy()               # [2, 128] per image and channel
+    for n, q in ctb.named_parameters():
+        out[f"ctb_grad_{n}"] = q.grad.numpy()
+    print("block_large ctb: y abs sum", float(out["ctb_y_abs_sum"]), "params", len(list(ctb.named_parameters())))
     np.savez_compressed(os.path.join(OUT, "block_large.npz"), **out)
     print("block_large:", len(out), "arrays,", os.path.getsize(os.path.join(OUT, "block_large.npz")) // 1024, "KB")
 
