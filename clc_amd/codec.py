@@ -147,13 +147,16 @@ class _Plan:
 class CodecEngine:
     """engine = CodecEngine(model); outs = engine.compress(x[B], refs); xs = engine.decompress(outs, refs)."""
 
-    def __init__(self, model, threads: int = 8, use_graph: bool = True):
+    def __init__(self, model, threads: int = 8, use_graph: bool = True, max_plans: int = 0):
+        """max_plans > 0: keep at most that many captured signatures per direction (least recently used out first) — a data set of many
+        image sizes would otherwise pin one graph memory pool per size for the engine's lifetime."""
         model.eval()
         self.model = model          # (may be a weakref.proxy: the engine a model builds for its own compress() must not keep the model alive)
         self.use_graph = use_graph
         self.pool = ThreadPoolExecutor(max_workers=max(1, threads))
         self._enc = {}
         self._dec = {}
+        self.max_plans = int(max_plans)
         self.last = {}   # wall-clock split of the last compress() / decompress() call (ms): device segments incl. the hops' copies and waits | host rANS
         self.zc = int(model.entropy_bottleneck.channels)   # hyper-latent channels (192 in the reference configuration)
         model.update()   # CDF tables (no-op when present)
@@ -180,6 +183,15 @@ class CodecEngine:
             pass
 
     # ---------------------------------------------------------------- shared pieces
+    def _plan(self, table, sig, build):
+        pl = table.pop(sig, None)          # (re-inserted below: dict order = recency)
+        if pl is None:
+            while self.max_plans > 0 and len(table) >= self.max_plans:
+                table.pop(next(iter(table)))   # least recently used: its graphs, pool and pinned buffers go with it (outside any capture)
+            pl = build()
+        table[sig] = pl
+        return pl
+
     def _sig(self, x, refs):
         # (the kernel state is part of the signature: a captured graph keeps the kernels it was captured with, so a changed tuning /
         #  precision state must not replay the old plan — and the result's `kernel_config` must be the one that encoded)
@@ -253,9 +265,7 @@ class CodecEngine:
         if not getattr(self.model, "use_ref", True) or not hasattr(self.model, "ref_encoder"):
             refs = None
         sig = self._sig(x, refs)
-        pl = self._enc.get(sig)
-        if pl is None:
-            pl = self._enc[sig] = self._build_encoder(x, refs)
+        pl = self._plan(self._enc, sig, lambda: self._build_encoder(x, refs))
         t0 = time.perf_counter()
         pl.x.copy_(x, non_blocking=True)
         if refs is not None:
@@ -354,9 +364,7 @@ class CodecEngine:
         zshape = tuple(int(v) for v in items[0]["shape"])
         dev = next(m.parameters()).device
         sig = (B, zshape, None if refs is None else tuple(tuple(r.shape) for r in refs), kernel_config())
-        pl = self._dec.get(sig)
-        if pl is None:
-            pl = self._dec[sig] = self._build_decoder(B, zshape, refs, dev)
+        pl = self._plan(self._dec, sig, lambda: self._build_decoder(B, zshape, refs, dev))
         if refs is not None:
             for d, r in zip(pl.refs, refs):
                 d.copy_(r, non_blocking=True)

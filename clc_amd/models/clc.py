@@ -32,6 +32,7 @@ from ..ops import ACT_GELU, ACT_HALFTANH, ACT_NONE, CL
 
 SCALES_MIN, SCALES_MAX, SCALES_LEVELS = 0.11, 256, 64
 CODEC_GRAPH = os.environ.get("CLC_CODEC_GRAPH", "1") != "0"   # compress() / decompress() of one image on captured hipGraph segments
+CODEC_GRAPH_PLANS = int(os.environ.get("CLC_CODEC_GRAPH_PLANS", "6"))   # captured image sizes kept per model and direction (LRU)
 
 
 def get_scale_table(min=SCALES_MIN, max=SCALES_MAX, levels=SCALES_LEVELS):
@@ -353,7 +354,7 @@ class _SliceCodec(CompressionModel):
             was_training = self.training
             # (a proxy: model -> engine -> model would be a reference cycle, freed only by a garbage collection at some later time — e.g.
             #  inside another engine's graph capture, where releasing this one's graphs and pinned buffers is illegal)
-            eng = CodecEngine(weakref.proxy(self), threads=1)
+            eng = CodecEngine(weakref.proxy(self), threads=1, max_plans=CODEC_GRAPH_PLANS)
             self.train(was_training)
             self.__dict__["_codec_eng"], self.__dict__["_codec_eng_stamp"] = eng, self._codec_stamp()
         return eng

@@ -134,6 +134,15 @@ def test_reference_surface_single_image_codec_rides_on_captured_graphs(dev, kind
     rb = [torch.cat([refs[0][j], refs[1][j]]) for j in range(R)]
     eb = m.compress(xb, rb) if R else m.compress(xb)
     assert len(eb["strings"][0]) == 1 and len(eb["strings"][1]) == 2
+    # the model's own engine keeps a bounded number of captured sizes (least recently used out first)
+    eng2 = m.__dict__["_codec_eng"]
+    assert eng2.max_plans == mclc.CODEC_GRAPH_PLANS
+    eng2.max_plans = 1
+    other = torch.nn.functional.pad(imgs[0], (0, 128, 0, 0))      # another signature
+    ro = [torch.nn.functional.pad(r, (0, 128, 0, 0)) for r in refs[0]]
+    ao = m.compress(other, ro) if R else m.compress(other)
+    assert len(eng2._enc) == 1 and ao["strings"] == m._compress_eager(other, ro if R else None)["strings"]
+    eng2.max_plans = mclc.CODEC_GRAPH_PLANS
     old = mclc.CODEC_GRAPH
     mclc.CODEC_GRAPH = False
     try:
