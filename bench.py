@@ -343,8 +343,10 @@ def _kernel_name(L, r):
     if f in (4, 5):   # family 5 = the 1x1 instantiation (its own symbol)
         return (f"conv_igemm_dma2_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}, {1 if f == 5 else 3}, "
                 f"{(variant >> 24) & 3}, {'true' if (variant >> 26) & 1 else 'false'}>")   # (..., OP: 1 = squared operand (GDN's norm convolution), BF: bf16 MFMA)
-    if f == 12:       # halo-resident 3x3 kernel (csrc/conv_halo.hip): <TR, SHUF>
-        return f"conv_halo3x3_kernel<{'true' if (variant >> 1) & 1 else 'false'}, {'true' if variant & 1 else 'false'}>"
+    if f == 13:       # Winograd F(2x2, 3x3) kernel (csrc/conv_wino.hip): <SHUF>
+        return f"conv_wino_kernel<{'true' if variant & 1 else 'false'}>"
+    if f == 12:       # halo-resident 3x3 kernel (csrc/conv_halo.hip): <CI, TR, SHUF>
+        return f"conv_halo3x3_kernel<{64 * ((variant >> 4) & 15)}, {'true' if (variant >> 1) & 1 else 'false'}, {'true' if variant & 1 else 'false'}>"
     if f == 11:       # the wave-private persistent kernel of the 128 -> 128 / 64 -> 64 1x1 layers on large maps (csrc/fused_mlp.hip)
         return f"lin_kernel<{(variant >> 16) & 15}, {(variant >> 8) & 15}, {variant & 15}>"
     if f == 10:       # 16-column MFMAs for the <= 16-channel tail of the synthesis transform
@@ -414,6 +416,8 @@ def transforms_leg(model, x, refs, engine=None):
         engine.transposer.refresh()
         if getattr(engine, "halo_packer", None) is not None:
             engine.halo_packer.refresh()
+        if getattr(engine, "wino_packer", None) is not None:
+            engine.wino_packer.refresh()
         engine.gdn_cache.refresh()
     for name, fwd in cases.items():
         with torch.no_grad():

@@ -1418,6 +1418,10 @@ extern "C" int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream) {
   p.bf16 = clc_tuning[CLC_TUNE_BF16] != 0 && img_pix > 256;
   // 3x3 / stride 1 / 128 input channels with the filter also supplied in fragment order: halo-resident tile, filter streamed from L2 into
   // registers, no barrier in the K loop (conv_halo.hip; same K order and epilogue arithmetic -> same bits)
+  if ((clc_tuning[CLC_TUNE_WINO] & (d->transposed ? 2 : 1)) && d->w_wino && d->ks == 3 && d->stride == 1 && classes == 1) {
+    const int v = clc_conv_wino_launch(&p, d->w_wino, st);   // Winograd F(2x2, 3x3): conv_wino.hip
+    if (v) return v;
+  }
   if (clc_tuning[CLC_TUNE_HALO] && d->w_packed && d->ks == 3 && d->stride == 1 && classes == 1) {
     const int v = clc_conv_halo_launch(&p, d->w_packed, st);
     if (v) return v;

@@ -33,9 +33,9 @@ void clc_set_error(const char* fmt, ...) {
 extern "C" const char* clc_last_error(void) { return g_err; }
 extern "C" int clc_version(void) { return 200; }
 
-#define CLC_TUNING_DEFAULTS {2, 1, 1, 0, 1024, 64, 1, 8, 1, 1, 1, 1, 0, 1, 0, 1, 3, 1, 1, 1, 1, 1, 1}
-int clc_tuning[23] = CLC_TUNING_DEFAULTS;   // (CLC_TUNE_COUNT entries: csrc/common.h, which this host-only file cannot include)
-static const int clc_tuning_default[23] = CLC_TUNING_DEFAULTS;
+#define CLC_TUNING_DEFAULTS {2, 1, 1, 0, 1024, 64, 1, 8, 1, 1, 1, 1, 0, 1, 0, 1, 3, 1, 1, 1, 1, 1, 1, 3}
+int clc_tuning[24] = CLC_TUNING_DEFAULTS;   // (CLC_TUNE_COUNT entries: csrc/common.h, which this host-only file cannot include)
+static const int clc_tuning_default[24] = CLC_TUNING_DEFAULTS;
 extern "C" int clc_set_tuning(int key, int value) {
   if (key < 0 || key >= (int)(sizeof(clc_tuning) / sizeof(clc_tuning[0]))) { clc_set_error("clc_set_tuning: key %d out of range", key); return -1; }
   const int old = clc_tuning[key];
@@ -55,6 +55,8 @@ extern "C" int clc_get_tuning(int key) {
 //  order key of the codec path.)
 static uint32_t clc_order_hash(bool* dflt_out) {
   const int kGeneration = 6;
+  // (key 23 — Winograd kernel — reaches only launches that carry a transformed filter (clc_conv_desc.w_wino), which the host side hands over for
+  //  TRAINING forward passes and data gradients alone: not an order key of the codec path.)
   static const int order_keys[] = {0, 4, 5, 12, 14, 16};
   uint32_t h = 2166136261u ^ (uint32_t)kGeneration;
   bool dflt = true;

@@ -33,7 +33,7 @@ class ConvDesc(C.Structure):
                 ("res_gate", fp), ("ldg", C.c_int), ("res_gate_act", C.c_int), ("res_gate_pre", C.c_int),
                 ("out_gate", fp), ("ldog", C.c_int), ("out_gate_act", C.c_int), ("out_gate_pre", C.c_int),
                 ("w3", fp), ("bias3", fp), ("w4", fp), ("bias4", fp),
-                ("workspace", fp), ("workspace_bytes", C.c_size_t), ("batch_variant_ok", C.c_int), ("w_packed", fp)]
+                ("workspace", fp), ("workspace_bytes", C.c_size_t), ("batch_variant_ok", C.c_int), ("w_packed", fp), ("w_wino", fp)]
 
 
 class WgradDesc(C.Structure):
@@ -75,6 +75,10 @@ class TransposeEntry(C.Structure):
     _fields_ = [("w", fp), ("wt", fp), ("Cout", C.c_int), ("T", C.c_int), ("Cin", C.c_int), ("tile_begin", C.c_int)]
 
 
+class WinoEntry(C.Structure):
+    _fields_ = [("w", fp), ("out", fp), ("N", C.c_int), ("K", C.c_int), ("flip", C.c_int), ("block_begin", C.c_int)]
+
+
 class HaloPackEntry(C.Structure):
     _fields_ = [("w", fp), ("out", fp), ("N", C.c_int), ("K", C.c_int), ("block_begin", C.c_int)]
 
@@ -110,6 +114,8 @@ SIGNATURES = {
     "clc_filter_transpose": (_i, [fp, fp, _i, _i, _i, fp]),
     "clc_filter_pack_halo": (_i, [fp, fp, _i, _i, fp]),
     "clc_filter_pack_halo_batched": (_i, [fp, _i, _i, fp]),
+    "clc_filter_wino": (_i, [fp, fp, _i, _i, _i, fp]),
+    "clc_filter_wino_batched": (_i, [fp, _i, _i, fp]),
     "clc_filter_transpose_batched": (_i, [fp, _i, _i, fp]),
     "clc_partial_reduce_batched": (_i, [C.POINTER(ReduceEntry), _i, fp]),
     "clc_act_bwd": (_i, [fp, _i, fp, _i, _i, _i, fp, _i, _l, _i, fp]),
@@ -219,6 +225,8 @@ def load():
     for item in filter(None, os.environ.get("CLC_TUNING", "").split(",")):
         k, v = item.split(":")
         L.clc_set_tuning(int(k), int(v))
+    if os.environ.get("CLC_WINO"):   # Winograd F(2x2, 3x3) for the 128-channel 3x3 layers (tuning key 23): bit 0 forward, bit 1 data gradients
+        L.clc_set_tuning(23, int(os.environ["CLC_WINO"]))
     _lib = L
     return L
 

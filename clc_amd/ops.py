@@ -584,10 +584,44 @@ def halo_packed(w, transposed_image=None):
     return halo_pack(to_kernel_weight(w), w.shape[0], w.shape[1])
 
 
+# ---- Winograd F(2x2, 3x3) kernel (csrc/conv_wino.hip): needs the TRANSFORMED filter U = G g G^T in fragment order.  Same provenance rules as the
+# halo kernel's image: per-step batched launch inside a TrainEngine step (clc_amd.train.WinoPacker -> w._clc_wu / w._clc_wu_t), per use elsewhere.
+# (switched by tuning key 23 / the CLC_WINO environment variable: bit 0 = forward launches of a recorded (training) pass, bit 1 = data gradients.
+#  Never taken without autograd recording: eval forwards, the parity measurement and the codec keep the direct kernels and their bits.)
+
+
+def wino_ok(N, H, W, Cin, rows, ks, stride, transposed=False):
+    """may a [rows][3][3][Cin] filter on an N x H x W map take the Winograd kernel?  (the C side re-checks everything and falls through)"""
+    if not (_L().clc_get_tuning(23) & (2 if transposed else 1)):
+        return False
+    # (a per-IMAGE rule, so that an image's result does not depend on the batch it is in)
+    return (ks == 3 and stride == 1 and Cin % 128 == 0 and Cin <= 1024 and rows % 128 == 0 and H % 8 == 0 and W % 16 == 0
+            and (H // 8) * (W // 16) * (rows // 128) >= 32)
+
+
+def wino_pack(wk, rows, K, flip=False):
+    """[rows][9][K] filter rows -> U = G g G^T in fragment order (clc_filter_wino; 16 / 9 of the size).  flip: taps reversed (data gradients)."""
+    out = torch.empty(rows * 16 * K, device=wk.device, dtype=torch.float32)
+    _lib.check(_L().clc_filter_wino(wk.data_ptr(), out.data_ptr(), int(rows), int(K), int(bool(flip)), _stream()), "clc_filter_wino")
+    return out
+
+
+def wino_packed(w, transposed_image=None):
+    tr = transposed_image is not None
+    setattr(w, "_clc_wino_use_t" if tr else "_clc_wino_use", True)
+    if WT_CACHE_VALID:
+        u = getattr(w, "_clc_wu_t" if tr else "_clc_wu", None)
+        if u is not None:
+            return u
+    if tr:
+        return wino_pack(transposed_image, transposed_image.shape[0], w.shape[0], flip=True)
+    return wino_pack(to_kernel_weight(w), w.shape[0], w.shape[1])
+
+
 def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_NONE, norm=NORM_NONE, mul=None,
              res=None, res_scale=1.0, res_first=False, y_pre=None, shuffle=False, transposed=False, out=None, out_hw=None,
              xs=None, xs_act=ACT_NONE, xs_pre=False, w2=None, bias2=None, pre_deriv=False, res_gate=None, out_gate=None, wx=None, batch_variant_ok=False,
-             wpk=None):
+             wpk=None, wwino=None):
     """One clc_conv2d launch. ``w`` must already be in kernel layout [Cout][ks][ks][Cin].
     wpk: the same filter in the halo kernel's fragment order (halo_packed / halo_pack), or None.
     batch_variant_ok: the summation order may depend on the batch size (training forward passes only, never the codec path).
@@ -650,6 +684,9 @@ def conv_raw(x, w, bias=None, *, ks, stride=1, pad=None, act=ACT_NONE, in_op=IN_
     if wpk is not None:   # the same filter in conv_halo3x3_kernel's fragment order: clc_conv2d takes that kernel when the launch qualifies
         d.w_packed = wpk.data_ptr()
         keep.append(wpk)
+    if wwino is not None:   # ... or its Winograd transform (takes precedence)
+        d.w_wino = wwino.data_ptr()
+        keep.append(wwino)
     if (transposed and H * W <= 1024) or (batch_variant_ok and ks == 3 and OH * OW <= 256):   # scratch for the K split of under-filled grids (0 bytes: no split)
         nws = _lib.load().clc_conv2d_workspace_bytes(C.byref(d))
         if nws:
@@ -859,9 +896,11 @@ class _ConvFn(Function):
         # GELU: the epilogue stores gelu'(v) (it has v in a register) instead of v, so the backward is one multiply inside
         # the gradient kernels' loaders — no erf/exp there and no elementwise dz pass
         deriv = save_pre and act == ACT_GELU
-        wpk = halo_packed(w) if (w2 is None and halo_ok(N, H, W, w.shape[1], Cout, ks, stride) and wk is w) else None
+        # (Winograd: TRAINING forward passes only — its bits differ from the direct kernels', and inference / codec results must not move)
+        wwino = wino_packed(w) if (need_grad and w2 is None and wk is w and wino_ok(N, H, W, w.shape[1], Cout, ks, stride)) else None
+        wpk = halo_packed(w) if (wwino is None and w2 is None and halo_ok(N, H, W, w.shape[1], Cout, ks, stride) and wk is w) else None
         y = conv_raw(x, wk, b, ks=ks, stride=stride, act=act, res=res, res_scale=res_scale, res_first=res_first, y_pre=y_pre, shuffle=shuffle,
-                     w2=wk2, bias2=b2, pre_deriv=deriv, out=out_buf, wx=wkx, batch_variant_ok=need_grad, wpk=wpk)
+                     w2=wk2, bias2=b2, pre_deriv=deriv, out=out_buf, wx=wkx, batch_variant_ok=need_grad, wpk=wpk, wwino=wwino)
         if out_buf is not None:   # written in place into the caller's (strided) buffer: hand autograd a fresh alias of it
             y = out_buf.detach()
         ctx.cfg = (ks, stride, ACT_SAVED_DERIV if deriv else act, res_scale, shuffle, b is not None, res is not None, res_first)
@@ -985,10 +1024,11 @@ class _ConvFn(Function):
                 gate_in.done = True
             wt1 = wt_of(w)
             # (data gradient of a 128 -> 128 layer: rows = Cin, K = 9 x Cout = 9 x 128)
-            wpk = (halo_packed(w, wt1) if (w2 is None and not fa and halo_ok(dz.shape[0], dz.shape[2], dz.shape[3], Cout, Cin, ks, stride)) else None)
+            wwino = (wino_packed(w, wt1) if (w2 is None and not fa and wino_ok(dz.shape[0], dz.shape[2], dz.shape[3], Cout, Cin, ks, stride, transposed=True)) else None)
+            wpk = (halo_packed(w, wt1) if (wwino is None and w2 is None and not fa and halo_ok(dz.shape[0], dz.shape[2], dz.shape[3], Cout, Cin, ks, stride)) else None)
             dx = conv_raw(dz, wt1, None, ks=ks, stride=stride, pad=pad, transposed=True, out_hw=(x.shape[2], x.shape[3]),
                           w2=(wt_of(w2) if w2 is not None else None), wx=(((wt_of(w3), None), (wt_of(w4), None)) if w3 is not None else None),
-                          res=extra, res_scale=extra_scale, res_gate=gate, out=dx_out, out_gate=og, wpk=wpk, **fa)
+                          res=extra, res_scale=extra_scale, res_gate=gate, out=dx_out, out_gate=og, wpk=wpk, wwino=wwino, **fa)
         elif fold_in is not None:
             fold_in.consumed = True
         if dx is not None and ctx.park_dx is not None and ctx.park_dx.park(dx):

@@ -313,6 +313,43 @@ class HaloPacker:
             _lib.check(ops._L().clc_filter_pack_halo_batched(self.table.data_ptr(), self.n, self.total_blocks, ops._stream()), "clc_filter_pack_halo_batched")
 
 
+class WinoPacker:
+    """Winograd-transformed images U = G g G^T of the filters conv_wino_kernel takes (csrc/conv_wino.hip), refreshed by ONE launch per step
+    (clc_filter_wino_batched) behind the batched transpose.  Which filters: the ones the discovery pass marked (ops.wino_packed:
+    `_clc_wino_use` forward, `_clc_wino_use_t` data gradient).  ops.wino_packed() hands the images out while ops.WT_CACHE_VALID is set."""
+
+    def __init__(self, params: List[nn.Parameter]):
+        jobs = []   # (parameter, source, rows, K, flip, attribute)
+        for p in params:
+            if p.dim() != 4 or not getattr(p, "_clc_is_filter", False) or ops.to_kernel_weight(p) is not p:
+                continue
+            if getattr(p, "_clc_wino_use", False):
+                jobs.append((p, p, p.shape[0], p.shape[1], 0, "_clc_wu"))
+            wt = getattr(p, "_clc_wt", None)
+            if getattr(p, "_clc_wino_use_t", False) and wt is not None:    # [Cin][9][Cout]: rows = Cin, K = Cout, taps flipped
+                jobs.append((p, wt, p.shape[1], p.shape[0], 1, "_clc_wu_t"))
+        self.n = len(jobs)
+        if not jobs:
+            return
+        dev = jobs[0][0].device
+        total = sum(rows * 16 * K for _, _, rows, K, _, _ in jobs)
+        self.buf = torch.empty(total, dtype=torch.float32, device=dev)
+        entries, off, blocks = [], 0, 0
+        for p, src, rows, K, flip, attr in jobs:
+            n = rows * 16 * K
+            out = self.buf[off: off + n]
+            off += n
+            setattr(p, attr, out)
+            entries.append(_lib.WinoEntry(src.data_ptr(), out.data_ptr(), int(rows), int(K), int(flip), blocks))
+            blocks += (rows * K // 4 + 255) // 256
+        self.total_blocks = blocks
+        self.table = torch.frombuffer(bytearray(b"".join(bytes(e) for e in entries)), dtype=torch.uint8).to(dev)
+
+    def refresh(self):
+        if self.n:
+            _lib.check(ops._L().clc_filter_wino_batched(self.table.data_ptr(), self.n, self.total_blocks, ops._stream()), "clc_filter_wino_batched")
+
+
 class GDNReparamCache:
     """The effective (re-parametrised) gamma / beta of every GDN module — and gamma transposed for the data-gradient conv — refreshed by ONE
     launch per step (clc_gdn_reparam_fwd_batched) instead of one launch per module inside the forward pass.  Like the transposed filter
@@ -407,6 +444,7 @@ class TrainEngine:
         self.aux_opt = self._make_opt(aux, self.aux_lr, 0.0)
         self.transposer = FilterTransposer(live)
         self.halo_packer = HaloPacker(live)
+        self.wino_packer = WinoPacker(live)
         self.gdn_cache = GDNReparamCache(self.model, live)
         cut = self.opt.p_arena.offsets[len(late)] if (late and early) else 0
         n_el = self.opt.grad_flat.numel()
@@ -440,6 +478,7 @@ class TrainEngine:
         self.aux_opt.zero_grad()
         self.transposer.refresh()
         self.halo_packer.refresh()
+        self.wino_packer.refresh()
         self.gdn_cache.refresh()
         ops.WT_CACHE_VALID = True      # (the transposed filter images are this step's: see ops.WT_CACHE_VALID)
         try:
@@ -457,6 +496,7 @@ class TrainEngine:
         self.aux_opt.zero_grad()
         self.transposer.refresh()
         self.halo_packer.refresh()
+        self.wino_packer.refresh()
         self.gdn_cache.refresh()
         self.model._keep_boundary = True
         ops.WT_CACHE_VALID = True

@@ -125,6 +125,13 @@ typedef struct {
    * filter).  With it, 3x3 / stride-1 / pad-1 layers with 128 (64) input channels and a multiple of 128 (64) output channels on maps whose
    * height is a multiple of 8 and width of 16 run on the halo-resident kernel (csrc/conv_halo.hip) — same bits as the tiled kernels.  NULL: tiled. */
   const float* w_packed;
+  /* optional: the filter's Winograd F(2x2, 3x3) transform in fragment order (clc_filter_wino; for transposed = 1: of the transposed filter, taps
+   * flipped).  With it, 3x3 / stride-1 / pad-1 layers with 128 k input and 128 k output channels on maps whose height is a multiple of 8 and
+   * width of 16 run on conv_wino_kernel (csrc/conv_wino.hip): 2.25x fewer multiplications, ANOTHER summation order than the direct kernels
+   * (fp32 error of a few ulp of the operands; measured 4..9e-7 of the largest output against fp64, the direct kernels 1.3e-6).  Takes precedence
+   * over w_packed.  For TRAINING launches (forward of a recorded pass, data gradients): a launch whose result feeds the entropy coder or a parity
+   * measurement leaves it NULL (direct kernels) — the codec's kernel_config tag does not cover this kernel. */
+  const float* w_wino;
 } clc_conv_desc;
 
 int clc_conv2d(const clc_conv_desc* d, clc_stream_t stream);
@@ -135,6 +142,12 @@ int clc_filter_pack_halo(const float* w, float* out, int N, int K, clc_stream_t 
  * 16-B elements) over the preceding entries, total_blocks = the grand total */
 typedef struct { const float* w; float* out; int N, K, block_begin; } clc_halo_pack_entry;
 int clc_filter_pack_halo_batched(const clc_halo_pack_entry* table_dev, int n_entries, int total_blocks, clc_stream_t stream);
+/* [N][3][3][K] filter rows (N, K multiples of 128) -> `out` (16 / 9 of the floats): U = G g G^T per (row, channel) in the fragment order
+ * clc_conv_desc.w_wino expects; flip = 1 reverses the taps (data gradients: pass the transposed filter).  The batched form: device table,
+ * block_begin = running sum of ceil(N * K / 4 / 256). */
+int clc_filter_wino(const float* w, float* out, int N, int K, int flip, clc_stream_t stream);
+typedef struct { const float* w; float* out; int N, K, flip, block_begin; } clc_wino_entry;
+int clc_filter_wino_batched(const clc_wino_entry* table_dev, int n_entries, int total_blocks, clc_stream_t stream);
 /* scratch bytes with which clc_conv2d would split this launch's K range (0: it would not split) */
 size_t clc_conv2d_workspace_bytes(const clc_conv_desc* d);
 

@@ -61,3 +61,21 @@ def test_world_size_mismatch_is_an_error():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120,
                        env=dict(os.environ, PYTHONPATH=ROOT, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_recorded_launches_map_to_the_profilers_kernel_names():
+    """bench.py's roofline leg joins its live per-launch HIP-event times with `rocprofv3 --kernel-trace` names: every variant id the conv entry
+    point can return must have a name (an unnamed family stopped the 2-rank bench once), and the names are the instantiations' own."""
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    from clc_amd import lib
+
+    L = lib.load()
+    rec = lambda variant, label="fwd 128->128": types.SimpleNamespace(fam="conv_igemm", variant=variant, label=label)
+    assert bench._kernel_name(L, rec((13 << 20) | (1 << 4) | 1)) == "conv_wino_kernel<true>"
+    assert bench._kernel_name(L, rec((13 << 20) | (4 << 4) | 2, "dgrad 512->128")) == "conv_wino_kernel<false>"
+    assert bench._kernel_name(L, rec((12 << 20) | (2 << 4) | 2, "dgrad 128->128")) == "conv_halo3x3_kernel<128, true, false>"
+    assert bench._kernel_name(L, rec((12 << 20) | (1 << 4) | 1)) == "conv_halo3x3_kernel<64, false, true>"
+    for fam in (1, 2, 3, 4, 5, 8, 10, 11, 12, 13):
+        assert bench._kernel_name(L, rec((fam << 20) | (2 << 16) | (16 << 3) | 4)).split("<")[0].endswith("kernel")

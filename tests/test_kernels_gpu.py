@@ -1335,3 +1335,139 @@ def test_halo_filter_pack_is_the_documented_fragment_order(dev, rows, K):
     want = src[:, None] + np.arange(4)[None, :]
     assert pk.shape[0] == rows * 9 * K // 4 and np.array_equal(pk, want.astype(np.float32))
     assert np.array_equal(np.sort(pk.reshape(-1)), np.arange(rows * 9 * K, dtype=np.float32))    # a permutation: nothing dropped, nothing twice
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,mode", [
+    (8, 64, 64, 128, 128, "plain"), (2, 128, 128, 128, 128, "lrelu_res"), (8, 32, 32, 128, 512, "shuffle_lrelu"), (2, 64, 64, 128, 512, "shuffle"),
+    (8, 64, 64, 128, 128, "dgrad_gate"), (3, 48, 96, 128, 128, "plain"), (1, 256, 256, 128, 128, "pre"), (2, 64, 64, 256, 128, "plain"),
+    (2, 64, 64, 128, 512, "dgrad_gate"), (3, 72, 80, 128, 128, "strided"), (1, 64, 128, 128, 128, "plain")])
+def test_wino_conv_vs_direct_and_fp64(dev, N, H, W, Cin, Cout, mode):
+    """conv_wino_kernel (csrc/conv_wino.hip: Winograd F(2x2, 3x3) for 3x3 / stride-1 layers with 128 k channels; input transform B^T d B from an
+    LDS-resident halo, 16 batched MFMA GEMMs against the pre-transformed filter U = G g G^T, output transform A^T M A through LDS into the
+    shared epilogues) on the launches the training step gives it — forward with bias / LeakyReLU / residual / saved pre-activation, the
+    PixelShuffle store of the sub-pixel convolutions (/root/reference/models/CLC_run.py:28-30), the data gradient with the consumer-side
+    activation gate and a 512-channel K range, channel ranges of wider buffers, image borders, non-power-of-two maps.  ANOTHER summation
+    order than the direct kernels, so not their bits: held to an fp64 convolution at least as tightly as the direct kernel is (both errors
+    printed), and to the direct kernel within 4e-6 of the largest output."""
+    from clc_amd import lib, ops
+    from clc_amd.ops import ACT_LRELU
+
+    L = lib.load()
+    restore = L.clc_set_tuning(23, 3)
+    try:
+        g = torch.Generator().manual_seed(N * 1000 + H + Cout)
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).to(dev).contiguous(memory_format=CL)
+        b = (torch.randn(Cout, generator=g) * 0.1).to(dev)
+        wk = ops.to_kernel_weight(w)
+        kw = dict(ks=3, stride=1)
+        tr = mode.startswith("dgrad")
+        if tr:   # "x" is dY [N, Cout, H, W]; the launch's K channels = Cout, its rows = Cin
+            x = _dev(torch.randn(N, Cout, H, W, generator=g), dev)
+            assert ops.wino_ok(N, H, W, Cout, Cin, 3, 1, transposed=True)
+            wt = ops.filter_transpose(wk, Cout, 9, Cin).view(Cin, -1)
+            u = ops.wino_pack(wt, Cin, Cout, flip=True)
+            gate = _dev(torch.randn(N, Cin, H, W, generator=g), dev)
+            res = _dev(torch.randn(N, Cin, H, W, generator=g), dev)
+            run = lambda wwino: ops.conv_raw(x, wt, None, ks=3, stride=1, pad=1, transposed=True, out_hw=(H, W), out_gate=(gate, ACT_LRELU, False),
+                                             res=res, res_scale=0.25, wwino=wwino)
+            ref = F.conv_transpose2d(x.double().cpu(), w.double().cpu(), padding=1)
+            gc = gate.double().cpu()
+            ref = (ref + 0.25 * res.double().cpu()) * torch.where(gc > 0, 1.0, 0.01)     # out_gate: the WHOLE result times act'(saved)
+        else:
+            wide = _dev(torch.randn(N, 2 * Cin, H, W, generator=g), dev)
+            x = wide[:, Cin:] if mode == "strided" else _dev(torch.randn(N, Cin, H, W, generator=g), dev)
+            assert ops.wino_ok(N, H, W, Cin, Cout, 3, 1)
+            ref = F.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), padding=1)
+            if mode in ("plain", "strided"):
+                kw.update(bias=b)
+            elif mode in ("lrelu_res", "pre"):
+                r = _dev(torch.randn(N, Cout, H, W, generator=g), dev)
+                kw.update(bias=b, act=ACT_LRELU, res=r, res_scale=0.5)
+                if mode == "pre":
+                    kw.update(y_pre=ops.new_act(N, Cout, H, W, x))
+                pre_ref = ref
+                ref = F.leaky_relu(ref, 0.01) + 0.5 * r.double().cpu()
+            elif mode == "shuffle_lrelu":
+                kw.update(bias=b, act=ACT_LRELU, shuffle=True)
+                ref = F.pixel_shuffle(F.leaky_relu(ref, 0.01), 2)
+            elif mode == "shuffle":
+                kw.update(bias=b, shuffle=True)
+                ref = F.pixel_shuffle(ref, 2)
+            outw = ops.new_act(N, 2 * Cout, H, W, wide) if mode == "strided" else None
+            run = lambda wwino: ops.conv_raw(x, wk, kw.get("bias"), **{k: v for k, v in kw.items() if k != "bias"}, wwino=wwino,
+                                             out=(outw[:, :Cout] if outw is not None else None))
+            u = ops.wino_pack(wk, Cout, Cin)
+        ops.PROFILE = []
+        try:
+            y_w = run(u).clone()
+            pre_w = kw["y_pre"].clone() if "y_pre" in kw else None
+            y_d = run(None).clone()
+            torch.cuda.synchronize()
+            variants = [r.variant >> 20 for r in ops.PROFILE if r.fam == "conv_igemm"]
+        finally:
+            ops.PROFILE = None
+        assert variants[0] == 13 and variants[1] != 13, variants          # the Winograd kernel ran, then a direct one
+        scale = ref.abs().max().item()
+        e_w = (y_w.double().cpu() - ref).abs().max().item() / scale
+        e_d = (y_d.double().cpu() - ref).abs().max().item() / scale
+        print(f"wino {N}x{H}x{W} {Cin}->{Cout} {mode}: err vs fp64 winograd {e_w:.2e} direct {e_d:.2e}")
+        assert e_w < 3e-6 and e_w < 1.5 * e_d + 2e-7, (e_w, e_d)
+        assert (y_w - y_d).abs().max().item() / scale < 4e-6
+        if pre_w is not None:
+            assert (pre_w.double().cpu() - pre_ref).abs().max().item() / pre_ref.abs().max().item() < 3e-6
+        # an image's result does not depend on the batch it is in (per-image eligibility, per-item arithmetic)
+        if not tr and mode == "plain" and N > 1:
+            one = ops.conv_raw(x[:1].contiguous(memory_format=CL), wk, b, ks=3, stride=1, wwino=u)
+            assert torch.equal(one, y_w[:1])
+        # the tuning key switches it off (bit 0: forward launches, bit 1: data gradients)
+        L.clc_set_tuning(23, 1 if tr else 2)
+        ops.PROFILE = []
+        try:
+            y_off = run(u).clone()
+            assert (ops.PROFILE[0].variant >> 20) != 13
+        finally:
+            ops.PROFILE = None
+        assert torch.equal(y_off, y_d)
+    finally:
+        L.clc_set_tuning(23, restore)
+
+
+def test_wino_forward_is_training_only(dev):
+    """The Winograd kernel's bits are not the direct kernels': it may serve a recorded (training) forward and the data gradients, never an eval /
+    no_grad forward — the parity measurement, the codec and `model.forward` under no_grad keep their bits whatever tuning key 23 says."""
+    from clc_amd import lib, ops
+
+    L = lib.load()
+    g = torch.Generator().manual_seed(5)
+    x = _dev(torch.randn(2, 128, 64, 64, generator=g), dev).requires_grad_(True)
+    w = torch.nn.Parameter((torch.randn(128, 128, 3, 3, generator=g) * 0.05).to(dev).contiguous(memory_format=CL))
+    b = torch.nn.Parameter(torch.zeros(128, device=dev))
+
+    def fams(fn):
+        ops.PROFILE = []
+        try:
+            y = fn()
+            torch.cuda.synchronize()
+            return y, [r.variant >> 20 for r in ops.PROFILE if r.fam == "conv_igemm"]
+        finally:
+            ops.PROFILE = None
+
+    restore = L.clc_set_tuning(23, 3)
+    try:
+        with torch.no_grad():
+            y_eval, v = fams(lambda: ops.conv2d(x, w, b))
+        assert 13 not in v, v
+        y_tr, v = fams(lambda: ops.conv2d(x, w, b))
+        assert v == [13], v
+        L.clc_set_tuning(23, 0)
+        with torch.no_grad():
+            y_off, _ = fams(lambda: ops.conv2d(x, w, b))
+        assert torch.equal(y_eval, y_off)
+        assert (y_tr - y_eval).abs().max().item() / y_eval.abs().max().item() < 4e-6
+        L.clc_set_tuning(23, 3)
+        _, v = fams(lambda: y_tr.square().sum().backward())
+        ops.flush_wgrads()
+        assert 13 in v, v       # the data gradient took it too
+        assert x.grad is not None and torch.isfinite(x.grad).all()
+    finally:
+        L.clc_set_tuning(23, restore)

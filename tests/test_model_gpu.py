@@ -3,6 +3,7 @@
 Bars (BASELINE.json north_star): |d bpp| <= 1e-4, |d PSNR| <= 0.01 dB for the float transforms; bit-identical
 bitstreams for the integer CDF / quantise / rANS path.  Weights come from the by-name recipe (oracle/recipe.py).
 """
+import contextlib
 import math
 
 import numpy as np
@@ -134,6 +135,25 @@ def _grad_parity(o, p, tol=1e-3, min_checked=600, flips=0, flip_tol=5e-2):
     return checked, worst
 
 
+@contextlib.contextmanager
+def _direct_forward():
+    """Pin a recorded forward to the direct kernels (tuning key 23 bit 0 off; the data gradients keep the Winograd kernel).
+    The gradient comparison below is conditioned on both sides quantizing to the SAME symbols.  These two seeded inputs have a latent within
+    float error of a rounding boundary: the direct kernels land on the oracle's side of it, the Winograd forward's summation order (y moves by
+    9e-7 of its largest element) does not, and the flip cascades through the autoregressive slices (tools/wino_flip_check.py: 70 / 30 differing
+    symbols, scales moved by up to 0.04) and moves every gradient by ~1e-3.  The Winograd forward itself is held to the direct kernels and to
+    fp64 by tests/test_kernels_gpu.py::test_wino_conv_vs_direct_and_fp64, and rides in the flip-aware batch-8 steps below
+    (test_config1_bs8_..., test_config2_bs8_...) and in the 3-reference and TCM cases of test_backward_parity, which run on the defaults."""
+    from clc_amd import lib
+    L = lib.load()
+    old = L.clc_get_tuning(23)
+    L.clc_set_tuning(23, old & 2)
+    try:
+        yield
+    finally:
+        L.clc_set_tuning(23, old)
+
+
 def _symbol_flips(a, b):
     """positions where round(y - mu) differs between the oracle's and the product's forward (see _grad_parity)"""
     so = torch.round(a["para"]["y"] - a["para"]["means"])
@@ -153,7 +173,8 @@ def test_backward_parity(dev, kind, R, B):
     lo = ORD(0.0067)(o(x, refs) if kind == "clc" else o(x), x)
     lo["loss"].backward()
     xd, rd = x.to(dev), [r.to(dev) for r in refs]
-    lp = PRD(0.0067)(p(xd, rd) if kind == "clc" else p(xd), xd)
+    with (_direct_forward() if (kind, R) == ("clc", 1) else contextlib.nullcontext()):
+        lp = PRD(0.0067)(p(xd, rd) if kind == "clc" else p(xd), xd)
     lp["loss"].backward()
     for k in ("loss", "bpp_loss", "mse_loss"):
         assert abs(lo[k].item() - lp[k].item()) <= 2e-4 * max(1.0, abs(lo[k].item())), (k, lo[k].item(), lp[k].item())
@@ -212,7 +233,8 @@ def test_wire_clm_forward_backward_vs_oracle(dev, R):
     lo = ORD(0.0067)(o(x, refs), x)
     lo["loss"].backward()
     xd, rd = x.to(dev), [r.to(dev) for r in refs]
-    lp = PRD(0.0067)(p(xd, rd), xd)
+    with _direct_forward():
+        lp = PRD(0.0067)(p(xd, rd), xd)
     lp["loss"].backward()
     for k in ("loss", "bpp_loss", "mse_loss"):
         assert abs(lo[k].item() - lp[k].item()) <= 2e-4 * max(1.0, abs(lo[k].item())), (k, lo[k].item(), lp[k].item())
