@@ -32,7 +32,7 @@ enum { CLC_TUNE_DMA_LOOP = 0 /* 1: conv_igemm_dma_kernel, 2: conv_igemm_dma2_ker
        CLC_TUNE_N16 = 20 /* <= 16 output channels on large maps (the 12-channel tail of g_s): 16-column MFMAs (v_mfma_f32_16x16x4_f32); ANOTHER summation order */,
        CLC_TUNE_LIN = 21 /* 128 -> 128 / 64 -> 64 1x1 layers on >= 32 768 rows: the wave-private persistent kernel with whole-line stores (fused_mlp.hip: lin_kernel; same bits) */,
        CLC_TUNE_HALO = 22 /* 3x3 / stride-1 layers with 128 input channels whose caller supplies the packed filter (clc_conv_desc.w_packed): the halo-resident barrier-free kernel (conv_halo.hip; same bits); bit mask: 1 = 128-input-channel layers, 2 = 64-input-channel layers */,
-       CLC_TUNE_WINO = 23 /* 3x3 / stride-1 layers with 128 k input channels whose caller supplies the Winograd-transformed filter (clc_conv_desc.w_wino): conv_wino_kernel (F(2x2, 3x3); ANOTHER summation order); bit mask: 1 = forward launches, 2 = data gradients */,
+       CLC_TUNE_WINO = 23 /* 3x3 / stride-1 layers with 128 k input channels whose caller supplies the Winograd-transformed filter (clc_conv_desc.w_wino): conv_wino_kernel / conv_wino64_kernel (F(2x2, 3x3); ANOTHER summation order); bit mask: 1 = forward launches, 2 = data gradients, 4 = the 64-wide kernel for layers of 64 k channels, 8 = the 64-wide kernel on every layer (experiment) */,
        CLC_TUNE_COUNT = 24 };
 extern int clc_tuning[CLC_TUNE_COUNT];
 // fused_mlp.hip: y = W x + b (+ res_scale * res) on the wave-private persistent kernel; 0 = shape not built (the caller falls through)

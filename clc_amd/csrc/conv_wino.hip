@@ -18,7 +18,8 @@
 //     one (tile, 4 channels, output row) and hands its two pixels to the SHARED epilogue (epilogue_store4 / epilogue_store: bias, activation,
 //     residual, gates, saved pre-activation, PixelShuffle — everything the tiled kernels do).
 // Input channels beyond 128 (data gradients of the sub-pixel convolutions: 512) pass through the halo 128 at a time.
-// ANOTHER summation order than the direct kernels (transformed domain): the codec's kernel generation counts it (rans_host.cpp).
+// ANOTHER summation order than the direct kernels (transformed domain): the host side hands the transformed filter (clc_conv_desc.w_wino) to
+// TRAINING launches only — recorded forwards and data gradients; eval forwards, the parity measurement and the codec keep the direct kernels' bits.
 #include "common.h"
 
 namespace {
@@ -194,6 +195,179 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(const WinoParams wp) 
   }
 }
 
+// ---- the 64-wide instantiation: 64 input channels resident (45 KB halo), 64 output channels per item, 16-channel chunks (V: 32 KB) — 78 KB of LDS and
+// <= 256 VGPRs, so TWO workgroups of 4 waves share a CU and one's transforms / output rounds run under the other's MFMAs.  Wave w owns row w of
+// the 4 x 4 transformed positions (xi = 4 w .. 4 w + 3): 4 x (32 tiles x 64 out) accumulators, 64 MFMAs per chunk.  Takes the 64 -> 64 layers of
+// the transforms' first / last stages (128 x 128 maps at 256 x 256 input), which the 128-wide kernel cannot.
+constexpr int HALO2_FLOATS = HPIX * 64;   // 46 080 B
+constexpr int V2_FLOATS = 16 * 32 * 16;   // 32 768 B
+constexpr int PIECES2 = HPIX / 4;         // 1-KB LDS-DMA pieces (four pixels each)
+
+template <bool SHUF>
+__global__ __launch_bounds__(256, 2) void conv_wino64_kernel(const WinoParams wp) {
+  const ConvParams& p = wp.c;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* halo = smem;                  // [HPIX][64], 16-B chunk c of halo pixel (hy, hx) in slot c ^ (hx & 15)
+  float* V = smem + HALO2_FLOATS;      // [16][32][16]: chunk q of row t in slot q ^ ((t >> 2) & 3)
+  float* S = smem;                     // output rounds: [16][32][32] over the halo and the head of V (both free by then)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int tiles_w = p.W / TW, tiles_h = p.H / TH;
+  const int KCT = wp.ncg * 2;          // 32-channel chunks of the packed filter (wp.ncg: groups of 64 input channels)
+  const int NC16 = wp.ncg * 4;         // 16-channel chunks in all
+  const int i0 = (int)((long)wp.items * blockIdx.x / gridDim.x), i1 = (int)((long)wp.items * (blockIdx.x + 1) / gridDim.x);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp.u), 0, wp.u_bytes, 0x00020000);
+  // input-transform role: (tile t, 16-B chunk q of the 16-channel chunk, half); output-transform role: (tile to, 16-B chunk qo of a 32-channel block)
+  const int q = tid & 3, t = (tid >> 2) & 31, half = tid >> 7;
+  const int ty = t >> 3, tx = t & 7;
+  const int qo = tid & 7, to = tid >> 3;
+  int afo[2];
+#pragma unroll
+  for (int t8 = 0; t8 < 2; ++t8) afo[t8] = li * 16 + (((2 * t8 + h) ^ ((li >> 2) & 3)) << 2);
+  const unsigned b_lane = (unsigned)lane * 16u;
+
+  int cur_pt = -1, cur_cg = -1;
+  for (int it = i0; it < i1; ++it) {
+    const int pt = it / wp.ntn, nt = it - pt * wp.ntn;      // nt: n-tile of 64 output channels = blocks 2 (nt & 1), +1 of 128-row tile nt >> 1
+    const int txx = pt % tiles_w, t2 = pt / tiles_w, tyy = t2 % tiles_h, n = t2 / tiles_h;
+    const int oy0 = tyy * TH, ox0 = txx * TW;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s][nb][r] = 0.f;
+    f32x4 bq[2][2][2];
+    auto load_b = [&](int slot, int s, int c16) {     // xi = 4 wave + s, 16-channel chunk c16 (global): both 32-row blocks
+      const int kcg = c16 >> 1, t8g = 2 * (c16 & 1);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const unsigned base = (unsigned)((((((nt >> 1) * 16 + 4 * wave + s) * KCT + kcg) * 4 + 2 * (nt & 1) + nb) * 4 + t8g)) * 1024u;
+#pragma unroll
+        for (int t8 = 0; t8 < 2; ++t8) bq[slot][nb][t8] = buf_load4(ur, b_lane + base + (unsigned)(t8 * 1024));
+      }
+    };
+    load_b(0, 0, 0);
+
+    for (int cg = 0; cg < wp.ncg; ++cg) {
+      if (pt != cur_pt || cg != cur_cg) {   // block-uniform.  (Every wave is past the last read of the old halo / the output rounds: barriers below.)
+        cur_pt = pt; cur_cg = cg;
+        const int org = ((n * p.H + oy0 - 1) * p.W + ox0 - 1) * p.ldx + cg * 64;
+#pragma unroll 1
+        for (int pc = wave; pc < PIECES2; pc += 4) {
+          const int P = 4 * pc + (lane >> 4), hy = P / HW, hx = P - hy * HW;
+          const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+          const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+          const int c = (lane & 15) ^ (hx & 15);
+          dma16(xr, halo + pc * 256, ok ? (unsigned)(org + (hy * p.W + hx) * p.ldx + c * 4) * 4u : kOOB);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+#pragma unroll 1
+      for (int kc = 0; kc < 4; ++kc) {
+        __syncthreads();     // the halo has landed; every wave is done reading V
+        {
+          const int cidx = kc * 4 + q;
+          f32x4 d[3][4];
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const int hy = 2 * ty + r + half, hx = 2 * tx + c;
+              d[r][c] = *reinterpret_cast<const f32x4*>(halo + (hy * HW + hx) * 64 + ((cidx ^ (hx & 15)) << 2));
+            }
+          f32x4 T[2][4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (half == 0) { T[0][c] = d[0][c] - d[2][c]; T[1][c] = d[1][c] + d[2][c]; }
+            else           { T[0][c] = d[1][c] - d[0][c]; T[1][c] = d[0][c] - d[2][c]; }
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const f32x4 v0 = T[i][0] - T[i][2], v1 = T[i][1] + T[i][2], v2 = T[i][2] - T[i][1], v3 = T[i][1] - T[i][3];
+            float* dst = V + (((2 * half + i) * 4) * 32 + t) * 16 + ((q ^ ((t >> 2) & 3)) << 2);
+            *reinterpret_cast<f32x4*>(dst) = v0;
+            *reinterpret_cast<f32x4*>(dst + 1 * 32 * 16) = v1;
+            *reinterpret_cast<f32x4*>(dst + 2 * 32 * 16) = v2;
+            *reinterpret_cast<f32x4*>(dst + 3 * 32 * 16) = v3;
+          }
+        }
+        __syncthreads();
+        const int c16 = cg * 4 + kc;
+        f32x4 aq[2][2];   // (one xi ahead, like the filter fragments: all four at once would not fit beside the accumulators)
+#pragma unroll
+        for (int t8 = 0; t8 < 2; ++t8) aq[0][t8] = *reinterpret_cast<const f32x4*>(V + (4 * wave) * 512 + afo[t8]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int cur = s & 1;
+          if (s < 3) {
+            load_b(cur ^ 1, s + 1, c16);
+#pragma unroll
+            for (int t8 = 0; t8 < 2; ++t8) aq[cur ^ 1][t8] = *reinterpret_cast<const f32x4*>(V + (4 * wave + s + 1) * 512 + afo[t8]);
+          } else {
+            load_b(cur ^ 1, 0, c16 + 1 < NC16 ? c16 + 1 : 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t8 = 0; t8 < 2; ++t8)
+#pragma unroll
+            for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+              for (int nb = 0; nb < 2; ++nb) acc[s][nb] = MFMA(aq[cur][t8][ss], bq[cur][nb][t8][ss], acc[s][nb]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    // ---- output transform A^T M A and the epilogue, 32 output channels at a time through LDS (over the halo: the next item re-deposits it)
+    cur_pt = -1;
+#pragma unroll 1
+    for (int nb = 0; nb < 2; ++nb) {
+      __syncthreads();       // the last chunk's MFMAs have read V / the previous round's image is free
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float* dst = S + (4 * wave + s) * 1024 + li;
+        const f32x16& a = nb == 0 ? acc[s][0] : acc[s][1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * h) * 32] = a[r];
+      }
+      __syncthreads();
+      {
+        const int tyo = to >> 3, txo = to & 7;
+        const int co = nt * 64 + nb * 32 + qo * 4;
+#pragma unroll 1
+        for (int r = 0; r < 2; ++r) {       // output row r of the 2 x 2: A^T = [1 1 1 0; 0 1 -1 -1] -> M rows r .. r + 2, signs + + / - -
+          const float sg = r ? -1.f : 1.f;
+          f32x4 Sr[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            f32x4 m[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) m[i] = *reinterpret_cast<const f32x4*>(S + (((i + r) * 4 + j) * 32 + to) * 32 + (qo << 2));
+            Sr[j] = (m[0] + sg * m[1]) + sg * m[2];
+          }
+          const f32x4 y0 = (Sr[0] + Sr[1]) + Sr[2], y1 = (Sr[1] - Sr[2]) - Sr[3];
+          const int py = oy0 + 2 * tyo + r, px = ox0 + 2 * txo;
+          const int mrow = (n * p.OH + py) * p.OW + px;
+          if (!SHUF) {
+#pragma unroll 1
+            for (int e = 0; e < 2; ++e) epilogue_store4(p, p.bias, e ? y1 : y0, mrow + e, co, p.OH, p.OW, 0, 0);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float bv = p.bias ? p.bias[co + e] : 0.f;
+              epilogue_store(p, y0[e], bv, mrow, co + e, p.OH, p.OW, 0, 0);
+              epilogue_store(p, y1[e], bv, mrow + 1, co + e, p.OH, p.OW, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();         // the next item's halo deposit / transforms write over S
+  }
+}
+
 // ---- filter transform U = G g G^T, [N][9][K] rows (K-contiguous) -> [n-tile of 128][16 xi][K / 32 chunks][4 blocks of 32 rows][4 t8][64 lanes] x 16 B.
 // G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1].  flip: the taps reversed (the data gradient of a stride-1 'same' convolution is the same convolution
 // with the transposed, 180-degree-rotated filter).  One thread per (row, 4 channels).
@@ -252,8 +426,8 @@ __global__ void filter_wino_batched_kernel(const clc_wino_entry* __restrict__ ta
 }  // namespace
 
 extern "C" int clc_filter_wino(const float* w, float* out, int N, int K, int flip, clc_stream_t stream) {
-  CLC_CHECK(w && out && N > 0 && N % 128 == 0 && K > 0 && K % 128 == 0 && aligned16(w) && aligned16(out),
-            "clc_filter_wino: rows and channels must be positive multiples of 128, pointers 16-B aligned (got N=%d K=%d)", N, K);
+  CLC_CHECK(w && out && N > 0 && N % 64 == 0 && K > 0 && K % 64 == 0 && aligned16(w) && aligned16(out),
+            "clc_filter_wino: rows and channels must be positive multiples of 64, pointers 16-B aligned (got N=%d K=%d)", N, K);
   const long total = (long)N * K / 4;
   hipLaunchKernelGGL(filter_wino_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, out, N, K, flip);
   CLC_LAUNCH_CHECK();
@@ -267,36 +441,52 @@ extern "C" int clc_filter_wino_batched(const clc_wino_entry* table_dev, int n_en
 }
 
 // Called by clc_conv2d (conv_igemm.hip) with the filled kernel parameters; 0 = the launch does not qualify (the caller falls through), else the variant
-// id (family 13: bit 0 shuffle, bit 1 transposed, bits 4.. input-channel groups).
+// id (family 13: bit 0 shuffle, bit 1 transposed, bits 4..11 input-channel groups, bit 12 the 64-wide kernel).
 int clc_conv_wino_launch(const void* conv_params, const float* u, hipStream_t st) {
   const ConvParams& p = *reinterpret_cast<const ConvParams*>(conv_params);
-  if (!u || p.ks != 3 || p.stride != 1 || p.pad != 1 || p.Cin % 128 || p.Cin > 1024 || p.Cout % 128 || p.H % TH || p.W % TW || p.OH != p.H || p.OW != p.W) return 0;
+  if (!u || p.ks != 3 || p.stride != 1 || p.pad != 1 || p.Cin % 64 || p.Cin > 1024 || p.Cout % 64 || p.H % TH || p.W % TW || p.OH != p.H || p.OW != p.W) return 0;
   if (p.xs || p.in_op != CLC_IN_NONE || p.group_rows || p.bf16 || p.ksplit > 1 || p.ldx % 4 || !aligned16(p.x) || !aligned16(u)) return 0;
   const bool shuf = p.shuffle != 0;
   if (!shuf && !p.vec_epi) return 0;
-  const size_t ub = (size_t)p.Cout * 16 * p.Cin * 4;
+  const size_t ub = (size_t)((p.Cout + 127) / 128 * 128) * 16 * p.Cin * 4;
   if (ub >= (1ull << 31)) return 0;
+  const int mode = clc_tuning[CLC_TUNE_WINO];
+  const bool wide = p.Cin % 128 == 0 && p.Cout % 128 == 0 && !(mode & 8);   // (bit 3: the 64-wide kernel on every layer — an experiment switch)
+  if (!wide && !(mode & 4)) return 0;                                          // bit 2: the 64-wide kernel for layers of 64 k channels
+  const int nw = wide ? 128 : 64;
   WinoParams wp;
   wp.c = p;
   wp.u = u;
-  wp.ntn = p.Cout / 128;
-  wp.ncg = p.Cin / 128;
+  wp.ntn = p.Cout / nw;
+  wp.ncg = p.Cin / nw;
   wp.items = p.N * (p.H / TH) * (p.W / TW) * wp.ntn;
   wp.u_bytes = (unsigned)ub;
-  // Whether a launch takes this kernel must not depend on the batch size: its bits differ from the direct kernels', and an image's bits must be the
-  // same in any batch (encoder and decoder of a stream may run at different batch sizes).  So the rule looks at ONE image: at least 32 items
-  // per image (128 -> 128 from 64 x 64 maps up, 128 -> 512 from 32 x 32) — a single 256 x 256 image then runs some launches on 32 workgroups.
-  if ((p.H / TH) * (p.W / TW) * wp.ntn < 32) return 0;
-  const int grid = wp.items < 256 ? wp.items : 256;
-  const int lds = (HALO_FLOATS + V_FLOATS) * 4;
-  static PerDeviceOnce once[2];
-  if (shuf) {
-    if (once[0].first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(conv_wino_kernel<true>, dim3(grid), dim3(512), lds, st, wp);
+  // A per-IMAGE rule (an image's result must not depend on the batch it is in): at least 32 items of 128 output channels per image (128 -> 128
+  // from 64 x 64 maps up, 128 -> 512 from 32 x 32), 64 items of 64 (64 -> 64 from 64 x 128 maps up).
+  if ((p.H / TH) * (p.W / TW) * wp.ntn < (wide ? 32 : 64)) return 0;
+  static PerDeviceOnce once[4];
+  const int k = (wide ? 0 : 2) + (shuf ? 1 : 0);
+  if (wide) {
+    const int grid = wp.items < 256 ? wp.items : 256;
+    const int lds = (HALO_FLOATS + V_FLOATS) * 4;
+    if (shuf) {
+      if (once[k].first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL(conv_wino_kernel<true>, dim3(grid), dim3(512), lds, st, wp);
+    } else {
+      if (once[k].first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL(conv_wino_kernel<false>, dim3(grid), dim3(512), lds, st, wp);
+    }
   } else {
-    if (once[1].first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(conv_wino_kernel<false>, dim3(grid), dim3(512), lds, st, wp);
+    const int grid = wp.items < 512 ? wp.items : 512;
+    const int lds = (HALO2_FLOATS + V2_FLOATS) * 4;
+    if (shuf) {
+      if (once[k].first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL(conv_wino64_kernel<true>, dim3(grid), dim3(256), lds, st, wp);
+    } else {
+      if (once[k].first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL(conv_wino64_kernel<false>, dim3(grid), dim3(256), lds, st, wp);
+    }
   }
   CLC_LAUNCH_CHECK();
-  return (13 << 20) | (wp.ncg << 4) | ((p.transposed ? 1 : 0) << 1) | (shuf ? 1 : 0);
+  return (13 << 20) | ((wide ? 0 : 1) << 12) | (wp.ncg << 4) | ((p.transposed ? 1 : 0) << 1) | (shuf ? 1 : 0);
 }

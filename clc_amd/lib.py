@@ -225,7 +225,7 @@ def load():
     for item in filter(None, os.environ.get("CLC_TUNING", "").split(",")):
         k, v = item.split(":")
         L.clc_set_tuning(int(k), int(v))
-    if os.environ.get("CLC_WINO"):   # Winograd F(2x2, 3x3) for the 128-channel 3x3 layers (tuning key 23): bit 0 forward, bit 1 data gradients
+    if os.environ.get("CLC_WINO"):   # Winograd F(2x2, 3x3) for the 3x3 layers of the transforms (tuning key 23): bit 0 forward, bit 1 data gradients, bit 2 the 64-wide kernel
         L.clc_set_tuning(23, int(os.environ["CLC_WINO"]))
     _lib = L
     return L

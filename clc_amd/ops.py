@@ -591,17 +591,21 @@ def halo_packed(w, transposed_image=None):
 
 
 def wino_ok(N, H, W, Cin, rows, ks, stride, transposed=False):
-    """may a [rows][3][3][Cin] filter on an N x H x W map take the Winograd kernel?  (the C side re-checks everything and falls through)"""
-    if not (_L().clc_get_tuning(23) & (2 if transposed else 1)):
+    """may a [rows][3][3][Cin] filter on an N x H x W map take the Winograd kernels?  (the C side re-checks everything and falls through)"""
+    mode = _L().clc_get_tuning(23)
+    if not (mode & (2 if transposed else 1)) or not (ks == 3 and stride == 1 and H % 8 == 0 and W % 16 == 0 and Cin <= 1024):
         return False
-    # (a per-IMAGE rule, so that an image's result does not depend on the batch it is in)
-    return (ks == 3 and stride == 1 and Cin % 128 == 0 and Cin <= 1024 and rows % 128 == 0 and H % 8 == 0 and W % 16 == 0
-            and (H // 8) * (W // 16) * (rows // 128) >= 32)
+    # (per-IMAGE rules, so that an image's result does not depend on the batch it is in)
+    if Cin % 128 == 0 and rows % 128 == 0 and not (mode & 8):
+        return (H // 8) * (W // 16) * (rows // 128) >= 32
+    # bit 2: the 64-wide kernel for layers of 64 k channels
+    return bool(mode & 4) and Cin % 64 == 0 and rows % 64 == 0 and (H // 8) * (W // 16) * (rows // 64) >= 64
 
 
 def wino_pack(wk, rows, K, flip=False):
-    """[rows][9][K] filter rows -> U = G g G^T in fragment order (clc_filter_wino; 16 / 9 of the size).  flip: taps reversed (data gradients)."""
-    out = torch.empty(rows * 16 * K, device=wk.device, dtype=torch.float32)
+    """[rows][9][K] filter rows -> U = G g G^T in fragment order (clc_filter_wino; 16 / 9 of the size, rows padded to 128).  flip: taps reversed
+    (data gradients)."""
+    out = torch.empty(-(-rows // 128) * 128 * 16 * K, device=wk.device, dtype=torch.float32)
     _lib.check(_L().clc_filter_wino(wk.data_ptr(), out.data_ptr(), int(rows), int(K), int(bool(flip)), _stream()), "clc_filter_wino")
     return out
 

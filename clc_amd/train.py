@@ -332,11 +332,11 @@ class WinoPacker:
         if not jobs:
             return
         dev = jobs[0][0].device
-        total = sum(rows * 16 * K for _, _, rows, K, _, _ in jobs)
+        total = sum(-(-rows // 128) * 128 * 16 * K for _, _, rows, K, _, _ in jobs)   # (rows padded to the kernels' 128-row filter tiles)
         self.buf = torch.empty(total, dtype=torch.float32, device=dev)
         entries, off, blocks = [], 0, 0
         for p, src, rows, K, flip, attr in jobs:
-            n = rows * 16 * K
+            n = -(-rows // 128) * 128 * 16 * K
             out = self.buf[off: off + n]
             off += n
             setattr(p, attr, out)

@@ -126,8 +126,8 @@ typedef struct {
    * height is a multiple of 8 and width of 16 run on the halo-resident kernel (csrc/conv_halo.hip) — same bits as the tiled kernels.  NULL: tiled. */
   const float* w_packed;
   /* optional: the filter's Winograd F(2x2, 3x3) transform in fragment order (clc_filter_wino; for transposed = 1: of the transposed filter, taps
-   * flipped).  With it, 3x3 / stride-1 / pad-1 layers with 128 k input and 128 k output channels on maps whose height is a multiple of 8 and
-   * width of 16 run on conv_wino_kernel (csrc/conv_wino.hip): 2.25x fewer multiplications, ANOTHER summation order than the direct kernels
+   * flipped).  With it, 3x3 / stride-1 / pad-1 layers with 64 k input and 64 k output channels on maps whose height is a multiple of 8 and
+   * width of 16 run on conv_wino_kernel / conv_wino64_kernel (csrc/conv_wino.hip): 2.25x fewer multiplications, ANOTHER summation order than the direct kernels
    * (fp32 error of a few ulp of the operands; measured 4..9e-7 of the largest output against fp64, the direct kernels 1.3e-6).  Takes precedence
    * over w_packed.  For TRAINING launches (forward of a recorded pass, data gradients): a launch whose result feeds the entropy coder or a parity
    * measurement leaves it NULL (direct kernels) — the codec's kernel_config tag does not cover this kernel. */
@@ -142,7 +142,7 @@ int clc_filter_pack_halo(const float* w, float* out, int N, int K, clc_stream_t 
  * 16-B elements) over the preceding entries, total_blocks = the grand total */
 typedef struct { const float* w; float* out; int N, K, block_begin; } clc_halo_pack_entry;
 int clc_filter_pack_halo_batched(const clc_halo_pack_entry* table_dev, int n_entries, int total_blocks, clc_stream_t stream);
-/* [N][3][3][K] filter rows (N, K multiples of 128) -> `out` (16 / 9 of the floats): U = G g G^T per (row, channel) in the fragment order
+/* [N][3][3][K] filter rows (N, K multiples of 64) -> `out` (ceil(N / 128) * 128 * 16 * K floats): U = G g G^T per (row, channel) in the fragment order
  * clc_conv_desc.w_wino expects; flip = 1 reverses the taps (data gradients: pass the transposed filter).  The batched form: device table,
  * block_begin = running sum of ceil(N * K / 4 / 256). */
 int clc_filter_wino(const float* w, float* out, int N, int K, int flip, clc_stream_t stream);

@@ -166,13 +166,15 @@ def test_conv_fwd_bwd(dev, case, act):
 
 
 @pytest.mark.parametrize("case", [(8, 64, 16, 16, 64, 3), (8, 128, 16, 16, 64, 1), (2, 448, 16, 16, 224, 3), (2, 64, 64, 64, 128, 3), (4, 64, 32, 32, 64, 1)])
-def test_conv_paired_filters(dev, case):
+def test_conv_paired_filters(dev, case, request):
     """w2/bias2: the second half of the batch on a second filter set in the same launch == two separate launches, bit
     for bit (forward, data gradient, both filter gradients), for both kernel families."""
     from clc_amd import ops
 
     N, Cin, H, W, Cout, ks = case
     h = N // 2
+    # (the paired launch has no Winograd form: compare with separate launches on the same, direct kernels — key 23 off for this test)
+    request.addfinalizer(lambda old=ops._L().clc_set_tuning(23, 0): ops._L().clc_set_tuning(23, old))
     x = _rand((N, Cin, H, W), 1)
     w1, w2 = _rand((Cout, Cin, ks, ks), 2, 0.05), _rand((Cout, Cin, ks, ks), 3, 0.05)
     b1, b2 = _rand((Cout,), 4, 0.1), _rand((Cout,), 5, 0.1)
@@ -775,8 +777,9 @@ def test_activation_gate_in_consumer_dgrad(dev, kind):
     ba = _rand((Ca,), 3, 0.1)
     wb = _rand((96, C, 3, 3), 4, (1.0 / (C * 9)) ** 0.5)
     bb = _rand((96,), 5, 0.1)
-    with torch.no_grad():   # the kernel's own activated output decides which side of 0 a pre-activation of ~1e-8 falls on (see test_conv_fwd_bwd)
-        ya_gpu = ops.conv2d(_dev(x, dev), _dev(wa, dev), _dev(ba, dev), act=act, shuffle=shuffle).cpu()
+    # the kernel's own activated output decides which side of 0 a pre-activation of ~1e-8 falls on (see test_conv_fwd_bwd) — of a RECORDED
+    # forward like the ones below (a no_grad forward may run another kernel: the Winograd forms serve recorded passes only)
+    ya_gpu = ops.conv2d(_dev(x, dev, grad=True), _dev(wa, dev, grad=True), _dev(ba, dev, grad=True), act=act, shuffle=shuffle).detach().cpu()
     ref_in = [t.clone().requires_grad_() for t in (x, wa, ba, wb, bb)]
     t = F.conv2d(ref_in[0], ref_in[1], ref_in[2], padding=ks // 2)
     if shuffle:
@@ -1340,7 +1343,9 @@ def test_halo_filter_pack_is_the_documented_fragment_order(dev, rows, K):
 @pytest.mark.parametrize("N,H,W,Cin,Cout,mode", [
     (8, 64, 64, 128, 128, "plain"), (2, 128, 128, 128, 128, "lrelu_res"), (8, 32, 32, 128, 512, "shuffle_lrelu"), (2, 64, 64, 128, 512, "shuffle"),
     (8, 64, 64, 128, 128, "dgrad_gate"), (3, 48, 96, 128, 128, "plain"), (1, 256, 256, 128, 128, "pre"), (2, 64, 64, 256, 128, "plain"),
-    (2, 64, 64, 128, 512, "dgrad_gate"), (3, 72, 80, 128, 128, "strided"), (1, 64, 128, 128, 128, "plain")])
+    (2, 64, 64, 128, 512, "dgrad_gate"), (3, 72, 80, 128, 128, "strided"), (1, 64, 128, 128, 128, "plain"),
+    (8, 128, 128, 64, 64, "plain"), (2, 128, 128, 64, 64, "lrelu_res"), (2, 128, 128, 64, 64, "dgrad_gate"), (2, 64, 64, 64, 256, "shuffle_lrelu"),
+    (1, 128, 128, 64, 64, "pre"), (3, 72, 80, 64, 128, "strided"), (2, 64, 128, 192, 64, "plain"), (2, 64, 128, 64, 192, "dgrad_gate")])
 def test_wino_conv_vs_direct_and_fp64(dev, N, H, W, Cin, Cout, mode):
     """conv_wino_kernel (csrc/conv_wino.hip: Winograd F(2x2, 3x3) for 3x3 / stride-1 layers with 128 k channels; input transform B^T d B from an
     LDS-resident halo, 16 batched MFMA GEMMs against the pre-transformed filter U = G g G^T, output transform A^T M A through LDS into the
@@ -1353,7 +1358,7 @@ def test_wino_conv_vs_direct_and_fp64(dev, N, H, W, Cin, Cout, mode):
     from clc_amd.ops import ACT_LRELU
 
     L = lib.load()
-    restore = L.clc_set_tuning(23, 3)
+    restore = L.clc_set_tuning(23, 7)     # (bit 2: the 64-wide instantiation for layers of 64 k channels)
     try:
         g = torch.Generator().manual_seed(N * 1000 + H + Cout)
         w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).to(dev).contiguous(memory_format=CL)
@@ -1403,10 +1408,12 @@ def test_wino_conv_vs_direct_and_fp64(dev, N, H, W, Cin, Cout, mode):
             pre_w = kw["y_pre"].clone() if "y_pre" in kw else None
             y_d = run(None).clone()
             torch.cuda.synchronize()
-            variants = [r.variant >> 20 for r in ops.PROFILE if r.fam == "conv_igemm"]
+            full = [r.variant for r in ops.PROFILE if r.fam == "conv_igemm"]
+            variants = [v >> 20 for v in full]
         finally:
             ops.PROFILE = None
         assert variants[0] == 13 and variants[1] != 13, variants          # the Winograd kernel ran, then a direct one
+        assert ((full[0] >> 12) & 1) == (0 if (Cin % 128 == 0 and Cout % 128 == 0) else 1), hex(full[0])   # which instantiation
         scale = ref.abs().max().item()
         e_w = (y_w.double().cpu() - ref).abs().max().item() / scale
         e_d = (y_d.double().cpu() - ref).abs().max().item() / scale

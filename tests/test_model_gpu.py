@@ -254,10 +254,15 @@ def test_wire_clm_forward_backward_vs_oracle(dev, R):
     assert rec["x_hat"].shape == (1, 3, 512, 512) and torch.isfinite(rec["x_hat"]).all()
 
 
-def test_config1_bs8_train_mode_step_vs_oracle(dev):
+@pytest.mark.parametrize("fwd", ["direct", "default"])
+def test_config1_bs8_train_mode_step_vs_oracle(dev, fwd):
     """BASELINE configs[1] at its quoted size (CLC lambda 0.0067 MSE, 256x256, batch 8, 1 reference), TRAIN mode: the additive-noise
     proxy is injected identically on both sides (one U(-1/2,1/2) tensor for y, one for z), so the loss terms (<= 2e-4) and the
-    gradients are comparable element for element (train mode consumes RNG)."""
+    gradients are comparable element for element (train mode consumes RNG).
+    fwd = "direct": the recorded forward pinned to the direct kernels (_direct_forward) — at most 8 of the 655 360 STE-rounded symbols may
+    differ from the oracle's.  fwd = "default": the step as the engine runs it, Winograd forward included — its other summation order moves
+    more knife-edge symbols (each flip cascades through the autoregressive slices; measured 39): at most 1e-4 of the elements, gradients
+    held flip-aware like the first case."""
     from clc_amd.train import RateDistortionLoss as PRD
     from oracle.loss import RateDistortionLoss as ORD
 
@@ -273,13 +278,14 @@ def test_config1_bs8_train_mode_step_vs_oracle(dev):
         lo = ORD(0.0067)(oo, x)
         lo["loss"].backward()
         xd, rd = x.to(dev), [r.to(dev) for r in refs]
-        po = p(xd, rd)
+        with (_direct_forward() if fwd == "direct" else contextlib.nullcontext()):
+            po = p(xd, rd)
         lp = PRD(0.0067)(po, xd)
         lp["loss"].backward()
     flips = _symbol_flips(oo, po)
     for k in ("loss", "bpp_loss", "mse_loss"):
         assert abs(lo[k].item() - lp[k].item()) <= 2e-4 * max(1.0, abs(lo[k].item())), (k, lo[k].item(), lp[k].item())
-    assert flips <= 8, flips   # of 655 360 latent elements
+    assert flips <= (8 if fwd == "direct" else 65), flips   # of 655 360 latent elements
     checked, worst = _grad_parity(o, p, tol=4e-3, flips=flips)   # (8-image / 512x512 / N=128 reductions: measured worst 1.1e-3 .. 3.2e-3 of a tensor's largest element, fp32 summation order)
     print("bs8 train-mode: checked", checked, "worst rel err", worst, "symbol flips", flips)
 
@@ -460,7 +466,8 @@ def test_train_engine_steps(dev):
     assert min(losses[False][3:]) < losses[False][0], losses[False]
 
 
-def test_config2_bs8_r3_train_mode_step_vs_oracle(dev):
+@pytest.mark.parametrize("fwd", ["direct", "default"])
+def test_config2_bs8_r3_train_mode_step_vs_oracle(dev, fwd):
     """BASELINE configs[2] at its quoted size (CLC lambda 0.025 MSE, 256x256, batch 8, 3 references), TRAIN mode with the noise
     injected identically on both sides: loss terms and every gradient vs the oracle (VERDICT r2 weak #4: bs2 only before)."""
     from clc_amd.train import RateDistortionLoss as PRD
@@ -478,13 +485,14 @@ def test_config2_bs8_r3_train_mode_step_vs_oracle(dev):
         lo = ORD(0.025)(oo, x)
         lo["loss"].backward()
         xd, rd = x.to(dev), [r.to(dev) for r in refs]
-        po = p(xd, rd)
+        with (_direct_forward() if fwd == "direct" else contextlib.nullcontext()):
+            po = p(xd, rd)
         lp = PRD(0.025)(po, xd)
         lp["loss"].backward()
     flips = _symbol_flips(oo, po)
     for k in ("loss", "bpp_loss", "mse_loss"):
         assert abs(lo[k].item() - lp[k].item()) <= 2e-4 * max(1.0, abs(lo[k].item())), (k, lo[k].item(), lp[k].item())
-    assert flips <= 8, flips   # of 655 360 latent elements
+    assert flips <= (8 if fwd == "direct" else 65), flips   # of 655 360 latent elements (see test_config1_bs8_train_mode_step_vs_oracle)
     checked, worst = _grad_parity(o, p, tol=4e-3, flips=flips)   # (8-image / 512x512 / N=128 reductions: measured worst 1.1e-3 .. 3.2e-3 of a tensor's largest element, fp32 summation order)
     print("configs[2] bs8 R=3 train-mode: checked", checked, "worst rel err", worst, "symbol flips", flips)
 

@@ -10,7 +10,8 @@ CL = torch.channels_last
 dev = torch.device("cuda:0")
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 15
 L = ops._L()
-L.clc_set_tuning(23, 3)
+MODE = int(os.environ.get("WINO_MODE", "7"))
+L.clc_set_tuning(23, MODE)
 SHAPES = [  # name, N, H, W, Cin, Cout, shuffle, transposed
     ("128->128 @8x128^2 fwd", 8, 128, 128, 128, 128, False, False),
     ("128->128 @8x128^2 dgrad", 8, 128, 128, 128, 128, False, True),
@@ -18,6 +19,10 @@ SHAPES = [  # name, N, H, W, Cin, Cout, shuffle, transposed
     ("128->512 @8x64^2 fwd+shuffle", 8, 64, 64, 128, 512, True, False),
     ("128->512 @8x32^2 fwd+shuffle", 8, 32, 32, 128, 512, True, False),
     ("128->512 @8x64^2 dgrad (512 ch in)", 8, 64, 64, 128, 512, False, True),
+    ("64->64 @8x128^2 fwd", 8, 128, 128, 64, 64, False, False),
+    ("64->64 @8x128^2 dgrad", 8, 128, 128, 64, 64, False, True),
+    ("64->64 @8x64^2 fwd", 8, 64, 64, 64, 64, False, False),
+    ("64->256 @8x64^2 fwd+shuffle", 8, 64, 64, 64, 256, True, False),
 ]
 g = torch.Generator().manual_seed(0)
 NB = 4
@@ -29,14 +34,14 @@ for name, N, H, W, Cin, Cout, shuf, tr in SHAPES:
         outs = [ops.new_act(N, Cin, H, W, xs[0]) for _ in range(NB)]
         wt = ops.filter_transpose(w, Cout, 9, Cin).view(Cin, -1)
         u = ops.wino_pack(wt, Cin, Cout, flip=True)
-        pk = ops.halo_pack(wt, Cin, Cout) if Cout in (64, 128) else None
+        pk = ops.halo_pack(wt, Cin, Cout) if Cout == 128 else None
         call = lambda i, **k: ops.conv_raw(xs[i % NB], wt, None, ks=3, stride=1, pad=1, transposed=True, out_hw=(H, W), out=outs[i % NB], **k)
         ref = F.conv_transpose2d(xs[0].double().cpu(), w.double().cpu(), padding=1)
     else:
         xs = [torch.randn(N, Cin, H, W, generator=g).to(dev).contiguous(memory_format=CL) for _ in range(NB)]
         outs = [ops.new_act(N, Cout // 4, 2 * H, 2 * W, xs[0]) if shuf else ops.new_act(N, Cout, H, W, xs[0]) for _ in range(NB)]
         u = ops.wino_pack(w, Cout, Cin)
-        pk = ops.halo_pack(w, Cout, Cin)
+        pk = ops.halo_pack(w, Cout, Cin) if Cin == 128 else None
         call = lambda i, **k: ops.conv_raw(xs[i % NB], w, b, ks=3, stride=1, act=0, shuffle=shuf, out=outs[i % NB], **k)
         ref = F.conv2d(xs[0].double().cpu(), w.double().cpu(), b.double().cpu(), padding=1)
         if shuf:
