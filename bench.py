@@ -344,7 +344,7 @@ def _kernel_name(L, r):
         return (f"conv_igemm_dma2_kernel<{bm}, {bn}, {(variant >> 16) & 15}, {(variant >> 12) & 15}, {tr}, {1 if f == 5 else 3}, "
                 f"{(variant >> 24) & 3}, {'true' if (variant >> 26) & 1 else 'false'}>")   # (..., OP: 1 = squared operand (GDN's norm convolution), BF: bf16 MFMA)
     if f == 13:       # Winograd F(2x2, 3x3) kernel (csrc/conv_wino.hip): <SHUF>
-        return f"conv_wino_kernel<{'true' if variant & 1 else 'false'}>"
+        return f"conv_wino{'64' if (variant >> 12) & 1 else ''}_kernel<{'true' if variant & 1 else 'false'}>"   # (bit 12: the 64-wide instantiation)
     if f == 12:       # halo-resident 3x3 kernel (csrc/conv_halo.hip): <CI, TR, SHUF>
         return f"conv_halo3x3_kernel<{64 * ((variant >> 4) & 15)}, {'true' if (variant >> 1) & 1 else 'false'}, {'true' if variant & 1 else 'false'}>"
     if f == 11:       # the wave-private persistent kernel of the 128 -> 128 / 64 -> 64 1x1 layers on large maps (csrc/fused_mlp.hip)

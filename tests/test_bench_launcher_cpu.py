@@ -75,6 +75,7 @@ def test_recorded_launches_map_to_the_profilers_kernel_names():
     rec = lambda variant, label="fwd 128->128": types.SimpleNamespace(fam="conv_igemm", variant=variant, label=label)
     assert bench._kernel_name(L, rec((13 << 20) | (1 << 4) | 1)) == "conv_wino_kernel<true>"
     assert bench._kernel_name(L, rec((13 << 20) | (4 << 4) | 2, "dgrad 512->128")) == "conv_wino_kernel<false>"
+    assert bench._kernel_name(L, rec((13 << 20) | (1 << 12) | (1 << 4) | 2, "dgrad 64->64")) == "conv_wino64_kernel<false>"
     assert bench._kernel_name(L, rec((12 << 20) | (2 << 4) | 2, "dgrad 128->128")) == "conv_halo3x3_kernel<128, true, false>"
     assert bench._kernel_name(L, rec((12 << 20) | (1 << 4) | 1)) == "conv_halo3x3_kernel<64, false, true>"
     for fam in (1, 2, 3, 4, 5, 8, 10, 11, 12, 13):

@@ -12,7 +12,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 15
 L = ops._L()
 MODE = int(os.environ.get("WINO_MODE", "7"))
 L.clc_set_tuning(23, MODE)
-SHAPES = [  # name, N, H, W, Cin, Cout, shuffle, transposed
+SHAPES_ALL = [  # name, N, H, W, Cin, Cout, shuffle, transposed
     ("128->128 @8x128^2 fwd", 8, 128, 128, 128, 128, False, False),
     ("128->128 @8x128^2 dgrad", 8, 128, 128, 128, 128, False, True),
     ("128->128 @8x64^2 fwd", 8, 64, 64, 128, 128, False, False),
@@ -24,6 +24,7 @@ SHAPES = [  # name, N, H, W, Cin, Cout, shuffle, transposed
     ("64->64 @8x64^2 fwd", 8, 64, 64, 64, 64, False, False),
     ("64->256 @8x64^2 fwd+shuffle", 8, 64, 64, 64, 256, True, False),
 ]
+SHAPES = SHAPES_ALL[:int(os.environ.get('WINO_SHAPES', len(SHAPES_ALL)))]
 g = torch.Generator().manual_seed(0)
 NB = 4
 for name, N, H, W, Cin, Cout, shuf, tr in SHAPES:
@@ -72,3 +73,20 @@ for name, N, H, W, Cin, Cout, shuf, tr in SHAPES:
         res[label + "_err"] = ((o - ref).abs().max() / ref.abs().max()).item()
     print(f"{name:36s} direct {res['direct'] * 1e3:7.1f} us {flops / res['direct'] / 1e9:6.1f} TF (err {res['direct_err']:.1e}) | wino {res['wino'] * 1e3:7.1f} us "
           f"{flops / res['wino'] / 1e9:6.1f} TF-equivalent (err {res['wino_err']:.1e}) | x{res['direct'] / res['wino']:.3f}", flush=True)
+
+if hasattr(L, "clc_wino_debug") or os.environ.get("CLC_LIB_PATH"):   # a -DWINO_AB=32 build: phase time stamps of one item of the LAST wide launch
+    import ctypes
+    try:
+        fn = L.clc_wino_debug
+        buf = (ctypes.c_ulonglong * 32)()
+        torch.cuda.synchronize()
+        fn(buf)
+        t = list(buf)
+        names = {0: "item start", 1: "halo landed + barrier", 2: "first transform", 11: "after last chunk", 12: "DMA wait", 13: "round 0 barrier", 14: "round 0 staged",
+                 15: "round 0 stored", 16: "round 1 barrier", 17: "round 1 staged", 18: "round 1 stored"}
+        for k in range(1, 19):
+            print(f"  stamp {k:2d} {names.get(k, 'chunk %d barrier' % (k - 3)):24s} +{t[k] - t[k - 1]:7d} ticks  (total {t[k] - t[0]})")
+        if t[19] and t[20]:
+            print(f"  round 0: staged -> y in registers {t[19] - t[14]} ticks, -> first pixel pair stored {t[20] - t[19]}, -> second {t[15] - t[20]}")
+    except AttributeError:
+        pass
