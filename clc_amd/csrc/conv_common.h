@@ -123,6 +123,62 @@ __device__ __forceinline__ unsigned a_offset(const ConvParams& p, const RowState
   return ok ? off : kOOB;
 }
 
+// The LEAN form of the same epilogue for the launches the Winograd kernels take most: bias, LeakyReLU / ReLU / none, a residual (before or after the
+// activation), the saved pre-activation, the consumer-side LeakyReLU / ReLU gate — no GDN, no gated residual, no stored derivative.  Same operations
+// in the same order on the same values as epilogue_math4 (same bits); the activation is two selects instead of a switch over every activation the
+// ABI knows, which in the general form costs ~1.3 k cycles per pixel PAIR once several pixels per thread are unrolled behind each other.
+__device__ __forceinline__ bool epilogue_is_lean(const ConvParams& p) {
+  return p.norm == CLC_NORM_NONE && !p.res_gate && !p.pre_deriv && (p.act == CLC_ACT_NONE || p.act == CLC_ACT_LRELU || p.act == CLC_ACT_RELU) &&
+         (!p.out_gate || p.og_act == CLC_ACT_LRELU || p.og_act == CLC_ACT_RELU);
+}
+__device__ __forceinline__ float lean_act(float v, int act) {
+  return act == CLC_ACT_NONE ? v : (v > 0.f ? v : (act == CLC_ACT_LRELU ? 0.01f * v : 0.f));
+}
+struct Lean4In { f32x4 rr, og; };
+__device__ __forceinline__ Lean4In lean_load4(const ConvParams& p, size_t pix, int co) {
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  Lean4In in;
+  in.rr = p.res ? *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + co) : z;
+  in.og = p.out_gate ? *reinterpret_cast<const f32x4*>(p.out_gate + pix * p.ldog + co) : z;
+  return in;
+}
+__device__ __forceinline__ void lean_finish4(const ConvParams& p, f32x4 bv, f32x4 acc, const Lean4In& in, size_t pix, int co) {
+  f32x4 v = acc;
+  v[0] += bv[0]; v[1] += bv[1]; v[2] += bv[2]; v[3] += bv[3];
+  f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+  if (p.res) {
+    rv = p.res_scale * in.rr;
+    if (p.res_first) v = v + rv;
+  }
+  if (p.y_pre) *reinterpret_cast<f32x4*>(p.y_pre + pix * p.ldp + co) = v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = lean_act(v[q], p.act);
+  if (p.res && !p.res_first) v = v + rv;
+  if (p.out_gate) {
+    const float gs = p.og_act == CLC_ACT_LRELU ? 0.01f : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = v[q] * (in.og[q] > 0.f ? 1.f : gs);
+  }
+  *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + co) = v;
+}
+// ... and its PixelShuffle(2) form: channels co .. co + 3 of pixel (oy, ox) are the 2 x 2 sub-pixels of output channel co / 4
+__device__ __forceinline__ void lean_store_shuffle4(const ConvParams& p, f32x4 bv, f32x4 acc, int n, int oy, int ox, int co) {
+  const int ch = co >> 2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const size_t pix = (size_t)(n * 2 * p.OH + 2 * oy + (e >> 1)) * (2 * p.OW) + 2 * ox + (e & 1);
+    float v = acc[e] + bv[e];
+    float rterm = 0.f;
+    if (p.res) rterm = p.res_scale * p.res[pix * p.ldr + ch];
+    if (p.res && p.res_first) v += rterm;
+    if (p.y_pre) p.y_pre[pix * p.ldp + ch] = v;
+    v = lean_act(v, p.act);
+    if (p.res && !p.res_first) v += rterm;
+    if (p.out_gate) v *= (p.out_gate[pix * p.ldog + ch] > 0.f ? 1.f : (p.og_act == CLC_ACT_LRELU ? 0.01f : 0.f));
+    p.y[pix * p.ldy + ch] = v;
+  }
+}
+
 // Shared epilogue for one accumulator element.
 __device__ __forceinline__ void epilogue_store(const ConvParams& p, float acc, float bv, int m, int co, int DH, int DW, int ph, int pw) {
   size_t pix; int ch = co;
@@ -140,6 +196,16 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, float acc, f
   }
   float v = acc + bv;
   float rterm = 0.f;
+  if (epilogue_is_lean(p)) {   // (same operations, two selects instead of the activation switches: see epilogue_is_lean)
+    if (p.res) rterm = p.res_scale * p.res[pix * p.ldr + ch];
+    if (p.res && p.res_first) v += rterm;
+    if (p.y_pre) p.y_pre[pix * p.ldp + ch] = v;
+    v = lean_act(v, p.act);
+    if (p.res && !p.res_first) v += rterm;
+    if (p.out_gate) v *= (p.out_gate[pix * p.ldog + ch] > 0.f ? 1.f : (p.og_act == CLC_ACT_LRELU ? 0.01f : 0.f));
+    p.y[pix * p.ldy + ch] = v;
+    return;
+  }
   if (p.res) {
     rterm = p.res_scale * p.res[pix * p.ldr + ch];
     if (p.res_gate) rterm *= act_deriv(p.res_gate[pix * p.ldg + ch], p.rg_act, p.rg_pre);
@@ -215,64 +281,13 @@ __device__ __forceinline__ void epilogue_finish4(const ConvParams& p, f32x4 bv, 
 __device__ __forceinline__ void epilogue_store4(const ConvParams& p, const float* bias, f32x4 acc, int m, int co, int DH, int DW, int ph, int pw) {
   const size_t pix = epilogue_pixel(p, m, DH, DW, ph, pw);
   const f32x4 bv = epilogue_bias4(bias, co);
+  if (epilogue_is_lean(p)) {
+    const Lean4In in = lean_load4(p, pix, co);
+    lean_finish4(p, bv, acc, in, pix, co);
+    return;
+  }
   const Epi4In in = epilogue_load4(p, pix, co);
   epilogue_finish4(p, bv, acc, in, pix, co);
-}
-
-// The LEAN form of the same epilogue for the launches the Winograd kernels take most: bias, LeakyReLU / ReLU / none, a residual (before or after the
-// activation), the saved pre-activation, the consumer-side LeakyReLU / ReLU gate — no GDN, no gated residual, no stored derivative.  Same operations
-// in the same order on the same values as epilogue_math4 (same bits); the activation is two selects instead of a switch over every activation the
-// ABI knows, which in the general form costs ~1.3 k cycles per pixel PAIR once several pixels per thread are unrolled behind each other.
-__device__ __forceinline__ bool epilogue_is_lean(const ConvParams& p) {
-  return p.norm == CLC_NORM_NONE && !p.res_gate && !p.pre_deriv && (p.act == CLC_ACT_NONE || p.act == CLC_ACT_LRELU || p.act == CLC_ACT_RELU) &&
-         (!p.out_gate || p.og_act == CLC_ACT_LRELU || p.og_act == CLC_ACT_RELU);
-}
-__device__ __forceinline__ float lean_act(float v, int act) {
-  return act == CLC_ACT_NONE ? v : (v > 0.f ? v : (act == CLC_ACT_LRELU ? 0.01f * v : 0.f));
-}
-struct Lean4In { f32x4 rr, og; };
-__device__ __forceinline__ Lean4In lean_load4(const ConvParams& p, size_t pix, int co) {
-  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  Lean4In in;
-  in.rr = p.res ? *reinterpret_cast<const f32x4*>(p.res + pix * p.ldr + co) : z;
-  in.og = p.out_gate ? *reinterpret_cast<const f32x4*>(p.out_gate + pix * p.ldog + co) : z;
-  return in;
-}
-__device__ __forceinline__ void lean_finish4(const ConvParams& p, f32x4 bv, f32x4 acc, const Lean4In& in, size_t pix, int co) {
-  f32x4 v = acc;
-  v[0] += bv[0]; v[1] += bv[1]; v[2] += bv[2]; v[3] += bv[3];
-  f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-  if (p.res) {
-    rv = p.res_scale * in.rr;
-    if (p.res_first) v = v + rv;
-  }
-  if (p.y_pre) *reinterpret_cast<f32x4*>(p.y_pre + pix * p.ldp + co) = v;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) v[q] = lean_act(v[q], p.act);
-  if (p.res && !p.res_first) v = v + rv;
-  if (p.out_gate) {
-    const float gs = p.og_act == CLC_ACT_LRELU ? 0.01f : 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = v[q] * (in.og[q] > 0.f ? 1.f : gs);
-  }
-  *reinterpret_cast<f32x4*>(p.y + pix * p.ldy + co) = v;
-}
-// ... and its PixelShuffle(2) form: channels co .. co + 3 of pixel (oy, ox) are the 2 x 2 sub-pixels of output channel co / 4
-__device__ __forceinline__ void lean_store_shuffle4(const ConvParams& p, f32x4 bv, f32x4 acc, int n, int oy, int ox, int co) {
-  const int ch = co >> 2;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const size_t pix = (size_t)(n * 2 * p.OH + 2 * oy + (e >> 1)) * (2 * p.OW) + 2 * ox + (e & 1);
-    float v = acc[e] + bv[e];
-    float rterm = 0.f;
-    if (p.res) rterm = p.res_scale * p.res[pix * p.ldr + ch];
-    if (p.res && p.res_first) v += rterm;
-    if (p.y_pre) p.y_pre[pix * p.ldp + ch] = v;
-    v = lean_act(v, p.act);
-    if (p.res && !p.res_first) v += rterm;
-    if (p.out_gate) v *= (p.out_gate[pix * p.ldog + ch] > 0.f ? 1.f : (p.og_act == CLC_ACT_LRELU ? 0.01f : 0.f));
-    p.y[pix * p.ldy + ch] = v;
-  }
 }
 
 // Per-WAVE epilogue of one 32 x 32 accumulator block straight from the registers: lane (col = lane & 31, h = lane >> 5) holds rows

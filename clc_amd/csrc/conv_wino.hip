@@ -585,19 +585,21 @@ int clc_conv_wino_launch(const void* conv_params, const float* u, hipStream_t st
   const size_t ub = (size_t)((p.Cout + 127) / 128 * 128) * 16 * p.Cin * 4;
   if (ub >= (1ull << 31)) return 0;
   const int mode = clc_tuning[CLC_TUNE_WINO];
-  const bool wide = p.Cin % 128 == 0 && p.Cout % 128 == 0 && !(mode & 8);   // (bit 3: the 64-wide kernel on every layer — an experiment switch)
-  if (!wide && !(mode & 4)) return 0;                                          // bit 2: the 64-wide kernel for layers of 64 k channels
+  // Which instantiation: the 128-wide kernel (one workgroup per CU) where the launch has >= 192 of its items; else the 64-wide one (two per CU, half
+  // the output channels per item -> twice the items) where the channels are multiples of 64 and that makes >= 128 items.  (The rule may look at the
+  // batch: these kernels serve training launches only — an image's bits in a recorded pass need not be the bits of another batch.)
+  const int ptiles = p.N * (p.H / TH) * (p.W / TW);
+  const bool can128 = p.Cin % 128 == 0 && p.Cout % 128 == 0 && !(mode & 8);   // (bit 3: the 64-wide kernel on every layer — an experiment switch)
+  const bool wide = can128 && ptiles * (p.Cout / 128) >= 192;
+  if (!wide && (!(mode & 4) || ptiles * (p.Cout / 64) < 128)) return 0;        // bit 2: the 64-wide kernel
   const int nw = wide ? 128 : 64;
   WinoParams wp;
   wp.c = p;
   wp.u = u;
   wp.ntn = p.Cout / nw;
   wp.ncg = p.Cin / nw;
-  wp.items = p.N * (p.H / TH) * (p.W / TW) * wp.ntn;
+  wp.items = ptiles * wp.ntn;
   wp.u_bytes = (unsigned)ub;
-  // A per-IMAGE rule (an image's result must not depend on the batch it is in): at least 32 items of 128 output channels per image (128 -> 128
-  // from 64 x 64 maps up, 128 -> 512 from 32 x 32), 64 items of 64 (64 -> 64 from 64 x 128 maps up).
-  if ((p.H / TH) * (p.W / TW) * wp.ntn < (wide ? 32 : 64)) return 0;
   static PerDeviceOnce once[2];
   const int k = shuf ? 1 : 0;
   if (wide) {

@@ -595,11 +595,11 @@ def wino_ok(N, H, W, Cin, rows, ks, stride, transposed=False):
     mode = _L().clc_get_tuning(23)
     if not (mode & (2 if transposed else 1)) or not (ks == 3 and stride == 1 and H % 8 == 0 and W % 16 == 0 and Cin <= 1024):
         return False
-    # (per-IMAGE rules, so that an image's result does not depend on the batch it is in)
-    if Cin % 128 == 0 and rows % 128 == 0 and not (mode & 8):
-        return (H // 8) * (W // 16) * (rows // 128) >= 32
-    # bit 2: the 64-wide kernel for layers of 64 k channels
-    return bool(mode & 4) and Cin % 64 == 0 and rows % 64 == 0 and (H // 8) * (W // 16) * (rows // 64) >= 64
+    # the C side's rule (clc_conv_wino_launch): the 128-wide kernel from 192 items up, else the 64-wide one (bit 2) from 128 items up
+    ptiles = N * (H // 8) * (W // 16)
+    if Cin % 128 == 0 and rows % 128 == 0 and not (mode & 8) and ptiles * (rows // 128) >= 192:
+        return True
+    return bool(mode & 4) and Cin % 64 == 0 and rows % 64 == 0 and ptiles * (rows // 64) >= 128
 
 
 def wino_pack(wk, rows, K, flip=False):

@@ -1345,7 +1345,8 @@ def test_halo_filter_pack_is_the_documented_fragment_order(dev, rows, K):
     (8, 64, 64, 128, 128, "dgrad_gate"), (3, 48, 96, 128, 128, "plain"), (1, 256, 256, 128, 128, "pre"), (2, 64, 64, 256, 128, "plain"),
     (2, 64, 64, 128, 512, "dgrad_gate"), (3, 72, 80, 128, 128, "strided"), (1, 64, 128, 128, 128, "plain"),
     (8, 128, 128, 64, 64, "plain"), (2, 128, 128, 64, 64, "lrelu_res"), (2, 128, 128, 64, 64, "dgrad_gate"), (2, 64, 64, 64, 256, "shuffle_lrelu"),
-    (1, 128, 128, 64, 64, "pre"), (3, 72, 80, 64, 128, "strided"), (2, 64, 128, 192, 64, "plain"), (2, 64, 128, 64, 192, "dgrad_gate")])
+    (1, 128, 128, 64, 64, "pre"), (3, 72, 80, 64, 128, "strided"), (2, 64, 128, 192, 64, "plain"), (2, 64, 128, 64, 192, "dgrad_gate"),
+    (8, 32, 32, 320, 320, "plain"), (8, 32, 32, 320, 320, "dgrad_gate"), (8, 64, 64, 64, 64, "lrelu_res")])
 def test_wino_conv_vs_direct_and_fp64(dev, N, H, W, Cin, Cout, mode):
     """conv_wino_kernel (csrc/conv_wino.hip: Winograd F(2x2, 3x3) for 3x3 / stride-1 layers with 128 k channels; input transform B^T d B from an
     LDS-resident halo, 16 batched MFMA GEMMs against the pre-transformed filter U = G g G^T, output transform A^T M A through LDS into the
@@ -1413,7 +1414,9 @@ def test_wino_conv_vs_direct_and_fp64(dev, N, H, W, Cin, Cout, mode):
         finally:
             ops.PROFILE = None
         assert variants[0] == 13 and variants[1] != 13, variants          # the Winograd kernel ran, then a direct one
-        assert ((full[0] >> 12) & 1) == (0 if (Cin % 128 == 0 and Cout % 128 == 0) else 1), hex(full[0])   # which instantiation
+        rows_out = Cin if tr else Cout          # the launch's output channels
+        wide = Cin % 128 == 0 and Cout % 128 == 0 and N * (H // 8) * (W // 16) * (rows_out // 128) >= 192
+        assert ((full[0] >> 12) & 1) == (0 if wide else 1), hex(full[0])   # which instantiation: 128-wide from 192 items up, else the 64-wide one
         scale = ref.abs().max().item()
         e_w = (y_w.double().cpu() - ref).abs().max().item() / scale
         e_d = (y_d.double().cpu() - ref).abs().max().item() / scale
@@ -1422,10 +1425,8 @@ def test_wino_conv_vs_direct_and_fp64(dev, N, H, W, Cin, Cout, mode):
         assert (y_w - y_d).abs().max().item() / scale < 4e-6
         if pre_w is not None:
             assert (pre_w.double().cpu() - pre_ref).abs().max().item() / pre_ref.abs().max().item() < 3e-6
-        # an image's result does not depend on the batch it is in (per-image eligibility, per-item arithmetic)
-        if not tr and mode == "plain" and N > 1:
-            one = ops.conv_raw(x[:1].contiguous(memory_format=CL), wk, b, ks=3, stride=1, wwino=u)
-            assert torch.equal(one, y_w[:1])
+        # (which kernel a launch takes depends on its item count, i.e. on the batch: allowed, because these kernels serve recorded — training —
+        #  passes only; test_wino_forward_is_training_only holds that line)
         # the tuning key switches it off (bit 0: forward launches, bit 1: data gradients)
         L.clc_set_tuning(23, 1 if tr else 2)
         ops.PROFILE = []
@@ -1459,7 +1460,7 @@ def test_wino_forward_is_training_only(dev):
         finally:
             ops.PROFILE = None
 
-    restore = L.clc_set_tuning(23, 3)
+    restore = L.clc_set_tuning(23, 7)
     try:
         with torch.no_grad():
             y_eval, v = fams(lambda: ops.conv2d(x, w, b))
@@ -1471,7 +1472,7 @@ def test_wino_forward_is_training_only(dev):
             y_off, _ = fams(lambda: ops.conv2d(x, w, b))
         assert torch.equal(y_eval, y_off)
         assert (y_tr - y_eval).abs().max().item() / y_eval.abs().max().item() < 4e-6
-        L.clc_set_tuning(23, 3)
+        L.clc_set_tuning(23, 7)
         _, v = fams(lambda: y_tr.square().sum().backward())
         ops.flush_wgrads()
         assert 13 in v, v       # the data gradient took it too

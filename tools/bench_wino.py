@@ -23,6 +23,13 @@ SHAPES_ALL = [  # name, N, H, W, Cin, Cout, shuffle, transposed
     ("64->64 @8x128^2 dgrad", 8, 128, 128, 64, 64, False, True),
     ("64->64 @8x64^2 fwd", 8, 64, 64, 64, 64, False, False),
     ("64->256 @8x64^2 fwd+shuffle", 8, 64, 64, 64, 256, True, False),
+    ("64->64 @8x64^2 dgrad", 8, 64, 64, 64, 64, False, True),
+    ("320->320 @8x32^2 fwd", 8, 32, 32, 320, 320, False, False),
+    ("320->320 @8x32^2 dgrad", 8, 32, 32, 320, 320, False, True),
+    ("128->128 @8x32^2 fwd", 8, 32, 32, 128, 128, False, False),
+    ("128->128 @8x32^2 dgrad", 8, 32, 32, 128, 128, False, True),
+    ("128->512 @8x32^2 dgrad (512 ch in)", 8, 32, 32, 128, 512, False, True),
+    ("64->64 @8x32^2 fwd", 8, 32, 32, 64, 64, False, False),
 ]
 SHAPES = SHAPES_ALL[:int(os.environ.get('WINO_SHAPES', len(SHAPES_ALL)))]
 g = torch.Generator().manual_seed(0)
