@@ -11,7 +11,7 @@ timeout -k 10 400 python3 $R/bench.py > $O/bench.json 2> $O/bench.err || { echo 
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o $tag -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-parity --no-reduced --no-reference-loop > $O/kt.log 2>&1 || { echo "kernel-trace failed"; tail -5 $O/kt.log; exit 4; }
 db=$(find $O/kt -name "*results.db" | head -1)
 python3 $R/tools/prof_db.py stats $db --md $O/kernel_stats.md --csv $O/kernel_stats.csv > /dev/null || { echo "kernel stats summary failed"; exit 4; }
-python3 $R/tools/prof_db.py step $db > $O/step_timeline.txt || { echo "timeline summary failed"; exit 4; }
+python3 $R/tools/prof_db.py step $db --top 200 > $O/step_timeline.txt || { echo "timeline summary failed"; exit 4; }
 head -12 $O/step_timeline.txt
 timeout -k 10 400 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmcA -o pmc -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-parity --no-reduced --no-reference-loop > $O/pmcA.log 2>&1 || { echo "pmc A failed"; tail -5 $O/pmcA.log; exit 5; }
 python3 $R/tools/pmc_step.py $(find $O/pmcA -name "*counter_collection.csv" | head -1) $O/pmc_clock_mfma.md | tail -3 || { echo "pmc clock summary failed"; exit 5; }
