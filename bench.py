@@ -27,6 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense bf16 MFMA, same table (the headline 5 PF figure is 2:1 sparsity)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -329,9 +330,15 @@ def _kernel_name(L, r):
         dma = "true" if shape.endswith("dma=1") and wgrad_dma else "false"   # <..., true>: LDS-DMA-staged instantiation
         if variant == 1:
             return "wgrad_small_kernel"
-        if variant in (64908, 64916, 64932):
-            return f"conv_wgrad_taps_sk_kernel<{variant - 64900}, {dma}, false>"   # (last argument: the bf16-MFMA instantiation of the reduced-precision mode)
-        return f"conv_wgrad_sk_kernel<{variant // 1000}, {variant % 1000}, 2, 2, {dma}, false>"
+        # last argument (LDS-DMA-staged problems only): 0 = v_mfma_f32_32x32x2_f32, 1 = the reduced-precision mode's bf16 MFMA (tuning key 14), 2 = f32 products
+        # from three-way bf16 splits on the bf16 matrix cores (tuning key 24: bit 0 the all-taps kernels, bit 1 the tiled ones)
+        taps = variant in (64908, 64916, 64932)
+        bf = 0
+        if dma == "true":
+            bf = 1 if L.clc_get_tuning(14) and "dma=1" in shape else (2 if L.clc_get_tuning(24) & (1 if taps else 2) else 0)
+        if taps:
+            return f"conv_wgrad_taps_sk_kernel<{variant - 64900}, {dma}, {bf}>"
+        return f"conv_wgrad_sk_kernel<{variant // 1000}, {variant % 1000}, 2, 2, {dma}, {bf}>"
     if fam != "conv_igemm" or variant < (1 << 20):
         return fam   # conv_direct_small / single (non-deferred) wgrad calls / proxied entry points
     tr = "true" if shape.startswith("dgrad") else "false"
@@ -561,8 +568,15 @@ def roofline_leg(engine, x, refs):
         ff, tt = sum(v[0] for v in tr), sum(v[1] for v in tr)
         owners["transforms"] = {"gflop": round(ff / 1e9, 1), "ms": round(tt * 1e3, 3), "tflops": round(ff / tt / 1e12, 2),
                                 "frac_of_f32_mfma_peak": round(ff / tt / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
+    path = {}
+    if not hbm_bound and name.startswith("conv_wgrad") and name.rstrip(">").endswith(", 2"):
+        # f32 products from three-way bf16 splits: six v_mfma_f32_32x32x16_bf16 per algorithmic f32 multiply-add block (csrc/conv_wgrad.hip split3).  `peak`
+        # stays the dense MFMA peak of the arithmetic type (f32), as the contract says; this is the ceiling of the instructions actually issued.
+        path = {"instruction_path": "6 x v_mfma_f32_32x32x16_bf16 per 16 k (f32 operands split into three bf16 pieces in registers, f32 accumulate; error "
+                                    "against fp64 equal to the f32-MFMA kernel's: tools/check_split_wgrad.py, tests/test_kernels_gpu.py::test_split_wgrad_*)",
+                "instruction_path_peak": round(BF16_MFMA_PEAK_TFLOPS / 6, 1), "instruction_path_frac": round(achieved / (BF16_MFMA_PEAK_TFLOPS / 6), 4)}
     return {"bound": "hbm" if hbm_bound else "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s" if hbm_bound else "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "frac": round(achieved / peak, 4), **path, "traffic": traffic, "traffic_source": traffic_source,
             "launches_per_step": n, "avg_launch_ms": round(t / n * 1e3, 4),
             "avg_launch_ms_eager_bracketed": round(t_eager / n * 1e3, 4), "event_bracket_overhead_ms": round(empty * 1e3, 5),
             "timing_note": ("achieved / avg_launch_ms: this kernel's launches of one step (stream-K family: main grid + fix-up) re-issued in order inside "

@@ -33,7 +33,8 @@ enum { CLC_TUNE_DMA_LOOP = 0 /* 1: conv_igemm_dma_kernel, 2: conv_igemm_dma2_ker
        CLC_TUNE_LIN = 21 /* 128 -> 128 / 64 -> 64 1x1 layers on >= 32 768 rows: the wave-private persistent kernel with whole-line stores (fused_mlp.hip: lin_kernel; same bits) */,
        CLC_TUNE_HALO = 22 /* 3x3 / stride-1 layers with 128 input channels whose caller supplies the packed filter (clc_conv_desc.w_packed): the halo-resident barrier-free kernel (conv_halo.hip; same bits); bit mask: 1 = 128-input-channel layers, 2 = 64-input-channel layers */,
        CLC_TUNE_WINO = 23 /* 3x3 / stride-1 layers with 128 k input channels whose caller supplies the Winograd-transformed filter (clc_conv_desc.w_wino): conv_wino_kernel / conv_wino64_kernel (F(2x2, 3x3); ANOTHER summation order); bit mask: 1 = forward launches, 2 = data gradients, 4 = the 64-wide kernel for layers of 64 k channels, 8 = the 64-wide kernel on every layer (experiment) */,
-       CLC_TUNE_COUNT = 24 };
+       CLC_TUNE_SPLIT = 24 /* f32 products from three-way bf16 splits (six v_mfma_f32_32x32x16_bf16 per 16 k, f32 accumulate; error of an f32 multiply-add) instead of v_mfma_f32_32x32x2_f32 in the filter-gradient kernels: bit 0 = all-taps 3x3 kernels, bit 1 = tiled kernels */,
+       CLC_TUNE_COUNT = 25 };
 extern int clc_tuning[CLC_TUNE_COUNT];
 // fused_mlp.hip: y = W x + b (+ res_scale * res) on the wave-private persistent kernel; 0 = shape not built (the caller falls through)
 // conv_halo.hip: 0 = the launch does not qualify (conv_params: the ConvParams clc_conv2d filled)

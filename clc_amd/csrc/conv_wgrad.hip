@@ -60,10 +60,29 @@ struct WgradParams {
 // mode 1: same layout, accumulate (single writer per element); mode 2: compact tile image (stream-K partial slot).
 struct OutSpec { float* w; float* b; int mode; };
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// BF = 2: f32 products on the bf16 matrix cores.  An f32 value is the exact sum of three bf16 pieces (8 + 8 + 8 significand bits: v = h + m + l with
+// h = bf16(v), m = bf16(v - h), l = bf16(v - h - m); the differences are exact in f32), so a product is the sum of nine exact piece products; the six
+// largest — h h', h m', m h', h l', l h', m m' — are accumulated in f32 by six v_mfma_f32_32x32x16_bf16, the dropped three are <= 2^-23 of the product
+// together (an f32 multiply-add's own rounding is 2^-24).  The bf16 matrix rate is 16x the f32 one: 6 / 16 of the MFMA time, plus the splitting.
+__device__ __forceinline__ void split3(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 hb = (__bf16)v[e];
+    const float r = v[e] - (float)hb;
+    const __bf16 mb = (__bf16)r;
+    const float r2 = r - (float)mb;
+    h[e] = hb; m[e] = mb; l[e] = (__bf16)r2;
+  }
+}
+#define MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+// (small terms first: they meet the running sum at their own magnitude)
+#define MFMA_SPLIT6(ah, am, al, bh, bm, bl, c) do { \
+    c = MFMA_BF(al, bh, c); c = MFMA_BF(ah, bl, c); c = MFMA_BF(am, bm, c); \
+    c = MFMA_BF(am, bh, c); c = MFMA_BF(ah, bm, c); c = MFMA_BF(ah, bh, c); } while (0)
 
 // BF (with DMA): reduced-precision mode (CLC_TUNE_BF16) — the f32 tiles in LDS are rounded to bf16 at fragment read and 16 k are
 // contracted by one v_mfma_f32_32x32x16_bf16 (f32 accumulate): lane half h supplies k = 16 q + 2 j + h as element j for both operands.
-template <int BM, int BN, int WM, int WN, bool DMA = false, bool BF = false>
+template <int BM, int BN, int WM, int WN, bool DMA = false, int BF = 0>
 __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, const int by, const int k_begin, const int k_end, const OutSpec o, const int tid) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -251,7 +270,29 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
       if (use_dma && do_bias) bias_from_lds(buf);
       const float* Ab = As + (buf * BK + khalf) * BM + wm * (BM / WM) + li;
       const float* Bb = Bs + (buf * BK + khalf) * BN + wn * (BN / WN) + li;
-      if constexpr (BF) {
+      if constexpr (BF == 2) {
+#pragma unroll
+        for (int q = 0; q < BK / 16; ++q) {
+          bf16x8 pa[TM][3], pb[TN][3];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = Ab[(16 * q + 2 * e) * BM + i * 32];
+            split3(v, pa[i][0], pa[i][1], pa[i][2]);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = Bb[(16 * q + 2 * e) * BN + j * 32];
+            split3(v, pb[j][0], pb[j][1], pb[j][2]);
+          }
+#define CLC_TERM(ia, ib) _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = MFMA_BF(pa[i][ia], pb[j][ib], acc[i][j]);
+          CLC_TERM(2, 0) CLC_TERM(0, 2) CLC_TERM(1, 1) CLC_TERM(1, 0) CLC_TERM(0, 1) CLC_TERM(0, 0)   // term-major, small terms first
+#undef CLC_TERM
+        }
+      } else if constexpr (BF == 1) {
 #pragma unroll
         for (int q = 0; q < BK / 16; ++q) {
           bf16x8 pa[TM], pb[TN];
@@ -340,7 +381,7 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, c
 // the (TH+2) x (TW+2) input window are staged in LDS ONCE and the nine taps are nine shifted views of that window:
 // 64 co x (9 taps x 64 ci) outputs per workgroup, wave (wm, wn) = 32 co x 32 ci x 9 taps = 9 MFMA blocks (144 acc
 // registers), 10 ds_read_b32 per 9 MFMAs.  Same slab layout / fixed-order reduce as above.
-template <int TW, bool DMA = false, bool BF = false>
+template <int TW, bool DMA = false, int BF = 0>
 __device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int bx, const int by, const int t_begin, const int t_end, const OutSpec o, const int tid) {
   constexpr int TH = 32 / TW, XW = TW + 2, XH = TH + 2, XP = XH * XW;
   constexpr int LTW = TW == 32 ? 5 : (TW == 16 ? 4 : 3);
@@ -467,7 +508,52 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int 
     else if (more) load_tile(t_begin + kt + 1);
     const float* Ab = As + buf * 32 * 64 + wm * 32 + li;
     const float* Xb = Xs + buf * XP * 64 + wn * 32 + li;
-    if (DMA && BF) {   // reduced-precision mode: 16 k per v_mfma_f32_32x32x16_bf16, lane half h supplies k = 16 q + 2 j + h as element j
+    if (DMA && BF == 2) {   // f32 products from bf16 pieces (split3): 16 k per six v_mfma_f32_32x32x16_bf16, lane half h supplies k = 16 q + 2 j + h
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) bias_acc[i] += *reinterpret_cast<const f32x4*>(As + buf * 32 * 64 + (tid + i * 256) * 4);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        bf16x8 pa[3];
+        const float* xk[8];
+        {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int k = 16 * q + 2 * e + khalf;
+            v[e] = Ab[k * 64];
+            xk[e] = Xb + ((k >> LTW) * XW + (k & (TW - 1))) * 64;
+          }
+          split3(v, pa[0], pa[1], pa[2]);
+        }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          bf16x8 px[3][3];   // [kw][piece]
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = xk[e][(kh * XW + kw) * 64];
+            split3(v, px[kw][0], px[kw][1], px[kw][2]);
+          }
+          // term-major over the three taps of the row: consecutive MFMAs go to different accumulators (small terms first)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = MFMA_BF(pa[2], px[kw][0], acc[kh * 3 + kw]);
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = MFMA_BF(pa[0], px[kw][2], acc[kh * 3 + kw]);
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = MFMA_BF(pa[1], px[kw][1], acc[kh * 3 + kw]);
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = MFMA_BF(pa[1], px[kw][0], acc[kh * 3 + kw]);
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = MFMA_BF(pa[0], px[kw][1], acc[kh * 3 + kw]);
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = MFMA_BF(pa[0], px[kw][0], acc[kh * 3 + kw]);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's pieces have landed
+    } else if (DMA && BF == 1) {   // reduced-precision mode: 16 k per v_mfma_f32_32x32x16_bf16, lane half h supplies k = 16 q + 2 j + h as element j
       if (do_bias) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) bias_acc[i] += *reinterpret_cast<const f32x4*>(As + buf * 32 * 64 + (tid + i * 256) * 4);
@@ -713,7 +799,7 @@ __device__ __forceinline__ OutSpec sk_out(const SKGroup& g, const WgradParams& p
   return o;
 }
 
-template <int TW, bool DMA, bool BF = false>
+template <int TW, bool DMA, int BF = 0>
 __global__ __launch_bounds__(256, 2)
 void conv_wgrad_taps_sk_kernel(const SKGroup g) {
   const int w = blockIdx.x;
@@ -737,7 +823,7 @@ void conv_wgrad_taps_sk_kernel(const SKGroup g) {
 // resident workgroups per CU the register / LDS budget of each tile shape allows (= the split-K kernels' occupancy)
 constexpr int sk_wg_per_cu(int bm, int bn) { return bm * bn >= 128 * 128 ? 2 : (bm * bn >= 128 * 64 ? 3 : 5); }
 
-template <int BM, int BN, int WM, int WN, bool DMA, bool BF = false>
+template <int BM, int BN, int WM, int WN, bool DMA, int BF = 0>
 __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 128 * 128 ? 2 : (BM * BN >= 128 * 64 ? 4 : 6)))
 void conv_wgrad_sk_kernel(const SKGroup g) {
   const int w = blockIdx.x;
@@ -1220,9 +1306,14 @@ bool sk_collect(const Pending* pend, int n, SKGroup& g, float* region, int slot_
 inline bool dma_ok(const Pending& e) { return clc_tuning[CLC_TUNE_WGRAD_DMA] && e.d->dys == nullptr && e.d->in_op == CLC_IN_NONE; }
 // reduced-precision mode (CLC_TUNE_BF16): the LDS-DMA-staged problems of maps larger than 16x16 (= the analysis / synthesis transforms and
 // the reference encoder; the entropy-parameter nets on the 16x16 latents stay f32)
-inline bool bf_ok(const Pending& e) { return clc_tuning[CLC_TUNE_BF16] && dma_ok(e) && (long)e.d->OH * e.d->OW > 256; }
+inline int bf_ok(const Pending& e) {
+  if (!dma_ok(e)) return 0;
+  if (clc_tuning[CLC_TUNE_BF16] && (long)e.d->OH * e.d->OW > 256) return 1;
+  // (key 24) f32 products from three-way bf16 splits on the bf16 matrix cores (BF = 2): bit 0 = the all-taps 3x3 kernels, bit 1 = the tiled kernels
+  return (clc_tuning[CLC_TUNE_SPLIT] & (e.pl.taps ? 1 : 2)) ? 2 : 0;
+}
 
-template <int BM, int BN, bool DMA, bool BF = false>
+template <int BM, int BN, bool DMA, int BF = 0>
 int launch_variant_sk(const Pending* pend, int n, float* region, hipStream_t st) {
   static thread_local SKGroup g;   // (host staging of the kernel argument; launches are issued by one host thread per process)
   constexpr int slot = (int)sk_slot_floats(BM * BN, BM);
@@ -1240,7 +1331,7 @@ int launch_variant_sk(const Pending* pend, int n, float* region, hipStream_t st)
   return 0;
 }
 
-template <int TW, bool DMA, bool BF = false>
+template <int TW, bool DMA, int BF = 0>
 int launch_taps_sk(const Pending* pend, int n, float* region, hipStream_t st) {
   static thread_local SKGroup g;
   constexpr int slot = (int)sk_slot_floats(64 * 9 * 64, 64);
@@ -1290,31 +1381,38 @@ int flush_sk(Pending* pend, int& n, float* ws, hipStream_t st) {
   int rc;
   float* r = ws;
   if ((rc = launch_variant_sk<128, 128, true>(pend, n, r, st)) < 0) return rc;    // (the two launches of a family share its region: stream order)
-  if ((rc = launch_variant_sk<128, 128, true, true>(pend, n, r, st)) < 0) return rc;    // (reduced-precision mode: bf16 MFMA)
+  if ((rc = launch_variant_sk<128, 128, true, 1>(pend, n, r, st)) < 0) return rc;    // (reduced-precision mode: bf16 MFMA)
+  if ((rc = launch_variant_sk<128, 128, true, 2>(pend, n, r, st)) < 0) return rc;    // (f32 products from bf16 pieces)
   if ((rc = launch_variant_sk<128, 128, false>(pend, n, r, st)) < 0) return rc;
   r += kSKRegion[0] + kSKPlanFloats;
   if ((rc = launch_variant_sk<128, 64, true>(pend, n, r, st)) < 0) return rc;    // (the two launches of a family share its region: stream order)
-  if ((rc = launch_variant_sk<128, 64, true, true>(pend, n, r, st)) < 0) return rc;    // (reduced-precision mode: bf16 MFMA)
+  if ((rc = launch_variant_sk<128, 64, true, 1>(pend, n, r, st)) < 0) return rc;    // (reduced-precision mode: bf16 MFMA)
+  if ((rc = launch_variant_sk<128, 64, true, 2>(pend, n, r, st)) < 0) return rc;    // (f32 products from bf16 pieces)
   if ((rc = launch_variant_sk<128, 64, false>(pend, n, r, st)) < 0) return rc;
   r += kSKRegion[1] + kSKPlanFloats;
   if ((rc = launch_variant_sk<64, 128, true>(pend, n, r, st)) < 0) return rc;    // (the two launches of a family share its region: stream order)
-  if ((rc = launch_variant_sk<64, 128, true, true>(pend, n, r, st)) < 0) return rc;    // (reduced-precision mode: bf16 MFMA)
+  if ((rc = launch_variant_sk<64, 128, true, 1>(pend, n, r, st)) < 0) return rc;    // (reduced-precision mode: bf16 MFMA)
+  if ((rc = launch_variant_sk<64, 128, true, 2>(pend, n, r, st)) < 0) return rc;    // (f32 products from bf16 pieces)
   if ((rc = launch_variant_sk<64, 128, false>(pend, n, r, st)) < 0) return rc;
   r += kSKRegion[2] + kSKPlanFloats;
   if ((rc = launch_variant_sk<64, 64, true>(pend, n, r, st)) < 0) return rc;    // (the two launches of a family share its region: stream order)
-  if ((rc = launch_variant_sk<64, 64, true, true>(pend, n, r, st)) < 0) return rc;    // (reduced-precision mode: bf16 MFMA)
+  if ((rc = launch_variant_sk<64, 64, true, 1>(pend, n, r, st)) < 0) return rc;    // (reduced-precision mode: bf16 MFMA)
+  if ((rc = launch_variant_sk<64, 64, true, 2>(pend, n, r, st)) < 0) return rc;    // (f32 products from bf16 pieces)
   if ((rc = launch_variant_sk<64, 64, false>(pend, n, r, st)) < 0) return rc;
   r += kSKRegion[3] + kSKPlanFloats;
   if ((rc = launch_taps_sk<32, true>(pend, n, r, st)) < 0) return rc;
-  if ((rc = launch_taps_sk<32, true, true>(pend, n, r, st)) < 0) return rc;
+  if ((rc = launch_taps_sk<32, true, 1>(pend, n, r, st)) < 0) return rc;
+  if ((rc = launch_taps_sk<32, true, 2>(pend, n, r, st)) < 0) return rc;
   if ((rc = launch_taps_sk<32, false>(pend, n, r, st)) < 0) return rc;
   r += kSKRegion[4] + kSKPlanFloats;
   if ((rc = launch_taps_sk<16, true>(pend, n, r, st)) < 0) return rc;
-  if ((rc = launch_taps_sk<16, true, true>(pend, n, r, st)) < 0) return rc;
+  if ((rc = launch_taps_sk<16, true, 1>(pend, n, r, st)) < 0) return rc;
+  if ((rc = launch_taps_sk<16, true, 2>(pend, n, r, st)) < 0) return rc;
   if ((rc = launch_taps_sk<16, false>(pend, n, r, st)) < 0) return rc;
   r += kSKRegion[5] + kSKPlanFloats;
   if ((rc = launch_taps_sk<8, true>(pend, n, r, st)) < 0) return rc;
-  if ((rc = launch_taps_sk<8, true, true>(pend, n, r, st)) < 0) return rc;
+  if ((rc = launch_taps_sk<8, true, 1>(pend, n, r, st)) < 0) return rc;
+  if ((rc = launch_taps_sk<8, true, 2>(pend, n, r, st)) < 0) return rc;
   if ((rc = launch_taps_sk<8, false>(pend, n, r, st)) < 0) return rc;
   n = 0;
   return 0;

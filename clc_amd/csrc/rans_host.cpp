@@ -33,9 +33,9 @@ void clc_set_error(const char* fmt, ...) {
 extern "C" const char* clc_last_error(void) { return g_err; }
 extern "C" int clc_version(void) { return 200; }
 
-#define CLC_TUNING_DEFAULTS {2, 1, 1, 0, 1024, 64, 1, 8, 1, 1, 1, 1, 0, 1, 0, 1, 3, 1, 1, 1, 1, 1, 1, 7}
-int clc_tuning[24] = CLC_TUNING_DEFAULTS;   // (CLC_TUNE_COUNT entries: csrc/common.h, which this host-only file cannot include)
-static const int clc_tuning_default[24] = CLC_TUNING_DEFAULTS;
+#define CLC_TUNING_DEFAULTS {2, 1, 1, 0, 1024, 64, 1, 8, 1, 1, 1, 1, 0, 1, 0, 1, 3, 1, 1, 1, 1, 1, 1, 7, 3}
+int clc_tuning[25] = CLC_TUNING_DEFAULTS;   // (CLC_TUNE_COUNT entries: csrc/common.h, which this host-only file cannot include)
+static const int clc_tuning_default[25] = CLC_TUNING_DEFAULTS;
 extern "C" int clc_set_tuning(int key, int value) {
   if (key < 0 || key >= (int)(sizeof(clc_tuning) / sizeof(clc_tuning[0]))) { clc_set_error("clc_set_tuning: key %d out of range", key); return -1; }
   const int old = clc_tuning[key];
