@@ -508,49 +508,70 @@ __device__ __forceinline__ void wgrad_taps_body(const WgradParams& p, const int 
     else if (more) load_tile(t_begin + kt + 1);
     const float* Ab = As + buf * 32 * 64 + wm * 32 + li;
     const float* Xb = Xs + buf * XP * 64 + wn * 32 + li;
-    if (DMA && BF == 2) {   // f32 products from bf16 pieces (split3): 16 k per six v_mfma_f32_32x32x16_bf16, lane half h supplies k = 16 q + 2 j + h
+    if (DMA && BF == 2) {   // f32 products from bf16 pieces (split3), split in registers: 16 k per six v_mfma_f32_32x32x16_bf16.
+      // Lane half h supplies k = 16 q + 8 h + j as element j (any k <-> slot bijection serves, as long as both operands use it): a lane's 8 k are
+      // 8 CONSECUTIVE pixels of one row, so the three taps of a filter row need 10 consecutive window columns — 10 values read and split per
+      // (q, kh) instead of 24, the fragments of kw = 0 / 1 / 2 being three shifted views of them.  Software-pipelined: the values of step
+      // (q, kh) + 1 are read and split while the 18 MFMAs of step (q, kh) run (VALU issues between the 32-cycle MFMAs of the same wave).
       if (do_bias) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) bias_acc[i] += *reinterpret_cast<const f32x4*>(As + buf * 32 * 64 + (tid + i * 256) * 4);
       }
+      struct Row { bf16x8 x[3][3]; };   // [kw][piece]
+      auto split_a = [&](int q, bf16x8 (&pa)[3]) {
+        float v[8];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        bf16x8 pa[3];
-        const float* xk[8];
-        {
-          float v[8];
+        for (int e = 0; e < 8; ++e) v[e] = Ab[(16 * q + 8 * khalf + e) * 64];
+        split3(v, pa[0], pa[1], pa[2]);
+      };
+      auto split_row = [&](int q, int kh, Row& r) {
+        const int rowq = TW == 32 ? 0 : (TW == 16 ? q : 2 * q + khalf);
+        const int colq = TW == 32 ? 16 * q + 8 * khalf : (TW == 16 ? 8 * khalf : 0);
+        const float* xr = Xb + ((rowq + kh) * XW + colq) * 64;
+        __bf16 ph[10], pm[10], pl[10];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int k = 16 * q + 2 * e + khalf;
-            v[e] = Ab[k * 64];
-            xk[e] = Xb + ((k >> LTW) * XW + (k & (TW - 1))) * 64;
-          }
-          split3(v, pa[0], pa[1], pa[2]);
+        for (int c = 0; c < 10; ++c) {   // truncating pieces (masks and subtractions only): v = h + m + l exactly
+          const float v = xr[c * 64];
+          const unsigned hb = __builtin_bit_cast(unsigned, v) & 0xFFFF0000u;
+          const float r1 = v - __builtin_bit_cast(float, hb);
+          const unsigned mb = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+          const float r2 = r1 - __builtin_bit_cast(float, mb);
+          ph[c] = __builtin_bit_cast(__bf16, (unsigned short)(hb >> 16));
+          pm[c] = __builtin_bit_cast(__bf16, (unsigned short)(mb >> 16));
+          pl[c] = __builtin_bit_cast(__bf16, (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16));
         }
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          bf16x8 px[3][3];   // [kw][piece]
+        for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            float v[8];
+          for (int e = 0; e < 8; ++e) { r.x[kw][0][e] = ph[e + kw]; r.x[kw][1][e] = pm[e + kw]; r.x[kw][2][e] = pl[e + kw]; }
+      };
+      bf16x8 pa[2][3];
+      Row rows[2];
+      split_a(0, pa[0]);
+      split_row(0, 0, rows[0]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = xk[e][(kh * XW + kw) * 64];
-            split3(v, px[kw][0], px[kw][1], px[kw][2]);
-          }
-          // term-major over the three taps of the row: consecutive MFMAs go to different accumulators (small terms first)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = MFMA_BF(pa[2], px[kw][0], acc[kh * 3 + kw]);
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = MFMA_BF(pa[0], px[kw][2], acc[kh * 3 + kw]);
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = MFMA_BF(pa[1], px[kw][1], acc[kh * 3 + kw]);
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = MFMA_BF(pa[1], px[kw][0], acc[kh * 3 + kw]);
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = MFMA_BF(pa[0], px[kw][1], acc[kh * 3 + kw]);
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = MFMA_BF(pa[0], px[kw][0], acc[kh * 3 + kw]);
+      for (int st = 0; st < 6; ++st) {
+        const int q = st / 3, kh = st - 3 * q, cur = st & 1;
+        if (st + 1 < 6) {                                  // the next step's operands: independent of this step's MFMAs
+          const int qn = (st + 1) / 3, khn = (st + 1) - 3 * qn;
+          if (khn == 0) split_a(qn, pa[qn]);
+          split_row(qn, khn, rows[cur ^ 1]);
         }
+        const bf16x8 (&a)[3] = pa[q];
+        const Row& r = rows[cur];
+        // term-major over the three taps of the row: consecutive MFMAs go to different accumulators (small terms first)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = MFMA_BF(a[2], r.x[kw][0], acc[kh * 3 + kw]);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = MFMA_BF(a[0], r.x[kw][2], acc[kh * 3 + kw]);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = MFMA_BF(a[1], r.x[kw][1], acc[kh * 3 + kw]);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = MFMA_BF(a[1], r.x[kw][0], acc[kh * 3 + kw]);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = MFMA_BF(a[0], r.x[kw][1], acc[kh * 3 + kw]);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = MFMA_BF(a[0], r.x[kw][0], acc[kh * 3 + kw]);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's pieces have landed
     } else if (DMA && BF == 1) {   // reduced-precision mode: 16 k per v_mfma_f32_32x32x16_bf16, lane half h supplies k = 16 q + 2 j + h as element j
