@@ -575,6 +575,11 @@ def roofline_leg(engine, x, refs):
         path = {"instruction_path": "6 x v_mfma_f32_32x32x16_bf16 per 16 k (f32 operands split into three bf16 pieces in registers, f32 accumulate; error "
                                     "against fp64 equal to the f32-MFMA kernel's: tools/check_split_wgrad.py, tests/test_kernels_gpu.py::test_split_wgrad_*)",
                 "instruction_path_peak": round(BF16_MFMA_PEAK_TFLOPS / 6, 1), "instruction_path_frac": round(achieved / (BF16_MFMA_PEAK_TFLOPS / 6), 4)}
+    if not hbm_bound and name.startswith("conv_wino"):
+        # Winograd F(2x2, 3x3): `achieved` counts the direct convolution's FLOPs (the algorithmic figure the contract asks for), of which the kernel issues 16 / 36
+        path = {"instruction_path": "Winograd F(2x2, 3x3) on v_mfma_f32_32x32x2_f32: 16 of the direct convolution's 36 multiplications per 2x2 output tile "
+                                    "(csrc/conv_wino.hip); achieved x 16 / 36 is the rate of the MFMAs actually issued",
+                "instruction_path_peak": F32_MFMA_PEAK_TFLOPS, "instruction_path_frac": round(achieved * 16 / 36 / F32_MFMA_PEAK_TFLOPS, 4)}
     return {"bound": "hbm" if hbm_bound else "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s" if hbm_bound else "TFLOP/s",
             "frac": round(achieved / peak, 4), **path, "traffic": traffic, "traffic_source": traffic_source,
             "launches_per_step": n, "avg_launch_ms": round(t / n * 1e3, 4),
