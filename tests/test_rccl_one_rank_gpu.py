@@ -26,9 +26,9 @@ def _env(**kw):
 def test_rccl_one_rank_three_graph_step_is_bit_identical_to_no_group(dev, tmp_path):
     ref = str(tmp_path / "ref.json")
     tool = os.path.join(ROOT, "tools", "rehearse_2rank.py")
-    a = subprocess.run([sys.executable, tool, "--single", ref, "--steps", "3"], capture_output=True, text=True, timeout=400, env=_env(), cwd=ROOT)
+    a = subprocess.run([sys.executable, tool, "--single", ref, "--steps", "3"], capture_output=True, text=True, timeout=360, env=_env(), cwd=ROOT)
     assert a.returncode == 0, a.stderr[-2000:]
-    b = subprocess.run([sys.executable, tool, "--rccl1", ref, "--steps", "3"], capture_output=True, text=True, timeout=500, env=_env(), cwd=ROOT)
+    b = subprocess.run([sys.executable, tool, "--rccl1", ref, "--steps", "3"], capture_output=True, text=True, timeout=360, env=_env(), cwd=ROOT)
     assert b.returncode == 0, (b.stdout[-1500:], b.stderr[-3000:])
     rep = json.loads(next(l for l in b.stdout.splitlines() if l.startswith("REHEARSAL "))[len("REHEARSAL "):])
     assert rep["backend"] == "nccl" and rep["graphs"] == 3 and rep["bit_identical_to_no_group"]
@@ -37,7 +37,7 @@ def test_rccl_one_rank_three_graph_step_is_bit_identical_to_no_group(dev, tmp_pa
 
 def _bench(env):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "4",
-                        "--no-roofline", "--no-parity", "--no-reduced", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+                        "--no-roofline", "--no-parity", "--no-reduced", "--no-cpu-baseline"], capture_output=True, text=True, timeout=360, env=env, cwd=ROOT)
     if r.returncode != 0:   # keep the whole child output where a gpurun call brings it home
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "rccl_bench_child_failure.txt"), "w") as fh:

@@ -34,7 +34,7 @@ def test_bench_gpus2_self_launches_two_ranks(dev):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4"],
-                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+                       capture_output=True, text=True, timeout=360, env=env, cwd=ROOT)   # (under the GPU harness's 420-s silence limit: a hung child must fail THIS test, not get the whole run killed)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]
