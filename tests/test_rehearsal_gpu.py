@@ -18,7 +18,7 @@ def test_two_ranks_on_one_device_reproduce_the_single_rank_run(dev, tmp_path):
     a = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rehearse_2rank.py"), "--single", ref, "--steps", "2"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert a.returncode == 0, a.stderr[-2000:]
     b = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
-                        os.path.join(ROOT, "tools", "rehearse_2rank.py"), "--check", ref, "--steps", "2"], capture_output=True, text=True, timeout=500, env=env, cwd=ROOT)
+                        os.path.join(ROOT, "tools", "rehearse_2rank.py"), "--check", ref, "--steps", "2"], capture_output=True, text=True, timeout=360, env=env, cwd=ROOT)
     assert b.returncode == 0, (b.stdout[-1500:], b.stderr[-2500:])
     line = next(l for l in b.stdout.splitlines() if l.startswith("REHEARSAL "))
     rep = json.loads(line[len("REHEARSAL "):])
