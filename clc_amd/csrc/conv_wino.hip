@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(const WinoParams wp) 
         float* Vn = VV + ((kc + 1) & 1) * VB_FLOATS;
         const int c16 = cg * 8 + kc;
         f32x4 aq[2][2];
-        f32x4 da[4], db[4], T[4];
+        f32x4 da[4], T[4];
 #pragma unroll
         for (int t8 = 0; t8 < 2; ++t8) aq[0][t8] = *reinterpret_cast<const f32x4*>(Vc + (4 * wi) * 512 + afo[t8]);
         int npt = -1, ncg2 = 0;
@@ -193,17 +193,17 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(const WinoParams wp) 
           // the transform of chunk kc + 1 into the other buffer, a third per group.  (kc = 7: a throw-away pass over chunk 0 — nobody reads that
           // buffer before the next group's first transform / the output rounds overwrite it — instead of a branch around each part.)
           if (WINO_AB & 8) {
-          } else if (g == 0) {
+          } else if (g == 0) {       // (first patch row under group 0, second row + the row transform under group 1: 16 registers less across the boundary)
+            const int cb = (((kc + 1) & 7) * 4 + q);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) da[c] = *reinterpret_cast<const f32x4*>(halo + hbase + c * 128 + ((cb ^ (c < 2 ? sw0 : sw1)) << 2));
+          } else if (g == 1) {
             const int cb = (((kc + 1) & 7) * 4 + q);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-              const float* src = halo + hbase + c * 128 + ((cb ^ (c < 2 ? sw0 : sw1)) << 2);
-              da[c] = *reinterpret_cast<const f32x4*>(src);
-              db[c] = *reinterpret_cast<const f32x4*>(src + hdelta);
+              const f32x4 dbv = *reinterpret_cast<const f32x4*>(halo + hbase + hdelta + c * 128 + ((cb ^ (c < 2 ? sw0 : sw1)) << 2));
+              T[c] = da[c] + sg * dbv;
             }
-          } else if (g == 1) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) T[c] = da[c] + sg * db[c];
           } else if (g == 2) {
             float* dst = Vn + vdst;
             *reinterpret_cast<f32x4*>(dst) = T[0] - T[2];
