@@ -175,7 +175,9 @@ def test_container_header_errors_and_kernel_tag():
     from clc_amd import lib
 
     L = lib.load()
-    for key, val, changes in ((14, 1, True), (16, 7, True), (16, 1, False), (4, 256, True), (13, 0, False)):
+    # keys 22 (halo kernel: same bits), 23 (Winograd kernels) and 24 (split-bf16 filter gradients) reach training launches only — recorded forwards, data
+    # and filter gradients — never a launch of the codec path: not part of the tag
+    for key, val, changes in ((14, 1, True), (16, 7, True), (16, 1, False), (4, 256, True), (13, 0, False), (22, 0, False), (23, 0, False), (24, 0, False)):
         prev = L.clc_set_tuning(key, val)
         try:
             t2 = codec.kernel_config_tag()
@@ -185,7 +187,8 @@ def test_container_header_errors_and_kernel_tag():
                     codec.unpack(blob)                    # written under the default tuning, read under another
         finally:
             L.clc_set_tuning(key, prev)
-    assert codec.kernel_config_tag() == tag and L.clc_get_tuning(16) == 3
+    assert codec.kernel_config_tag() == tag and L.clc_get_tuning(16) == 3 and L.clc_get_tuning(23) == 7 and L.clc_get_tuning(24) == 3
+    assert L.clc_set_tuning(25, 1) < 0        # (one past the last key)
     # the state is captured WHEN THE KERNELS RAN (compress() returns it as `kernel_config`), not when pack() is called: an image encoded
     # under a temporary non-default state and packed after the default was restored carries the encoding state — as a version-2 header
     # with the full 32-bit hash beside the 7-bit tag (two non-default states cannot be mistaken for each other)
