@@ -462,6 +462,11 @@ def transforms_leg(model, x, refs, engine=None):
     return out
 
 
+def _tuning(key):
+    from clc_amd import lib as _clib
+    return int(_clib.load().clc_get_tuning(key))
+
+
 def roofline_leg(engine, x, refs):
     """One eager (non-graph) step with every launch through the C ABI bracketed by HIP events on its launch stream (per-kernel table,
     dominant kernel, in-step attribution to the sub-networks); then the dominant kernel's launches re-issued inside a hipGraph and
@@ -880,7 +885,12 @@ def main():
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "ranks_seen": (dist.get_world_size() if use_dist else 1),
                    "collective": ((("RCCL" if backend == "nccl" else backend) + " all-reduce of the flat fp32 gradient arena (64 MiB buckets) in two phases: everything "
                                    "downstream of the encoders goes on the wire while the analysis-transform / reference-encoder backward runs")
-                                  if use_dist else "none"), "hip_graph": not args.no_graph, "final_loss": loss},
+                                  if use_dist else "none"), "hip_graph": not args.no_graph, "final_loss": loss,
+                   # what the f32 arithmetic of the TRAINING launches runs on (inference, parity and codec launches: direct f32-MFMA kernels only)
+                   "training_kernels": {"winograd_f2x2_3x3 (tuning key 23)": _tuning(23), "wgrad_f32_products_from_bf16_splits (tuning key 24)": _tuning(24),
+                                        "note": "f32 operands and f32 accumulation throughout; key 23: 16/36 of the multiplications in the 3x3 / stride-1 layers of the "
+                                                "transforms; key 24: filter-gradient products formed from three bf16 pieces per operand on the bf16 matrix cores "
+                                                "(six MFMAs per 16 k), error against fp64 equal to the f32-MFMA kernels'"}},
     }
     if use_dist:
         # exposed_comm_ms: HIP events around the wait for the exchange (after graph A2), mean of 5 extra steps behind the timed region
