@@ -335,7 +335,7 @@ def _kernel_name(L, r):
         taps = variant in (64908, 64916, 64932)
         bf = 0
         if dma == "true":
-            bf = 1 if L.clc_get_tuning(14) and "dma=1" in shape else (2 if L.clc_get_tuning(24) & (1 if taps else 2) else 0)
+            bf = 1 if L.clc_get_tuning(14) and "dma=1" in shape else (2 if (L.clc_get_tuning(24) & (1 if taps else 2)) and (taps or variant != 64064) else 0)   # (64 x 64 tiles keep the f32 MFMAs)
         if taps:
             return f"conv_wgrad_taps_sk_kernel<{variant - 64900}, {dma}, {bf}>"
         return f"conv_wgrad_sk_kernel<{variant // 1000}, {variant % 1000}, 2, 2, {dma}, {bf}>"

@@ -1331,6 +1331,8 @@ inline int bf_ok(const Pending& e) {
   if (!dma_ok(e)) return 0;
   if (clc_tuning[CLC_TUNE_BF16] && (long)e.d->OH * e.d->OW > 256) return 1;
   // (key 24) f32 products from three-way bf16 splits on the bf16 matrix cores (BF = 2): bit 0 = the all-taps 3x3 kernels, bit 1 = the tiled kernels
+  // (the 64 x 64 tiles split 16 values per 6 MFMAs — VALU-bound, measured 0.93-0.99x: they keep the f32 MFMAs)
+  if (!e.pl.taps && e.pl.bm == 64 && e.pl.bn == 64) return 0;
   return (clc_tuning[CLC_TUNE_SPLIT] & (e.pl.taps ? 1 : 2)) ? 2 : 0;
 }
 

@@ -12,7 +12,7 @@ L = ops._L()
 CL = torch.channels_last
 g = torch.Generator().manual_seed(0)
 SHAPES = [("128->128 k3 @8x128^2", 8, 128, 128, 128, 128, 3), ("64->64 k3 @8x128^2", 8, 128, 128, 64, 64, 3), ("128->512 k3 @8x64^2", 8, 64, 64, 128, 512, 3),
-          ("128->128 k1 @8x128^2", 8, 128, 128, 128, 128, 1), ("320->320 k3 @8x32^2", 8, 32, 32, 320, 320, 3), ("640->224 k3 @8x16^2", 8, 16, 16, 640, 224, 3)]
+          ("128->128 k1 @8x128^2", 8, 128, 128, 128, 128, 1), ("320->320 k3 @8x32^2", 8, 32, 32, 320, 320, 3), ("64->64 k1 @8x128^2", 8, 128, 128, 64, 64, 1), ("64->256 k1 @8x128^2", 8, 128, 128, 64, 256, 1), ("192->64 k1 @8x128^2", 8, 128, 128, 192, 64, 1), ("640->224 k3 @8x16^2", 8, 16, 16, 640, 224, 3)]
 for name, N, H, W, Cin, Cout, ks in SHAPES:
     x = torch.randn(N, Cin, H, W, generator=g).to(dev).contiguous(memory_format=CL)
     dy = torch.randn(N, Cout, H, W, generator=g).to(dev).contiguous(memory_format=CL)
