@@ -208,12 +208,22 @@ def _inputs(dev, B, R, size=256):
     return synthetic_image(B, size, size, 100, smooth=True).to(dev), [synthetic_image(B, size, size, 101 + i, smooth=True).to(dev) for i in range(R)]
 
 
+@pytest.mark.parametrize("wgrad_arith", ["f32_mfma", "default"])
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_engine_equals_reference_training_loop(dev, use_graph):
+def test_engine_equals_reference_training_loop(dev, use_graph, wgrad_arith, request):
     """TrainEngine (flat arenas, fused optimizer, hipGraph) against the reference loop driven by torch.optim.AdamW on the same
     product model: 4 steps, the loss / bpp / aux-loss sequences and the final parameters.  Also pins that the captured path
-    applies exactly ONE update per call (the graph warm-up must not train)."""
+    applies exactly ONE update per call (the graph warm-up must not train).
+    wgrad_arith: the engine's GROUPED filter-gradient launches form their f32 products from bf16 splits by default (tuning key 24), the reference
+    loop's single launches use the f32 MFMAs — both at the same error against fp64, but two independent roundings instead of one summation
+    order and another.  "f32_mfma" pins key 24 to 0 (identical arithmetic on both sides: the strict sliver bar); "default" keeps it and
+    allows the larger sliver of sign-of-noise elements (measured 0.6-2.2 %; a wrong update rule moves ALL elements)."""
+    from clc_amd import lib
     from clc_amd.train import TrainEngine
+
+    if wgrad_arith == "f32_mfma":
+        L = lib.load()
+        request.addfinalizer(lambda old=L.clc_set_tuning(24, 0): L.clc_set_tuning(24, old))
 
     x, refs = _inputs(dev, 2, 1)
     m_ref = _model(dev).eval()          # eval-mode rounding: deterministic (the noise proxy would need shared RNG streams)
@@ -243,7 +253,7 @@ def test_engine_equals_reference_training_loop(dev, use_graph):
         assert float(d.max()) <= 2.2 * 4 * 1e-4 * (10.0 if n.endswith(".quantiles") else 1.0), n
         n_el += d.numel()
         n_bad += int((d > 0.05 * 1e-4 * (10.0 if n.endswith(".quantiles") else 1.0)).sum())
-    assert n_bad / n_el < 5e-3, (n_bad, n_el)
+    assert n_bad / n_el < (5e-3 if wgrad_arith == "f32_mfma" else 4e-2), (n_bad, n_el)
 
 
 def test_set_lr_reaches_captured_graph(dev):
